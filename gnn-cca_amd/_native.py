@@ -1,0 +1,86 @@
+"""ctypes binding of include/gnncca_mpn.h (libgnncca_mpn.so).  No compute here and no fallback: if the library is
+missing or a call fails, the caller gets an exception."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libgnncca_mpn.so")
+
+ABI_VERSION = 1
+MAX_LAYERS = 8
+OK, ERR_INVALID_ARG, ERR_UNSUPPORTED, ERR_WORKSPACE, ERR_HIP, ERR_NO_DEVICE = range(6)
+AGG = {"sum": 0, "mean": 1, "max": 2}
+GRAPH_UNSORTED, GRAPH_BAD_INDEX = 1, 2
+
+
+class Layer(C.Structure):
+    _fields_ = [("in_dim", C.c_int32), ("out_dim", C.c_int32), ("has_bn", C.c_int32), ("relu", C.c_int32)]
+
+
+class Mlp(C.Structure):
+    _fields_ = [("n_layers", C.c_int32), ("layers", Layer * MAX_LAYERS)]
+
+
+class MpnDims(C.Structure):
+    _fields_ = [("abi_version", C.c_int32), ("node_in", C.c_int32), ("edge_in", C.c_int32), ("node_dim", C.c_int32),
+                ("edge_dim", C.c_int32), ("agg", C.c_int32), ("num_enc_steps", C.c_int32),
+                ("num_class_steps", C.c_int32), ("reattach_nodes", C.c_int32), ("reattach_edges", C.c_int32),
+                ("enc_node", Mlp), ("enc_edge", Mlp), ("edge_mlp", Mlp), ("node_mlp", Mlp), ("cls_edge", Mlp)]
+
+
+class Trace(C.Structure):
+    _fields_ = [("h_enc", C.c_void_p), ("e_enc", C.c_void_p), ("h_steps", C.c_void_p), ("e_steps", C.c_void_p)]
+
+
+_SIGNATURES = {
+    "gnncca_abi_version": (C.c_int, []),
+    "gnncca_status_string": (C.c_char_p, [C.c_int]),
+    "gnncca_last_hip_error": (C.c_int, []),
+    "gnncca_param_count": (C.c_int, [C.POINTER(MpnDims)]),
+    "gnncca_packed_weights_bytes": (C.c_size_t, [C.POINTER(MpnDims)]),
+    "gnncca_pack_weights": (C.c_int, [C.POINTER(MpnDims), C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_size_t]),
+    "gnncca_workspace_bytes": (C.c_size_t, [C.POINTER(MpnDims), C.c_int64, C.c_int64]),
+    "gnncca_supported": (C.c_int, [C.POINTER(MpnDims)]),
+    "gnncca_num_outputs": (C.c_int, [C.POINTER(MpnDims)]),
+    "gnncca_mpn_forward": (C.c_int, [C.POINTER(MpnDims), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                     C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(Trace), C.c_void_p]),
+    "gnncca_read_graph_flags": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.c_void_p]),
+}
+
+_lib = None
+
+
+class NativeError(RuntimeError):
+    """A libgnncca_mpn call returned a non-zero status (the int status of SURVEY.md 8b, as a RuntimeError)."""
+
+
+def exported_symbols():
+    return sorted(_SIGNATURES)
+
+
+def lib():
+    """Load libgnncca_mpn.so (once).  Raises if it has not been built: there is no other compute path."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NativeError(f"{LIB_PATH} is missing: build it with `python gnn-cca_amd/build.py` "
+                              "(the MI355X HIP path is the only implementation; there is no CPU fallback)")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if the .so does not export a declared symbol
+            fn.restype, fn.argtypes = res, args
+        if handle.gnncca_abi_version() != ABI_VERSION:
+            raise NativeError("libgnncca_mpn.so ABI version mismatch; rebuild")
+        _lib = handle
+    return _lib
+
+
+def check(status, what):
+    if status != OK:
+        l = lib()
+        msg = l.gnncca_status_string(status).decode()
+        if status == ERR_HIP:
+            msg += f" (hipError_t {l.gnncca_last_hip_error()})"
+        if status == ERR_UNSUPPORTED:
+            raise NotImplementedError(f"{what}: {msg}")
+        raise NativeError(f"{what}: {msg}")

@@ -1,0 +1,57 @@
+// internal.h -- layouts shared by the host packer (pack.cpp) and the HIP kernels (mpn_kernels.hip).
+// Not part of the public ABI (include/gnncca_mpn.h is).
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+#include "gnncca_mpn.h"
+
+namespace gnncca {
+
+constexpr uint32_t kBlobMagic = 0x4D504E31u;  // "MPN1"
+constexpr int kH = 32;        // node latent width the MFMA step kernel is built for (node_out_dim)
+constexpr int kEF = 6;        // edge latent width (edge_out_dim): 3 k-steps of v_mfma_f32_32x32x2_f32
+constexpr int kProjOut = 48;  // per-node projection slots: [0,6) P_dst, [8,14) P_src+b_e, [16,48) Q+b_n
+constexpr int kPdStride = 8;  // floats per node in the P_dst gather table (32 B rows)
+constexpr int kPsQStride = 40;  // floats per node in the (P_src | Q) table: slots 8..47 of the projection
+constexpr int kMaxCls = 8;    // widest hidden layer of the edge classifier handled in registers
+constexpr int kMaxEdgeIn = 16;
+
+// Families of GRAPH_NET_PARAMS this build has kernels for.
+enum Family : uint32_t {
+    kFamilyNone = 0,
+    kFamilyMfma32x6 = 1,  // H = 32, EF = 6, single-layer edge/node MLPs (both shipped configs)
+};
+
+// Header of the packed weight blob.  All offsets are in floats from the start of the blob and are
+// multiples of 4 (16-byte aligned).  BatchNorm (eval) is already folded into weight and bias.
+struct BlobHeader {
+    uint32_t magic, abi_version, family, total_floats;
+    int32_t enc_node_layers;
+    int32_t enc_node_w[GNNCCA_MAX_LAYERS];  // [out][in] row-major
+    int32_t enc_node_b[GNNCCA_MAX_LAYERS];  // [out]
+    int32_t enc_last_wT;                    // last encoder layer transposed: [in][32]
+    int32_t enc_edge_w, enc_edge_b;         // [6][edge_in], [6]
+    int32_t wee;                            // [6][ef*6]   edge-feature block of the edge MLP
+    int32_t wne_b;                          // [3][64]     MFMA B operand: Wne[lane&31][2s + (lane>>5)]
+    int32_t proj_wT;                        // [nf*32][48] per-node projection, transposed
+    int32_t proj_b;                         // [48]        biases b_e (slots 8..13) and b_n (16..47)
+    int32_t cls_layers, cls_hidden;         // 1: Linear(6,1);  2: Linear(6,C1)+ReLU, Linear(C1,1)
+    int32_t cls_w1, cls_b1, cls_w2, cls_b2;
+    int32_t pad[8];
+};
+
+Family classify(const gnncca_mpn_dims* d);
+bool blob_header(const gnncca_mpn_dims* d, BlobHeader* out);  // false if unsupported
+bool dims_valid(const gnncca_mpn_dims* d);
+int mlp_param_count(const gnncca_mlp& m);
+
+// Workspace carve-up (byte offsets, all multiples of 256).
+struct Workspace {
+    size_t flags, seg_ptr, col32, perm, cursor, h0, act, partial, pd[2], psq[2], e, e0, total;
+    int ksplit;        // split-K factor of the first encoder GEMM
+    int64_t e_stride;  // floats between two feature planes of the edge state
+};
+Workspace carve(const gnncca_mpn_dims* d, int64_t n, int64_t e);
+
+}  // namespace gnncca

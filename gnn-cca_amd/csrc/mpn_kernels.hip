@@ -1,0 +1,752 @@
+// mpn_kernels.hip -- gfx950 (MI355X / CDNA4) kernels and the C-ABI forward of the GNN-CCA message-passing path.
+//
+// Algebra (derived from models/mpn.py:48,68-69,97-99): with the edge-MLP weight split by the
+// cat order [x[row] | x[col] | e] and the node-MLP weight by [x[row] | e'],
+//     P_src = h W_src^T + b_e,  P_dst = h W_dst^T,  Q = h W_nx^T + b_n            (per node, tiny)
+//     e'[k] = ReLU(P_src[row k] + P_dst[col k] + W_ee e[k])                         (per edge, VALU)
+//     m[k]  = ReLU(Q[row k] + W_ne e'[k])                                           (per edge, MFMA 32x32x2 f32)
+//     h'[i] = agg_{k : row k = i} m[k]                                              (in-register, per segment)
+// so no [E,70] / [E,38] concatenation is ever materialised.  The aggregation index is `row` (the SOURCE node),
+// exactly as the reference does it (mpn.py:99).
+//
+// Data layout in HBM (all fp32):
+//   edge state   e      : 6 feature planes [6][E_pad]  in ROW-SORTED edge order  -> coalesced 256-B wave loads
+//   gather table Pd     : [N][8]   (P_dst, 32-B rows)                             -> L1/L2-resident random reads
+//   segment table PsQ   : [N][40]  (P_src | pad | Q)                              -> wave-uniform reads
+//   topology     seg_ptr: [N+1] int32 CSR offsets by source node;  col32 [E] int32 (sorted order)
+// One wave owns (a share of) one source node's contiguous edge segment, so the per-destination reduction needs
+// no atomics and is bitwise reproducible.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+#include "internal.h"
+
+namespace gnncca {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+static thread_local int g_last_hip_error = 0;
+
+#define HIP_TRY(expr)                                  \
+    do {                                               \
+        hipError_t _e = (expr);                        \
+        if (_e != hipSuccess) {                        \
+            g_last_hip_error = (int)_e;                \
+            return GNNCCA_ERR_HIP;                     \
+        }                                              \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------------------
+// Graph plan, part 1 (parallel, optimistic): validates indices, narrows `col` to int32 and builds the CSR
+// offsets assuming `row` is non-decreasing -- true for every graph the reference builds (inference.py:209-216,
+// Batch.from_data_list keeps the order).  Sets GNNCCA_GRAPH_UNSORTED otherwise; part 2 then repairs the plan.
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void plan_rows_kernel(const long long* __restrict__ ei, int E, int N,
+                                                        int* __restrict__ seg_ptr, int* __restrict__ col32,
+                                                        unsigned* __restrict__ flags) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= E) return;
+    const long long r = ei[k], c = ei[(size_t)E + k];
+    if (r < 0 || r >= N || c < 0 || c >= N) {
+        atomicOr(flags, GNNCCA_GRAPH_BAD_INDEX);
+        return;
+    }
+    col32[k] = (int)c;
+    long long rp = -1;
+    if (k > 0) {
+        rp = ei[k - 1];
+        if (rp < 0 || rp >= N) return;  // its owner raises the flag
+    }
+    if (r < rp) {
+        atomicOr(flags, GNNCCA_GRAPH_UNSORTED);
+    } else {
+        for (long long n = rp + 1; n <= r; ++n) seg_ptr[n] = k;
+    }
+    if (k == E - 1)
+        for (long long n = r + 1; n <= N; ++n) seg_ptr[n] = E;
+}
+
+// Graph plan, part 2 (one workgroup; exits at once for sorted graphs): STABLE counting sort of the edges by
+// `row`, so that every segment keeps the caller's edge order -- the order torch's CPU index_add_ (and with it
+// the reference on CPU) sums in.  Only correctness matters here: the reference never produces such graphs.
+__global__ __launch_bounds__(1024) void plan_sort_fallback_kernel(const long long* __restrict__ ei, int E, int N,
+                                                                  int* __restrict__ seg_ptr, int* __restrict__ col32,
+                                                                  int* __restrict__ perm, int* cursor,
+                                                                  const unsigned* __restrict__ flags) {
+    const unsigned fl = __hip_atomic_load(flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!(fl & GNNCCA_GRAPH_UNSORTED) || (fl & GNNCCA_GRAPH_BAD_INDEX)) return;
+    __shared__ int s_rows[1024];
+    __shared__ int s_scan[1024];
+    __shared__ int s_carry;
+    const int tid = threadIdx.x;
+    for (int n = tid; n <= N; n += 1024) __hip_atomic_store(&cursor[n], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    for (int k = tid; k < E; k += 1024) atomicAdd(&cursor[(int)ei[k]], 1);
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    // exclusive scan of the histogram -> seg_ptr; cursor[n] := seg_ptr[n]
+    for (int n0 = 0; n0 <= N; n0 += 1024) {
+        const int n = n0 + tid;
+        const int v = (n < N) ? __hip_atomic_load(&cursor[n], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+        s_scan[tid] = v;
+        __syncthreads();
+        for (int d = 1; d < 1024; d <<= 1) {
+            const int add = (tid >= d) ? s_scan[tid - d] : 0;
+            __syncthreads();
+            s_scan[tid] += add;
+            __syncthreads();
+        }
+        const int excl = s_carry + s_scan[tid] - v;
+        if (n <= N) {
+            seg_ptr[n] = excl;
+            __hip_atomic_store(&cursor[n], excl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        if (tid == 1023) s_carry += s_scan[1023];
+        __syncthreads();
+    }
+    // stable placement, 1024 edges at a time in ascending edge id
+    for (int k0 = 0; k0 < E; k0 += 1024) {
+        const int k = k0 + tid;
+        const int r = (k < E) ? (int)ei[k] : -1;
+        s_rows[tid] = r;
+        __syncthreads();
+        if (k < E) {
+            int rank = 0;
+            for (int u = 0; u < tid; ++u) rank += (s_rows[u] == r);
+            const int pos = __hip_atomic_load(&cursor[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + rank;
+            perm[pos] = k;
+            col32[pos] = (int)ei[(size_t)E + k];
+        }
+        __syncthreads();
+        if (k < E) atomicAdd(&cursor[r], 1);
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Node encoder GEMM: part[ks][M][O] = in[M][kslice ks] . W[O][kslice ks]^T with v_mfma_f32_32x32x2_f32 (exact
+// fp32 FMA chain).  One wave = 32 rows x 32 output columns; a workgroup = 4 waves = 128 columns.
+// k-permutation: within a 64-deep chunk, lane (r, h) feeds k = kc + 32h + s at MFMA step s for BOTH operands, so
+// every lane reads 128 contiguous bytes of its own row (8 x float4) and no LDS transpose is needed.
+// Split-K over blockIdx.y fills the chip when M is small (M = 256 nodes -> 8 row tiles x 32 slices).
+// Replaces the first nn.Linear of encoder.node_mlp (models/mpn.py:131 <- models/mlp.py:13).
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dense_rows_mfma_kernel(const float* __restrict__ in, const float* __restrict__ W,
+                                                              float* __restrict__ part, int M, int K, int O,
+                                                              int kslice, int vec_ok) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int row0 = blockIdx.x * 32;
+    const int ks = blockIdx.y;
+    const int col0 = (blockIdx.z * 4 + wave) * 32;
+    if (col0 >= O) return;
+    const int arow = min(row0 + r, M - 1);
+    const int wrow = min(col0 + r, O - 1);
+    const float* __restrict__ ap = in + (size_t)arow * K;
+    const float* __restrict__ wp = W + (size_t)wrow * K;
+    const int kbeg = ks * kslice;
+    const int kend = min(kbeg + kslice, K);
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int kc = kbeg; kc < kend; kc += 64) {
+        float a[32], b[32];
+        const int k0 = kc + 32 * h;
+        if (vec_ok && kc + 64 <= kend) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const f32x4 av = *reinterpret_cast<const f32x4*>(ap + k0 + 4 * j);
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(wp + k0 + 4 * j);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    a[4 * j + q] = av[q];
+                    b[4 * j + q] = bv[q];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < 32; ++s) {
+                const int k = k0 + s;
+                a[s] = (k < kend) ? ap[k] : 0.f;
+                b[s] = (k < kend) ? wp[k] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 32; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], acc, 0, 0, 0);
+    }
+    const int col = col0 + r;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int row = row0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        if (row < M && col < O) part[((size_t)ks * M + row) * O + col] = acc[i];
+    }
+}
+
+// act[M][O] = [ReLU](bias + sum_ks part[ks][M][O]) -- only for encoders deeper than two layers.
+__global__ __launch_bounds__(256) void reduce_bias_act_kernel(const float* __restrict__ part, const float* __restrict__ bias,
+                                                              float* __restrict__ act, int M, int O, int ks, int relu) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)M * O) return;
+    float v = bias[idx % O];
+    for (int s = 0; s < ks; ++s) v += part[(size_t)s * M * O + idx];
+    act[idx] = relu ? fmaxf(v, 0.f) : v;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Per-node projection for the NEXT message-passing step.  Called by one whole wave that holds the node's latent
+// h[c] in lane c (c < 32, mirrored in lanes 32..63).  Lane o < 48 produces projection slot o:
+//   [0,6) P_dst   [8,14) P_src + b_e   [16,48) Q + b_n          (weights transposed in LDS: [c][48])
+// With reattach_initial_nodes the input is cat((initial, latent)) -- initial first (models/mpn.py:285).
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void project_node(float h_latent, float h_init, bool reatt_n, const float* s_projT,
+                                             const float* __restrict__ projb, float* __restrict__ pd_row,
+                                             float* __restrict__ psq_row, int lane) {
+    const int o = min(lane, kProjOut - 1);
+    float acc = projb[o];
+    const float* w = s_projT + o;
+    if (reatt_n) {
+#pragma unroll
+        for (int c = 0; c < kH; ++c)
+            acc = fmaf(w[c * kProjOut], __int_as_float(__builtin_amdgcn_readlane(__float_as_int(h_init), c)), acc);
+        w += kH * kProjOut;
+    }
+#pragma unroll
+    for (int c = 0; c < kH; ++c)
+        acc = fmaf(w[c * kProjOut], __int_as_float(__builtin_amdgcn_readlane(__float_as_int(h_latent), c)), acc);
+    if (lane < kPdStride)
+        pd_row[lane] = acc;
+    else if (lane < kProjOut)
+        psq_row[lane - kPdStride] = acc;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Encoder tail: finishes the previous GEMM layer (sum of split-K partials in fixed order + bias + ReLU), applies
+// the last encoder layer F -> 32 (+ReLU), stores h0 and emits the step-1 projections.  One wave per node.
+// Replaces the rest of encoder.node_mlp (models/mpn.py:131) and the x[row]/x[col] gathers of step 1.
+// ------------------------------------------------------------------------------------------------------------
+struct TailParams {
+    const float* blob;
+    const float* part;
+    float* h0;
+    float* trace_h;
+    float* pd_out;
+    float* psq_out;
+    int off_prev_b, off_lastWT, off_last_b, off_projwT, off_projb;
+    int ks, F, N, has_last, relu_prev, reatt_n, hin;
+};
+
+__global__ __launch_bounds__(256) void enc_tail_kernel(const TailParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* s_proj = smem;                                    // [hin][48]
+    float* s_last = s_proj + p.hin * kProjOut;               // [F][32]   (has_last)
+    float* s_row = s_last + (p.has_last ? p.F * kH : 0);     // [4][F]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* __restrict__ blob = p.blob;
+    for (int i = tid; i < p.hin * kProjOut; i += 256) s_proj[i] = blob[p.off_projwT + i];
+    if (p.has_last)
+        for (int i = tid; i < p.F * kH; i += 256) s_last[i] = blob[p.off_lastWT + i];
+    __syncthreads();
+    const int o = lane & 31, half = lane >> 5;
+    float* rowbuf = s_row + wave * p.F;
+    for (int grp = blockIdx.x; grp * 4 < p.N; grp += gridDim.x) {
+        const int node = grp * 4 + wave;
+        const bool active = node < p.N;
+        if (active) {
+            for (int f = lane; f < p.F; f += 64) {
+                float v = blob[p.off_prev_b + f];
+                for (int s = 0; s < p.ks; ++s) v += p.part[((size_t)s * p.N + node) * p.F + f];
+                rowbuf[f] = p.relu_prev ? fmaxf(v, 0.f) : v;
+            }
+        }
+        __syncthreads();
+        float hv = 0.f;
+        if (active) {
+            if (p.has_last) {
+                float acc = 0.f;
+                for (int f = half; f < p.F; f += 2) acc = fmaf(rowbuf[f], s_last[f * kH + o], acc);
+                acc += __shfl_xor(acc, 32);
+                hv = fmaxf(acc + blob[p.off_last_b + o], 0.f);
+            } else {
+                hv = rowbuf[o];
+            }
+            if (lane < kH) {
+                p.h0[(size_t)node * kH + lane] = hv;
+                if (p.trace_h) p.trace_h[(size_t)node * kH + lane] = hv;
+            }
+            project_node(hv, hv, p.reatt_n != 0, s_proj, blob + p.off_projb, p.pd_out + (size_t)node * kPdStride,
+                         p.psq_out + (size_t)node * kPsQStride, lane);
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// One message-passing step (MetaLayer.forward, models/mpn.py:32-54) fused with the edge encoder on step 1
+// (mpn.py:137) and the edge classifier on classifying steps (mpn.py:290-293).
+//
+// Work split: a source node's edge segment is owned by `wps` (1, 2 or 4) waves of one workgroup; a wave walks
+// its share in chunks of 64 edges (lane = edge).  Per chunk:
+//   VALU : e' = ReLU(P_src[node] + P_dst[col] + W_ee e)           6 x (2 + 6|12) FMAs per edge
+//          classifier logit (6 -> C1 -> 1) on classifying steps
+//   MFMA : two 32-edge tiles, D[edge][channel] = Q[node][channel] + sum_k e'[edge][k] Wne[channel][k] as three
+//          v_mfma_f32_32x32x2_f32 each (K = 6 exactly, 32 channels = one tile: no padding waste).  The A operand
+//          (edge-major) comes straight from the VALU registers through one v_permlane32_swap per feature pair.
+//   the accumulator layout puts the CHANNEL on the lane and the 32 edges of a tile in registers/half-waves, so
+//   the per-source reduction is 16 in-register adds + one cross-half add: no atomics, no LDS, fixed order.
+// After its segment a wave group reduces across its waves through LDS and projects h' for the next step.
+// ------------------------------------------------------------------------------------------------------------
+struct StepParams {
+    const float* blob;
+    const int* seg_ptr;
+    const int* col32;
+    const int* perm;
+    const unsigned* flags;
+    const float* edge_attr;
+    float* e;
+    float* e0;
+    const float* pd_in;
+    const float* psq_in;
+    float* pd_out;
+    float* psq_out;
+    const float* h0;
+    float* trace_h;
+    float* trace_e;
+    float* trace_e_enc;
+    float* logits;
+    long long e_stride;
+    int off_wee, off_wneb, off_projwT, off_projb, off_encw, off_encb, off_cw1, off_cb1, off_cw2, off_cb2;
+    int cls_layers, cls_hidden;  // cls_layers == 0: this step does not classify
+    int N, E, edge_in, attr_vec, first, update, agg, reatt_n, wps, store_e, hin;
+};
+
+template <bool REATT_E, bool MSG>
+__global__ __launch_bounds__(256) void mpn_step_kernel(const StepParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int EFIN = REATT_E ? 2 * kEF : kEF;
+    float* s_proj = smem;                                   // [hin][48]   (MSG)
+    float* s_part = smem + (MSG ? p.hin * kProjOut : 0);    // [4][32]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const float* __restrict__ blob = p.blob;
+    const unsigned gflags = p.flags[0];
+    if (gflags & GNNCCA_GRAPH_BAD_INDEX) {  // poisoned graph: make the failure visible in the outputs
+        if (p.logits)
+            for (size_t k = (size_t)blockIdx.x * 256 + tid; k < (size_t)p.E; k += (size_t)gridDim.x * 256)
+                p.logits[k] = __builtin_nanf("");
+        return;
+    }
+    const bool unsorted = (gflags & GNNCCA_GRAPH_UNSORTED) != 0;
+    if (MSG) {
+        for (int i = tid; i < p.hin * kProjOut; i += 256) s_proj[i] = blob[p.off_projwT + i];
+        __syncthreads();
+    }
+    const int wps = p.wps;
+    const int node = blockIdx.x * (4 / wps) + wave / wps;
+    const int sub = wave % wps;
+    const bool active = node < p.N;
+    int seg_s = 0, seg_t = 0;
+    if (active) {
+        seg_s = p.seg_ptr[node];
+        seg_t = p.seg_ptr[node + 1];
+    }
+    const int half = lane >> 5, ch = lane & 31;
+
+    float psrc[kEF];
+    float cinit = 0.f;
+    float bw[3] = {0.f, 0.f, 0.f};
+    if (active) {
+        const float* __restrict__ psq = p.psq_in + (size_t)node * kPsQStride;
+#pragma unroll
+        for (int f = 0; f < kEF; ++f) psrc[f] = p.update ? psq[f] : 0.f;
+        if (MSG) {
+            cinit = psq[8 + ch];
+#pragma unroll
+            for (int s = 0; s < 3; ++s) bw[s] = blob[p.off_wneb + s * 64 + lane];
+        }
+    }
+    const bool agg_max = p.agg == GNNCCA_AGG_MAX;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = agg_max ? -INFINITY : 0.f;
+
+    const float* __restrict__ wee = blob + p.off_wee;
+    for (int base = seg_s + 64 * sub; base < seg_t; base += 64 * wps) {
+        const int k = base + lane;
+        const bool valid = k < seg_t;
+        const int kk = valid ? k : seg_t - 1;
+        const int ko = unsorted ? p.perm[kk] : kk;  // the caller's edge id
+        float ein[EFIN];
+        if (p.first) {
+            // edge encoder: Linear(edge_in, 6) + ReLU on data.edge_attr (models/mpn.py:137)
+            float a[kMaxEdgeIn];
+            const float* __restrict__ ap = p.edge_attr + (size_t)ko * p.edge_in;
+            if (p.attr_vec) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(ap);
+                a[0] = v[0], a[1] = v[1], a[2] = v[2], a[3] = v[3];
+            } else {
+                for (int j = 0; j < p.edge_in; ++j) a[j] = ap[j];
+            }
+            float e0v[kEF];
+#pragma unroll
+            for (int f = 0; f < kEF; ++f) {
+                float s = blob[p.off_encb + f];
+                if (p.attr_vec) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) s = fmaf(blob[p.off_encw + f * 4 + j], a[j], s);
+                } else {
+                    for (int j = 0; j < p.edge_in; ++j) s = fmaf(blob[p.off_encw + f * p.edge_in + j], a[j], s);
+                }
+                e0v[f] = fmaxf(s, 0.f);
+            }
+#pragma unroll
+            for (int f = 0; f < kEF; ++f) {
+                ein[f] = e0v[f];
+                if (REATT_E) {
+                    ein[kEF + f] = e0v[f];  // cat((initial, latent)) with latent == initial on step 1 (mpn.py:283)
+                    if (valid) p.e0[(size_t)f * p.e_stride + k] = e0v[f];
+                }
+                if (p.trace_e_enc && valid) p.trace_e_enc[(size_t)ko * kEF + f] = e0v[f];
+            }
+        } else {
+#pragma unroll
+            for (int f = 0; f < kEF; ++f) {
+                if (REATT_E) {
+                    ein[f] = p.e0[(size_t)f * p.e_stride + kk];
+                    ein[kEF + f] = p.e[(size_t)f * p.e_stride + kk];
+                } else {
+                    ein[f] = p.e[(size_t)f * p.e_stride + kk];
+                }
+            }
+        }
+        float en[kEF];
+        if (p.update) {
+            // edge update: ReLU(W_e . cat(x[row], x[col], e) + b_e)   (models/mpn.py:48, 68-69)
+            const int j = p.col32[kk];
+            const float* __restrict__ pdj = p.pd_in + (size_t)j * kPdStride;
+            const f32x4 pd0 = *reinterpret_cast<const f32x4*>(pdj);
+            const f32x2 pd1 = *reinterpret_cast<const f32x2*>(pdj + 4);
+            const float pd[kEF] = {pd0[0], pd0[1], pd0[2], pd0[3], pd1[0], pd1[1]};
+#pragma unroll
+            for (int f = 0; f < kEF; ++f) {
+                float s = psrc[f] + pd[f];
+#pragma unroll
+                for (int g = 0; g < EFIN; ++g) s = fmaf(wee[f * EFIN + g], ein[g], s);
+                en[f] = fmaxf(s, 0.f);
+            }
+        } else {
+#pragma unroll
+            for (int f = 0; f < kEF; ++f) en[f] = ein[EFIN - kEF + f];
+        }
+        if (valid) {
+            if (p.store_e) {
+#pragma unroll
+                for (int f = 0; f < kEF; ++f) p.e[(size_t)f * p.e_stride + k] = en[f];
+            }
+            if (p.trace_e) {
+#pragma unroll
+                for (int f = 0; f < kEF; ++f) p.trace_e[(size_t)ko * kEF + f] = en[f];
+            }
+        }
+        if (p.cls_layers != 0) {
+            // classifier.edge_mlp (models/mpn.py:292): Linear(6,C1) [BN folded] ReLU Linear(C1,1), or Linear(6,1)
+            float logit;
+            if (p.cls_layers == 2) {
+                logit = blob[p.off_cb2];
+                for (int q = 0; q < p.cls_hidden; ++q) {
+                    float z = blob[p.off_cb1 + q];
+#pragma unroll
+                    for (int f = 0; f < kEF; ++f) z = fmaf(blob[p.off_cw1 + q * kEF + f], en[f], z);
+                    logit = fmaf(blob[p.off_cw2 + q], fmaxf(z, 0.f), logit);
+                }
+            } else {
+                logit = blob[p.off_cb1];
+#pragma unroll
+                for (int f = 0; f < kEF; ++f) logit = fmaf(blob[p.off_cw1 + f], en[f], logit);
+            }
+            if (valid) p.logits[ko] = logit;
+        }
+        if (MSG) {
+            // node message: ReLU(W_n . cat(x[row], e') + b_n)   (models/mpn.py:97-98), 64 edges x 32 channels
+            f32x16 d0, d1;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) d0[i] = d1[i] = cinit;
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                // lanes = edges.  After the swap: r[0] = A operand of tile 0 (edges 0..31), r[1] = of tile 1.
+                const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(en[2 * s]), __float_as_uint(en[2 * s + 1]),
+                                                                false, false);
+                d0 = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(r[0]), bw[s], d0, 0, 0, 0);
+                d1 = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(r[1]), bw[s], d1, 0, 0, 0);
+            }
+            // accumulator register i of lane (ch, half) is edge (i&3) + 8*(i>>2) + 4*half of the tile
+            if (base + 64 <= seg_t) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float m0 = fmaxf(d0[i], 0.f), m1 = fmaxf(d1[i], 0.f);
+                    acc[i] = agg_max ? fmaxf(acc[i], fmaxf(m0, m1)) : acc[i] + (m0 + m1);
+                }
+            } else {
+                const int rem = seg_t - base - 4 * half;
+                const float ident = agg_max ? -INFINITY : 0.f;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int eo = (i & 3) + 8 * (i >> 2);
+                    const float m0 = (eo < rem) ? fmaxf(d0[i], 0.f) : ident;
+                    const float m1 = (eo + 32 < rem) ? fmaxf(d1[i], 0.f) : ident;
+                    acc[i] = agg_max ? fmaxf(acc[i], fmaxf(m0, m1)) : acc[i] + (m0 + m1);
+                }
+            }
+        }
+    }
+
+    if (MSG) {
+        // aggregate by SOURCE node (models/mpn.py:99, 192-202): registers -> half-waves -> waves of the group
+        float v;
+        if (agg_max) {
+            v = acc[0];
+#pragma unroll
+            for (int i = 1; i < 16; ++i) v = fmaxf(v, acc[i]);
+            v = fmaxf(v, __shfl_xor(v, 32));
+        } else {
+            v = acc[0];
+#pragma unroll
+            for (int i = 1; i < 16; ++i) v += acc[i];
+            v += __shfl_xor(v, 32);
+        }
+        if (wps > 1) {
+            if (lane < kH) s_part[wave * kH + lane] = v;
+            __syncthreads();
+            if (sub == 0) {
+                const int w0 = wave;
+                v = s_part[w0 * kH + ch];
+                for (int u = 1; u < wps; ++u) {
+                    const float o = s_part[(w0 + u) * kH + ch];
+                    v = agg_max ? fmaxf(v, o) : v + o;
+                }
+            }
+        }
+        if (active && sub == 0) {
+            const int deg = seg_t - seg_s;
+            if (p.agg == GNNCCA_AGG_MEAN) v = v / (float)max(deg, 1);  // scatter_mean: count clamped to 1
+            if (deg == 0) v = 0.f;                                      // rows that receive nothing are 0
+            if (p.trace_h && lane < kH) p.trace_h[(size_t)node * kH + lane] = v;
+            if (p.pd_out) {
+                const float hi = p.reatt_n ? p.h0[(size_t)node * kH + ch] : 0.f;
+                project_node(v, hi, p.reatt_n != 0, s_proj, blob + p.off_projb, p.pd_out + (size_t)node * kPdStride,
+                             p.psq_out + (size_t)node * kPsQStride, lane);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+static inline dim3 grid1(size_t n, int b) { return dim3((unsigned)((n + b - 1) / b)); }
+
+template <bool RE, bool MSG>
+static hipError_t launch_step(const StepParams& sp, hipStream_t st) {
+    const int npg = 4 / sp.wps;
+    const unsigned blocks = (unsigned)((sp.N + npg - 1) / npg);
+    const size_t lds = ((MSG ? (size_t)sp.hin * kProjOut : 0) + 4 * kH) * sizeof(float);
+    hipLaunchKernelGGL((mpn_step_kernel<RE, MSG>), dim3(blocks), dim3(256), lds, st, sp);
+    return hipGetLastError();
+}
+
+}  // namespace gnncca
+
+using namespace gnncca;
+
+extern "C" {
+
+int gnncca_last_hip_error(void) { return g_last_hip_error; }
+
+int gnncca_read_graph_flags(const void* workspace, uint32_t* flags_out, gnncca_stream_t stream) {
+    if (!workspace || !flags_out) return GNNCCA_ERR_INVALID_ARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    HIP_TRY(hipMemcpyAsync(flags_out, workspace, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return GNNCCA_OK;
+}
+
+int gnncca_mpn_forward(const gnncca_mpn_dims* d, const void* packed_dev, const float* x, const int64_t* edge_index,
+                       const float* edge_attr, int64_t n_nodes, int64_t n_edges, void* workspace, size_t workspace_bytes,
+                       float* logits_out, const gnncca_trace* trace, gnncca_stream_t stream) {
+    if (!dims_valid(d) || n_nodes < 0 || n_edges < 0) return GNNCCA_ERR_INVALID_ARG;
+    if (classify(d) == kFamilyNone) return GNNCCA_ERR_UNSUPPORTED;
+    if (n_nodes >= (1ll << 31) - 64 || n_edges >= (1ll << 31) - 64) return GNNCCA_ERR_UNSUPPORTED;
+    if (n_nodes == 0) return n_edges == 0 ? GNNCCA_OK : GNNCCA_ERR_INVALID_ARG;
+    if (!packed_dev || !x || !workspace) return GNNCCA_ERR_INVALID_ARG;
+    if (n_edges > 0 && (!edge_index || !edge_attr || !logits_out)) return GNNCCA_ERR_INVALID_ARG;
+    const Workspace ws = carve(d, n_nodes, n_edges);
+    if (workspace_bytes < ws.total) return GNNCCA_ERR_WORKSPACE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    char* base = static_cast<char*>(workspace);
+    const int N = (int)n_nodes, E = (int)n_edges;
+    const float* blob = static_cast<const float*>(packed_dev);
+
+    // The blob header is a pure function of dims: recompute it on the host instead of reading it back.
+    BlobHeader hdr;
+    if (!blob_header(d, &hdr)) return GNNCCA_ERR_UNSUPPORTED;
+
+    unsigned* flags = reinterpret_cast<unsigned*>(base + ws.flags);
+    int* seg_ptr = reinterpret_cast<int*>(base + ws.seg_ptr);
+    int* col32 = reinterpret_cast<int*>(base + ws.col32);
+    int* perm = reinterpret_cast<int*>(base + ws.perm);
+    int* cursor = reinterpret_cast<int*>(base + ws.cursor);
+    float* h0 = reinterpret_cast<float*>(base + ws.h0);
+    float* act = reinterpret_cast<float*>(base + ws.act);
+    float* part = reinterpret_cast<float*>(base + ws.partial);
+    float* pd[2] = {reinterpret_cast<float*>(base + ws.pd[0]), reinterpret_cast<float*>(base + ws.pd[1])};
+    float* psq[2] = {reinterpret_cast<float*>(base + ws.psq[0]), reinterpret_cast<float*>(base + ws.psq[1])};
+    float* ebuf = reinterpret_cast<float*>(base + ws.e);
+    float* e0buf = reinterpret_cast<float*>(base + ws.e0);
+
+    HIP_TRY(hipMemsetAsync(flags, 0, 256, st));
+    if (E > 0) {
+        const long long* ei = reinterpret_cast<const long long*>(edge_index);
+        hipLaunchKernelGGL(plan_rows_kernel, grid1((size_t)E, 256), dim3(256), 0, st, ei, E, N, seg_ptr, col32, flags);
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(plan_sort_fallback_kernel, dim3(1), dim3(1024), 0, st, ei, E, N, seg_ptr, col32, perm, cursor,
+                           (const unsigned*)flags);
+        HIP_TRY(hipGetLastError());
+    }
+
+    // ---- node encoder -------------------------------------------------------------------------------------
+    const int nl = d->enc_node.n_layers;
+    const int n_gemm = nl == 1 ? 1 : nl - 1;
+    const float* cur_in = x;
+    int ks_last = 1;
+    for (int g = 0; g < n_gemm; ++g) {
+        const gnncca_layer& l = d->enc_node.layers[g];
+        const int K = l.in_dim, O = l.out_dim;
+        const int ks = g == 0 ? ws.ksplit : 1;
+        int kslice = (K + ks - 1) / ks;
+        kslice = (kslice + 63) / 64 * 64;
+        const int vec_ok = (K % 4 == 0) && ((reinterpret_cast<uintptr_t>(cur_in) & 15) == 0);
+        dim3 grid((N + 31) / 32, ks, (O + 127) / 128);
+        hipLaunchKernelGGL(dense_rows_mfma_kernel, grid, dim3(256), 0, st, cur_in, blob + hdr.enc_node_w[g], part, N, K, O,
+                           kslice, vec_ok);
+        HIP_TRY(hipGetLastError());
+        ks_last = ks;
+        if (g < n_gemm - 1) {
+            float* dst = act + (size_t)(g & 1) * N * O;
+            hipLaunchKernelGGL(reduce_bias_act_kernel, grid1((size_t)N * O, 256), dim3(256), 0, st, (const float*)part,
+                               blob + hdr.enc_node_b[g], dst, N, O, ks, l.relu);
+            HIP_TRY(hipGetLastError());
+            cur_in = dst;
+        }
+    }
+    const int nf = d->reattach_nodes ? 2 : 1;
+    const int hin = nf * kH;
+    {
+        const gnncca_layer& lprev = d->enc_node.layers[n_gemm - 1];
+        TailParams tp;
+        std::memset(&tp, 0, sizeof(tp));
+        tp.blob = blob;
+        tp.part = part;
+        tp.h0 = h0;
+        tp.trace_h = trace ? trace->h_enc : nullptr;
+        tp.pd_out = pd[0];
+        tp.psq_out = psq[0];
+        tp.off_prev_b = hdr.enc_node_b[n_gemm - 1];
+        tp.off_lastWT = hdr.enc_last_wT;
+        tp.off_last_b = hdr.enc_node_b[nl - 1];
+        tp.off_projwT = hdr.proj_wT;
+        tp.off_projb = hdr.proj_b;
+        tp.ks = ks_last;
+        tp.F = lprev.out_dim;
+        tp.N = N;
+        tp.has_last = nl >= 2;
+        tp.relu_prev = lprev.relu;
+        tp.reatt_n = d->reattach_nodes;
+        tp.hin = hin;
+        const size_t lds = ((size_t)hin * kProjOut + (tp.has_last ? (size_t)tp.F * kH : 0) + 4 * (size_t)tp.F) * sizeof(float);
+        if (lds > 160 * 1024) return GNNCCA_ERR_UNSUPPORTED;
+        if (lds > 64 * 1024)
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(enc_tail_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const unsigned blocks = (unsigned)std::min<size_t>(((size_t)N + 3) / 4, 2048);
+        hipLaunchKernelGGL(enc_tail_kernel, dim3(blocks), dim3(256), lds, st, tp);
+        HIP_TRY(hipGetLastError());
+    }
+    if (E == 0) return GNNCCA_OK;
+
+    // ---- message passing steps ----------------------------------------------------------------------------
+    const int L = d->num_enc_steps;
+    const int first_cls = L - d->num_class_steps + 1;  // models/mpn.py:277
+    const long long avg_deg = (E + (long long)N - 1) / N;
+    const int chunks = (int)((avg_deg + 63) / 64);
+    StepParams sp;
+    std::memset(&sp, 0, sizeof(sp));
+    sp.blob = blob;
+    sp.seg_ptr = seg_ptr;
+    sp.col32 = col32;
+    sp.perm = perm;
+    sp.flags = flags;
+    sp.edge_attr = edge_attr;
+    sp.e = ebuf;
+    sp.e0 = e0buf;
+    sp.h0 = h0;
+    sp.e_stride = ws.e_stride;
+    sp.off_wee = hdr.wee;
+    sp.off_wneb = hdr.wne_b;
+    sp.off_projwT = hdr.proj_wT;
+    sp.off_projb = hdr.proj_b;
+    sp.off_encw = hdr.enc_edge_w;
+    sp.off_encb = hdr.enc_edge_b;
+    sp.off_cw1 = hdr.cls_w1;
+    sp.off_cb1 = hdr.cls_b1;
+    sp.off_cw2 = hdr.cls_w2;
+    sp.off_cb2 = hdr.cls_b2;
+    sp.cls_hidden = hdr.cls_hidden;
+    sp.N = N;
+    sp.E = E;
+    sp.edge_in = d->edge_in;
+    sp.attr_vec = d->edge_in == 4 && (reinterpret_cast<uintptr_t>(edge_attr) & 15) == 0;
+    sp.agg = d->agg;
+    sp.reatt_n = d->reattach_nodes;
+    sp.wps = chunks >= 4 ? 4 : (chunks >= 2 ? 2 : 1);
+    sp.hin = hin;
+    const bool re = d->reattach_edges != 0;
+    int out_idx = 0;
+    if (L == 0) {  // models/mpn.py:295-297: classify the encoded edge features once
+        sp.first = 1;
+        sp.update = 0;
+        sp.cls_layers = hdr.cls_layers;
+        sp.logits = logits_out;
+        sp.trace_e_enc = trace ? trace->e_enc : nullptr;
+        HIP_TRY(re ? (launch_step<true, false>(sp, st)) : (launch_step<false, false>(sp, st)));
+        return GNNCCA_OK;
+    }
+    for (int step = 1; step <= L; ++step) {
+        const bool want_h = trace && trace->h_steps;
+        const bool msg = step < L || want_h;
+        sp.first = step == 1;
+        sp.update = 1;
+        sp.store_e = step < L;
+        sp.cls_layers = step >= first_cls ? hdr.cls_layers : 0;
+        sp.logits = step >= first_cls ? logits_out + (size_t)(out_idx++) * E : nullptr;
+        sp.pd_in = pd[(step - 1) & 1];
+        sp.psq_in = psq[(step - 1) & 1];
+        sp.pd_out = step < L ? pd[step & 1] : nullptr;
+        sp.psq_out = step < L ? psq[step & 1] : nullptr;
+        sp.trace_e_enc = (trace && step == 1) ? trace->e_enc : nullptr;
+        sp.trace_e = (trace && trace->e_steps) ? trace->e_steps + (size_t)(step - 1) * E * kEF : nullptr;
+        sp.trace_h = want_h ? trace->h_steps + (size_t)(step - 1) * N * kH : nullptr;
+        hipError_t err;
+        if (re)
+            err = msg ? launch_step<true, true>(sp, st) : launch_step<true, false>(sp, st);
+        else
+            err = msg ? launch_step<false, true>(sp, st) : launch_step<false, false>(sp, st);
+        HIP_TRY(err);
+    }
+    return GNNCCA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,312 @@
+// pack.cpp -- host side of libgnncca_mpn: dims validation, weight packing, workspace carve-up.
+// Pure C++ (no HIP calls): testable on a machine without a GPU.
+//
+// What the packing does, with the reference lines it derives from:
+//   * eval-mode BatchNorm1d (models/mlp.py:14-15) is folded into the preceding Linear:
+//       y = ((W x + b) - mean) / sqrt(var + 1e-5) * gamma + beta  ==  (s.W) x + ((b - mean) s + beta),
+//       s = gamma / sqrt(var + 1e-5)                       (computed in double, rounded once to fp32)
+//   * the edge MLP weight [EF][nf*2H + ef*EF] is split by the cat order of models/mpn.py:68
+//       [ x[row] | x[col] | edge_attr ]  ->  W_src, W_dst (per-node projections) and W_ee (per edge)
+//   * the node MLP weight [H][nf*H + EF] is split by the cat order of models/mpn.py:97
+//       [ x[row] | edge_attr ]           ->  W_nx (per-node projection Q) and W_ne (per edge, MFMA B operand)
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "internal.h"
+
+namespace gnncca {
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+int mlp_param_count(const gnncca_mlp& m) {
+    int n = 0;
+    for (int i = 0; i < m.n_layers; ++i) n += 2 + (m.layers[i].has_bn ? 4 : 0);
+    return n;
+}
+
+static bool mlp_chain_ok(const gnncca_mlp& m, int in_dim, int out_dim) {
+    if (m.n_layers < 0 || m.n_layers > GNNCCA_MAX_LAYERS) return false;
+    if (m.n_layers == 0) return in_dim == out_dim;
+    int cur = in_dim;
+    for (int i = 0; i < m.n_layers; ++i) {
+        const gnncca_layer& l = m.layers[i];
+        if (l.in_dim != cur || l.out_dim <= 0) return false;
+        if ((l.relu != 0) != (l.out_dim != 1)) return false;  // models/mlp.py:17
+        if (l.has_bn && l.out_dim == 1) return false;         // models/mlp.py:14
+        cur = l.out_dim;
+    }
+    return cur == out_dim;
+}
+
+bool dims_valid(const gnncca_mpn_dims* d) {
+    if (!d || d->abi_version != GNNCCA_ABI_VERSION) return false;
+    if (d->node_in <= 0 || d->edge_in <= 0 || d->node_dim <= 0 || d->edge_dim <= 0) return false;
+    if (d->agg < GNNCCA_AGG_SUM || d->agg > GNNCCA_AGG_MAX) return false;
+    if (d->num_enc_steps < 0) return false;
+    const int nf = d->reattach_nodes ? 2 : 1, ef = d->reattach_edges ? 2 : 1;
+    if (!mlp_chain_ok(d->enc_node, d->node_in, d->node_dim)) return false;
+    if (!mlp_chain_ok(d->enc_edge, d->edge_in, d->edge_dim)) return false;
+    if (d->edge_mlp.n_layers < 1 || d->node_mlp.n_layers < 1 || d->cls_edge.n_layers < 1) return false;
+    if (!mlp_chain_ok(d->edge_mlp, nf * 2 * d->node_dim + ef * d->edge_dim, d->edge_dim)) return false;  // mpn.py:213
+    if (!mlp_chain_ok(d->node_mlp, nf * d->node_dim + d->edge_dim, d->node_dim)) return false;           // mpn.py:215
+    if (!mlp_chain_ok(d->cls_edge, d->edge_dim, 1)) return false;
+    return true;
+}
+
+Family classify(const gnncca_mpn_dims* d) {
+    if (!dims_valid(d)) return kFamilyNone;
+    if (d->node_dim != kH || d->edge_dim != kEF) return kFamilyNone;
+    if (d->edge_in > kMaxEdgeIn) return kFamilyNone;
+    if (d->enc_edge.n_layers != 1 || d->edge_mlp.n_layers != 1 || d->node_mlp.n_layers != 1) return kFamilyNone;
+    if (d->enc_node.n_layers < 1) return kFamilyNone;
+    for (int i = 0; i < d->enc_node.n_layers; ++i)
+        if (d->enc_node.layers[i].out_dim > 1024) return kFamilyNone;
+    if (d->cls_edge.n_layers > 2) return kFamilyNone;
+    if (d->cls_edge.n_layers == 2 && d->cls_edge.layers[0].out_dim > kMaxCls) return kFamilyNone;
+    return kFamilyMfma32x6;
+}
+
+// ---------------------------------------------------------------------------------------------
+struct BlobPlan {
+    BlobHeader h;
+    size_t total_floats;
+};
+
+static BlobPlan plan_blob(const gnncca_mpn_dims* d) {
+    BlobPlan p;
+    std::memset(&p, 0, sizeof(p));
+    size_t off = align_up(sizeof(BlobHeader), 16) / 4;
+    auto take = [&](size_t n) { size_t o = off; off = align_up(off + n, 4); return (int32_t)o; };
+    const int nf = d->reattach_nodes ? 2 : 1, ef = d->reattach_edges ? 2 : 1;
+    p.h.magic = kBlobMagic;
+    p.h.abi_version = GNNCCA_ABI_VERSION;
+    p.h.family = kFamilyMfma32x6;
+    p.h.enc_node_layers = d->enc_node.n_layers;
+    for (int i = 0; i < d->enc_node.n_layers; ++i) {
+        const gnncca_layer& l = d->enc_node.layers[i];
+        p.h.enc_node_w[i] = take((size_t)l.in_dim * l.out_dim);
+        p.h.enc_node_b[i] = take(l.out_dim);
+    }
+    const gnncca_layer& last = d->enc_node.layers[d->enc_node.n_layers - 1];
+    p.h.enc_last_wT = take((size_t)last.in_dim * kH);
+    p.h.enc_edge_w = take((size_t)kEF * d->edge_in);
+    p.h.enc_edge_b = take(kEF);
+    p.h.wee = take((size_t)kEF * ef * kEF);
+    p.h.wne_b = take(3 * 64);
+    p.h.proj_wT = take((size_t)nf * kH * kProjOut);
+    p.h.proj_b = take(kProjOut);
+    p.h.cls_layers = d->cls_edge.n_layers;
+    p.h.cls_hidden = d->cls_edge.n_layers == 2 ? d->cls_edge.layers[0].out_dim : 0;
+    if (d->cls_edge.n_layers == 2) {
+        p.h.cls_w1 = take((size_t)p.h.cls_hidden * kEF);
+        p.h.cls_b1 = take(p.h.cls_hidden);
+        p.h.cls_w2 = take(p.h.cls_hidden);
+        p.h.cls_b2 = take(1);
+    } else {
+        p.h.cls_w1 = take(kEF);
+        p.h.cls_b1 = take(1);
+        p.h.cls_w2 = p.h.cls_b2 = 0;
+    }
+    p.total_floats = off;
+    p.h.total_floats = (uint32_t)off;
+    return p;
+}
+
+bool blob_header(const gnncca_mpn_dims* d, BlobHeader* out) {
+    if (classify(d) == kFamilyNone || !out) return false;
+    *out = plan_blob(d).h;
+    return true;
+}
+
+// One Linear with its BatchNorm folded in: returns W' [out][in] and b' [out].
+struct Folded {
+    std::vector<float> w, b;
+    int in, out;
+};
+
+static Folded fold_layer(const gnncca_layer& l, const float* const*& cur) {
+    Folded f;
+    f.in = l.in_dim;
+    f.out = l.out_dim;
+    const float* w = *cur++;
+    const float* b = *cur++;
+    f.w.resize((size_t)l.in_dim * l.out_dim);
+    f.b.resize(l.out_dim);
+    if (!l.has_bn) {
+        std::memcpy(f.w.data(), w, f.w.size() * sizeof(float));
+        std::memcpy(f.b.data(), b, f.b.size() * sizeof(float));
+        return f;
+    }
+    const float* gamma = *cur++;
+    const float* beta = *cur++;
+    const float* mean = *cur++;
+    const float* var = *cur++;
+    for (int o = 0; o < l.out_dim; ++o) {
+        // BatchNorm1d eval, eps = 1e-5 (torch default; models/mlp.py:15)
+        const double s = (double)gamma[o] / std::sqrt((double)var[o] + 1e-5);
+        for (int i = 0; i < l.in_dim; ++i) f.w[(size_t)o * l.in_dim + i] = (float)((double)w[(size_t)o * l.in_dim + i] * s);
+        f.b[o] = (float)(((double)b[o] - (double)mean[o]) * s + (double)beta[o]);
+    }
+    return f;
+}
+
+}  // namespace gnncca
+
+using namespace gnncca;
+
+extern "C" {
+
+int gnncca_abi_version(void) { return GNNCCA_ABI_VERSION; }
+
+const char* gnncca_status_string(int status) {
+    switch (status) {
+        case GNNCCA_OK: return "ok";
+        case GNNCCA_ERR_INVALID_ARG: return "invalid argument";
+        case GNNCCA_ERR_UNSUPPORTED: return "GRAPH_NET_PARAMS not supported by this build's HIP kernels";
+        case GNNCCA_ERR_WORKSPACE: return "workspace too small";
+        case GNNCCA_ERR_HIP: return "HIP runtime error";
+        case GNNCCA_ERR_NO_DEVICE: return "no gfx950 device";
+        default: return "unknown status";
+    }
+}
+
+int gnncca_param_count(const gnncca_mpn_dims* d) {
+    if (!dims_valid(d)) return -1;
+    return mlp_param_count(d->enc_node) + mlp_param_count(d->enc_edge) + mlp_param_count(d->edge_mlp) +
+           mlp_param_count(d->node_mlp) + mlp_param_count(d->cls_edge);
+}
+
+int gnncca_supported(const gnncca_mpn_dims* d) {
+    if (!dims_valid(d)) return GNNCCA_ERR_INVALID_ARG;
+    return classify(d) == kFamilyNone ? GNNCCA_ERR_UNSUPPORTED : GNNCCA_OK;
+}
+
+int gnncca_num_outputs(const gnncca_mpn_dims* d) {
+    if (!dims_valid(d)) return -1;
+    if (d->num_enc_steps == 0) return 1;                       // mpn.py:295-297
+    const int first = d->num_enc_steps - d->num_class_steps + 1;  // mpn.py:277
+    int n = 0;
+    for (int s = 1; s <= d->num_enc_steps; ++s) n += (s >= first);
+    return n;
+}
+
+size_t gnncca_packed_weights_bytes(const gnncca_mpn_dims* d) {
+    if (classify(d) == kFamilyNone) return 0;
+    return plan_blob(d).total_floats * sizeof(float);
+}
+
+int gnncca_pack_weights(const gnncca_mpn_dims* d, const float* const* params, int n_params, void* packed_host,
+                        size_t packed_bytes) {
+    if (!dims_valid(d) || !params || !packed_host) return GNNCCA_ERR_INVALID_ARG;
+    if (classify(d) == kFamilyNone) return GNNCCA_ERR_UNSUPPORTED;
+    if (n_params != gnncca_param_count(d)) return GNNCCA_ERR_INVALID_ARG;
+    for (int i = 0; i < n_params; ++i)
+        if (!params[i]) return GNNCCA_ERR_INVALID_ARG;
+    const BlobPlan p = plan_blob(d);
+    if (packed_bytes < p.total_floats * sizeof(float)) return GNNCCA_ERR_INVALID_ARG;
+    float* blob = static_cast<float*>(packed_host);
+    std::memset(blob, 0, p.total_floats * sizeof(float));
+    std::memcpy(blob, &p.h, sizeof(BlobHeader));
+    const int nf = d->reattach_nodes ? 2 : 1, ef = d->reattach_edges ? 2 : 1;
+    const float* const* cur = params;
+
+    // encoder.node_mlp
+    for (int i = 0; i < d->enc_node.n_layers; ++i) {
+        Folded f = fold_layer(d->enc_node.layers[i], cur);
+        std::memcpy(blob + p.h.enc_node_w[i], f.w.data(), f.w.size() * sizeof(float));
+        std::memcpy(blob + p.h.enc_node_b[i], f.b.data(), f.b.size() * sizeof(float));
+        if (i == d->enc_node.n_layers - 1)
+            for (int o = 0; o < kH; ++o)
+                for (int k = 0; k < f.in; ++k) blob[p.h.enc_last_wT + (size_t)k * kH + o] = f.w[(size_t)o * f.in + k];
+    }
+    // encoder.edge_mlp
+    {
+        Folded f = fold_layer(d->enc_edge.layers[0], cur);
+        std::memcpy(blob + p.h.enc_edge_w, f.w.data(), f.w.size() * sizeof(float));
+        std::memcpy(blob + p.h.enc_edge_b, f.b.data(), f.b.size() * sizeof(float));
+    }
+    // MPNet.edge_model.edge_mlp : columns [src nf*H | dst nf*H | edge ef*EF]   (mpn.py:68)
+    const int hin = nf * kH, ein = ef * kEF;
+    float* projT = blob + p.h.proj_wT;
+    float* projb = blob + p.h.proj_b;
+    {
+        Folded f = fold_layer(d->edge_mlp.layers[0], cur);
+        const int in = f.in;  // 2*hin + ein
+        for (int o = 0; o < kEF; ++o) {
+            for (int c = 0; c < hin; ++c) {
+                projT[(size_t)c * kProjOut + 8 + o] = f.w[(size_t)o * in + c];        // P_src
+                projT[(size_t)c * kProjOut + 0 + o] = f.w[(size_t)o * in + hin + c];  // P_dst
+            }
+            for (int g = 0; g < ein; ++g) blob[p.h.wee + (size_t)o * ein + g] = f.w[(size_t)o * in + 2 * hin + g];
+            projb[8 + o] = f.b[o];
+        }
+    }
+    // MPNet.node_model.node_mlp : columns [x[row] nf*H | edge EF]                (mpn.py:97)
+    {
+        Folded f = fold_layer(d->node_mlp.layers[0], cur);
+        const int in = f.in;  // hin + EF
+        for (int o = 0; o < kH; ++o) {
+            for (int c = 0; c < hin; ++c) projT[(size_t)c * kProjOut + 16 + o] = f.w[(size_t)o * in + c];  // Q
+            projb[16 + o] = f.b[o];
+        }
+        // B operand of v_mfma_f32_32x32x2_f32, k-step s: lane l holds B[k = l>>5][j = l&31] = Wne[j][2s + k]
+        for (int s = 0; s < 3; ++s)
+            for (int l = 0; l < 64; ++l) blob[p.h.wne_b + s * 64 + l] = f.w[(size_t)(l & 31) * in + hin + 2 * s + (l >> 5)];
+    }
+    // classifier.edge_mlp
+    {
+        Folded f1 = fold_layer(d->cls_edge.layers[0], cur);
+        std::memcpy(blob + p.h.cls_w1, f1.w.data(), f1.w.size() * sizeof(float));
+        std::memcpy(blob + p.h.cls_b1, f1.b.data(), f1.b.size() * sizeof(float));
+        if (d->cls_edge.n_layers == 2) {
+            Folded f2 = fold_layer(d->cls_edge.layers[1], cur);
+            std::memcpy(blob + p.h.cls_w2, f2.w.data(), f2.w.size() * sizeof(float));
+            std::memcpy(blob + p.h.cls_b2, f2.b.data(), f2.b.size() * sizeof(float));
+        }
+    }
+    return GNNCCA_OK;
+}
+
+}  // extern "C"
+
+namespace gnncca {
+
+Workspace carve(const gnncca_mpn_dims* d, int64_t n, int64_t e) {
+    Workspace w;
+    std::memset(&w, 0, sizeof(w));
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    const size_t N = (size_t)(n > 0 ? n : 0), E = (size_t)(e > 0 ? e : 0);
+    w.e_stride = (int64_t)align_up(E > 0 ? E : 1, 64);
+    // split-K of the first (widest) encoder GEMM: enough workgroups to cover the chip when N is small
+    const int k0 = d->enc_node.layers[0].in_dim;
+    const size_t row_tiles = (N + 31) / 32;
+    int ks = 1;
+    while (ks < 32 && row_tiles * (size_t)ks < 512 && k0 / (ks * 2) >= 64) ks *= 2;
+    w.ksplit = ks;
+    size_t fmax = 0;
+    for (int i = 0; i < d->enc_node.n_layers; ++i)
+        fmax = fmax > (size_t)d->enc_node.layers[i].out_dim ? fmax : (size_t)d->enc_node.layers[i].out_dim;
+    w.flags = take(256);
+    w.seg_ptr = take((N + 1) * 4);
+    w.col32 = take(E * 4);
+    w.perm = take(E * 4);
+    w.cursor = take((N + 1) * 4);
+    w.h0 = take(N * kH * 4);
+    w.act = take(d->enc_node.n_layers >= 3 ? 2 * N * fmax * 4 : 0);
+    w.partial = take((size_t)ks * N * fmax * 4);
+    for (int i = 0; i < 2; ++i) w.pd[i] = take(N * kPdStride * 4);
+    for (int i = 0; i < 2; ++i) w.psq[i] = take(N * kPsQStride * 4);
+    w.e = take((size_t)kEF * w.e_stride * 4);
+    w.e0 = take(d->reattach_edges ? (size_t)kEF * w.e_stride * 4 : 0);
+    w.total = off;
+    return w;
+}
+
+}  // namespace gnncca
+
+extern "C" size_t gnncca_workspace_bytes(const gnncca_mpn_dims* d, int64_t n_nodes, int64_t n_edges) {
+    if (classify(d) == kFamilyNone || n_nodes < 0 || n_edges < 0) return 0;
+    return carve(d, n_nodes, n_edges).total;
+}

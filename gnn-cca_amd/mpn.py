@@ -1,0 +1,258 @@
+"""Python host side of the MI355X message-passing path: a drop-in for the reference's ``models/mpn.py``.
+
+Same names, constructor arguments, ``forward(data)`` contract and ``state_dict`` keys as
+``models/mpn.py:144-299`` (``MOTMPNet``) and its helper classes, so ``main.py`` / ``inference.py`` can call it
+unchanged (``outputs = mpn_model(data_batch)``, inference.py:283).  What differs is where the arithmetic runs:
+``forward`` packs the parameters once into an HBM blob and calls ``gnncca_mpn_forward`` (include/gnncca_mpn.h),
+which enqueues the hand-written gfx950 kernels on torch's current HIP stream.  torch is used for device memory,
+streams and (in sharding.py) torch.distributed only.
+
+There is deliberately no CPU / eager-torch fallback: off-GPU tensors or a missing ``libgnncca_mpn.so`` raise.
+"""
+import ctypes as C
+
+import torch
+from torch import nn
+
+from . import _native as nat
+from .mlp import MLP
+
+
+class MetaLayer(nn.Module):
+    """Container mirroring models/mpn.py:10-57 (``edge_model`` / ``node_model`` children)."""
+
+    def __init__(self, edge_model=None, node_model=None):
+        super().__init__()
+        self.edge_model = edge_model
+        self.node_model = node_model
+
+    def forward(self, x, edge_index, edge_attr):
+        raise RuntimeError("MetaLayer is a parameter container here; call MOTMPNet.forward")
+
+
+class EdgeModel(nn.Module):
+    """Container mirroring models/mpn.py:59-69: owns ``edge_mlp`` (input = cat[x[row], x[col], e])."""
+
+    def __init__(self, edge_mlp):
+        super().__init__()
+        self.edge_mlp = edge_mlp
+
+
+class NodeModel(nn.Module):
+    """Container mirroring models/mpn.py:71-101: owns ``node_mlp`` (input = cat[x[row], e']) and the name of the
+    aggregator applied over ``row``."""
+
+    def __init__(self, node_mlp, node_agg_fn):
+        super().__init__()
+        self.node_mlp = node_mlp
+        self.node_agg_fn = node_agg_fn
+
+
+class MLPGraphIndependent(nn.Module):
+    """Container mirroring models/mpn.py:103-142: an optional node MLP and an optional edge MLP."""
+
+    def __init__(self, edge_in_dim=None, node_in_dim=None, edge_out_dim=None, node_out_dim=None,
+                 node_fc_dims=None, edge_fc_dims=None, dropout_p=None, use_batchnorm=None):
+        super().__init__()
+        self.node_mlp = None
+        self.edge_mlp = None
+        if node_in_dim is not None:  # node MLP is created first (parameter-init RNG order of the reference)
+            self.node_mlp = MLP(node_in_dim, list(node_fc_dims) + [node_out_dim], dropout_p, use_batchnorm)
+        if edge_in_dim is not None:
+            self.edge_mlp = MLP(edge_in_dim, list(edge_fc_dims) + [edge_out_dim], dropout_p, use_batchnorm)
+
+
+def _fill_mlp(dst, mlp):
+    dst.n_layers = 0 if mlp is None else len(mlp.plan)
+    if dst.n_layers > nat.MAX_LAYERS:
+        raise NotImplementedError(f"MLPs deeper than {nat.MAX_LAYERS} layers are not supported")
+    for i in range(dst.n_layers):
+        fan_in, width, has_bn, relu, _ = mlp.plan[i]
+        dst.layers[i].in_dim, dst.layers[i].out_dim = fan_in, width
+        dst.layers[i].has_bn, dst.layers[i].relu = int(has_bn), int(relu)
+
+
+class MOTMPNet(nn.Module):
+    """Drop-in for models/mpn.py:144-299.
+
+    ``MOTMPNet(model_params, bb_encoder=None, arch=None)``; ``forward(data)`` reads ``data.x [N, node_in]``,
+    ``data.edge_index [2, E] int64`` and ``data.edge_attr [E, edge_in]`` and returns
+    ``{'classified_edges': [Tensor[E, 1], ...]}`` -- one tensor per classified step, last = final.
+    """
+
+    def __init__(self, model_params, bb_encoder=None, arch=None):
+        super().__init__()
+        self.node_cnn = bb_encoder  # stored and never used, as in the reference (mpn.py:163)
+        self.model_params = model_params
+
+        edges_params = model_params['encoder_feats_dict']['edges']
+        nodes_params = model_params['encoder_feats_dict']['nodes'][arch]
+        edges_params.update(nodes_params)  # in-place merge into the caller's dict, like mpn.py:167-169
+        encoder_feats_dict = edges_params
+        classifier_feats_dict = model_params['classifier_feats_dict']
+
+        self.encoder = MLPGraphIndependent(**encoder_feats_dict)
+        self.classifier = MLPGraphIndependent(**classifier_feats_dict)
+        self.MPNet = self._build_core_MPNet(model_params=model_params, encoder_feats_dict=encoder_feats_dict)
+        self.num_enc_steps = model_params['num_enc_steps']
+        self.num_class_steps = model_params['num_class_steps']
+
+        self._enc = dict(encoder_feats_dict)
+        self._dims = None          # nat.MpnDims, built lazily (needs the finished module tree)
+        self._packed = None        # (key, device blob)
+        self._workspace = None     # grow-only device scratch
+        self._weights_dirty = True
+        self.last_workspace_bytes = 0
+
+    # -- construction --------------------------------------------------------------------------------------
+    def _build_core_MPNet(self, model_params, encoder_feats_dict):
+        node_agg_fn = model_params['node_agg_fn']
+        assert node_agg_fn.lower() in ('mean', 'max', 'sum'), "node_agg_fn can only be 'max', 'mean' or 'sum'."
+        self.reattach_initial_nodes = model_params['reattach_initial_nodes']
+        self.reattach_initial_edges = model_params['reattach_initial_edges']
+        nf = 2 if self.reattach_initial_nodes else 1
+        ef = 2 if self.reattach_initial_edges else 1
+        h, f = encoder_feats_dict['node_out_dim'], encoder_feats_dict['edge_out_dim']
+        edge_cfg, node_cfg = model_params['edge_model_feats_dict'], model_params['node_model_feats_dict']
+        # widths of the concatenations at mpn.py:68 and mpn.py:97
+        edge_mlp = MLP(nf * 2 * h + ef * f, edge_cfg['fc_dims'], edge_cfg['dropout_p'], edge_cfg['use_batchnorm'])
+        node_mlp = MLP(nf * h + f, node_cfg['fc_dims'], node_cfg['dropout_p'], node_cfg['use_batchnorm'])
+        # The reference then builds an unused `node_mlp_old` Linear(2h, h) (mpn.py:241-242); it only advances
+        # the global RNG after every real parameter exists, so it is not reproduced.
+        return MetaLayer(edge_model=EdgeModel(edge_mlp), node_model=NodeModel(node_mlp, node_agg_fn.lower()))
+
+    # -- native description ----------------------------------------------------------------------------------
+    def native_dims(self):
+        if self._dims is None:
+            d = nat.MpnDims()
+            d.abi_version = nat.ABI_VERSION
+            d.node_in = self._enc['node_in_dim']
+            d.edge_in = self._enc['edge_in_dim']
+            d.node_dim = self._enc['node_out_dim']
+            d.edge_dim = self._enc['edge_out_dim']
+            d.agg = nat.AGG[self.MPNet.node_model.node_agg_fn]
+            d.num_enc_steps, d.num_class_steps = int(self.num_enc_steps), int(self.num_class_steps)
+            d.reattach_nodes, d.reattach_edges = int(self.reattach_initial_nodes), int(self.reattach_initial_edges)
+            _fill_mlp(d.enc_node, self.encoder.node_mlp)
+            _fill_mlp(d.enc_edge, self.encoder.edge_mlp)
+            _fill_mlp(d.edge_mlp, self.MPNet.edge_model.edge_mlp)
+            _fill_mlp(d.node_mlp, self.MPNet.node_model.node_mlp)
+            _fill_mlp(d.cls_edge, self.classifier.edge_mlp)
+            self._dims = d
+        return self._dims
+
+    def native_param_tensors(self):
+        out = []
+        for mlp in (self.encoder.node_mlp, self.encoder.edge_mlp, self.MPNet.edge_model.edge_mlp,
+                    self.MPNet.node_model.node_mlp, self.classifier.edge_mlp):
+            if mlp is not None:
+                out += mlp.native_params()
+        return out
+
+    # -- weight cache ----------------------------------------------------------------------------------------
+    def invalidate_packed_weights(self):
+        self._weights_dirty = True
+
+    def _apply(self, fn, *a, **k):  # .cuda() / .to() / .float()
+        self._weights_dirty = True
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._weights_dirty = True
+        return super().load_state_dict(*a, **k)
+
+    def train(self, mode=True):
+        self._weights_dirty = True  # parameters may have been updated in place while training
+        return super().train(mode)
+
+    def pack_weights_host(self):
+        """state_dict -> the packed blob of gnncca_pack_weights, as a CPU uint8 tensor (what rank 0 broadcasts)."""
+        lib, d = nat.lib(), self.native_dims()
+        nat.check(lib.gnncca_supported(C.byref(d)), "MOTMPNet configuration")
+        host = [t.detach().to("cpu", torch.float32).contiguous() for t in self.native_param_tensors()]
+        ptrs = (C.c_void_p * len(host))(*[t.data_ptr() for t in host])
+        nbytes = lib.gnncca_packed_weights_bytes(C.byref(d))
+        blob = torch.zeros(nbytes, dtype=torch.uint8)
+        nat.check(lib.gnncca_pack_weights(C.byref(d), ptrs, len(host), blob.data_ptr(), nbytes), "gnncca_pack_weights")
+        return blob
+
+    def set_packed_weights(self, blob_dev):
+        """Install an already packed (e.g. RCCL-broadcast) blob living on this module's device."""
+        self._packed = (self._version_key(), blob_dev)
+        self._weights_dirty = False
+
+    def _version_key(self):
+        return sum(t._version for t in self.native_param_tensors())
+
+    def _packed_weights(self, device):
+        if self._weights_dirty or self._packed is None or self._packed[1].device != device \
+                or self._packed[0] != self._version_key():
+            self.set_packed_weights(self.pack_weights_host().to(device))
+        return self._packed[1]
+
+    def _scratch(self, nbytes, device):
+        ws = self._workspace
+        if ws is None or ws.device != device or ws.numel() < nbytes:
+            ws = self._workspace = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=device)
+        return ws
+
+    # -- forward -----------------------------------------------------------------------------------------------
+    def forward(self, data, trace=None):
+        """See class docstring.  ``trace`` (optional dict) receives the intermediate latents for debugging."""
+        x, edge_index, edge_attr = data.x, data.edge_index, data.edge_attr
+        if self.training:
+            raise NotImplementedError(
+                "train-mode forward (batch-statistics BatchNorm + autograd through the fused kernels) is not part "
+                "of the HIP path yet (SURVEY.md 8f row N3); call .eval()")
+        if not (x.is_cuda and edge_index.is_cuda and edge_attr.is_cuda):
+            raise RuntimeError("gnn_cca_amd.MOTMPNet runs on MI355X only: move the module and `data` to the GPU "
+                               "(there is no CPU fallback)")
+        lib, d = nat.lib(), self.native_dims()
+        dev = x.device
+        if x.dtype != torch.float32 or not x.is_contiguous():
+            x = x.float().contiguous()
+        if edge_attr.dtype != torch.float32 or not edge_attr.is_contiguous():
+            edge_attr = edge_attr.float().contiguous()
+        if edge_index.dtype != torch.int64 or not edge_index.is_contiguous():
+            edge_index = edge_index.long().contiguous()
+        n, e = x.shape[0], edge_index.shape[1]
+        if x.dim() != 2 or x.shape[1] != d.node_in or edge_index.dim() != 2 or edge_index.shape[0] != 2 \
+                or edge_attr.dim() != 2 or edge_attr.shape[0] != e or edge_attr.shape[1] != d.edge_in:
+            raise RuntimeError(f"shape mismatch: x {tuple(x.shape)}, edge_index {tuple(edge_index.shape)}, "
+                               f"edge_attr {tuple(edge_attr.shape)} for node_in={d.node_in}, edge_in={d.edge_in}")
+        blob = self._packed_weights(dev)
+        n_out = lib.gnncca_num_outputs(C.byref(d))
+        logits = torch.empty((n_out, e, 1), dtype=torch.float32, device=dev)
+        if n == 0 or e == 0:
+            return {'classified_edges': list(logits.unbind(0))}
+        ws_bytes = lib.gnncca_workspace_bytes(C.byref(d), n, e)
+        if ws_bytes == 0:
+            nat.check(lib.gnncca_supported(C.byref(d)), "MOTMPNet configuration")
+        ws = self._scratch(ws_bytes, dev)
+        self.last_workspace_bytes = ws_bytes
+        tr = None
+        if trace is not None:
+            L = int(self.num_enc_steps)
+            trace['h_enc'] = torch.empty((n, d.node_dim), dtype=torch.float32, device=dev)
+            trace['e_enc'] = torch.empty((e, d.edge_dim), dtype=torch.float32, device=dev)
+            trace['h_steps'] = torch.empty((L, n, d.node_dim), dtype=torch.float32, device=dev)
+            trace['e_steps'] = torch.empty((L, e, d.edge_dim), dtype=torch.float32, device=dev)
+            tr = C.byref(nat.Trace(trace['h_enc'].data_ptr(), trace['e_enc'].data_ptr(),
+                                   trace['h_steps'].data_ptr(), trace['e_steps'].data_ptr()))
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            st = lib.gnncca_mpn_forward(C.byref(d), blob.data_ptr(), x.data_ptr(), edge_index.data_ptr(),
+                                        edge_attr.data_ptr(), n, e, ws.data_ptr(), ws.numel(), logits.data_ptr(), tr,
+                                        stream)
+        nat.check(st, "gnncca_mpn_forward")
+        return {'classified_edges': list(logits.unbind(0))}
+
+    def graph_flags(self):
+        """Synchronises and returns the flag word of the last forward (bit 0: unsorted rows, bit 1: bad index)."""
+        if self._workspace is None:
+            return 0
+        out = C.c_uint32(0)
+        dev = self._workspace.device
+        nat.check(nat.lib().gnncca_read_graph_flags(self._workspace.data_ptr(), C.byref(out),
+                                                    torch.cuda.current_stream(dev).cuda_stream), "read_graph_flags")
+        return int(out.value)

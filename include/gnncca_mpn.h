@@ -1,0 +1,145 @@
+/*
+ * gnncca_mpn.h -- C ABI of the MI355X-native GNN-CCA message-passing path (libgnncca_mpn.so).
+ *
+ * The reference (vpulab/GNN-CCA) is pure Python and has NO native/FFI layer: the
+ * interface a caller binds is the Python module surface `models.mpn.MOTMPNet` (models/mpn.py:144-299).
+ * This header is therefore the boundary *below* that module: every entry point states which piece of
+ * the reference's Python it replaces.  The Python mirror of MOTMPNet (gnn-cca_amd/mpn.py) is the only
+ * intended caller and binds these symbols with ctypes.
+ *
+ * Conventions
+ *   - plain C, no torch / HIP types in signatures; `gnncca_stream_t` is a hipStream_t passed as void*.
+ *   - all device pointers are raw HBM addresses owned by the caller; nothing is allocated or freed here.
+ *   - every function returns a gnncca_status (0 = ok).  Nothing synchronises the stream except
+ *     gnncca_read_graph_flags().  All kernels are enqueued on the given stream.
+ *   - row-major fp32 everywhere at the boundary; `edge_index` is int64 [2][E] exactly as
+ *     torch_geometric hands it to MOTMPNet.forward (models/mpn.py:266).
+ */
+#ifndef GNNCCA_MPN_H
+#define GNNCCA_MPN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GNNCCA_ABI_VERSION 1
+#define GNNCCA_MAX_LAYERS 8
+
+#if defined(GNNCCA_BUILD)
+#define GNNCCA_API __attribute__((visibility("default")))
+#else
+#define GNNCCA_API
+#endif
+
+typedef void* gnncca_stream_t;
+
+typedef enum gnncca_status {
+    GNNCCA_OK = 0,
+    GNNCCA_ERR_INVALID_ARG = 1,     /* null pointer, negative size, inconsistent dims            */
+    GNNCCA_ERR_UNSUPPORTED = 2,     /* a legal GRAPH_NET_PARAMS this build has no HIP kernel for */
+    GNNCCA_ERR_WORKSPACE = 3,       /* workspace_bytes < gnncca_workspace_bytes(...)             */
+    GNNCCA_ERR_HIP = 4,             /* a HIP runtime call failed; see gnncca_last_hip_error()    */
+    GNNCCA_ERR_NO_DEVICE = 5        /* no gfx950 device visible                                  */
+} gnncca_status;
+
+/* Aggregators of models/mpn.py:192-202 (torch_scatter scatter_add / scatter_mean / scatter_max). */
+typedef enum gnncca_agg { GNNCCA_AGG_SUM = 0, GNNCCA_AGG_MEAN = 1, GNNCCA_AGG_MAX = 2 } gnncca_agg;
+
+/* One Linear(+BatchNorm1d eval)(+ReLU) block of models/mlp.py:10-24.  Dropout is the identity in eval. */
+typedef struct gnncca_layer {
+    int32_t in_dim;
+    int32_t out_dim;
+    int32_t has_bn;   /* models/mlp.py:14  (use_batchnorm and dim != 1) */
+    int32_t relu;     /* models/mlp.py:17  (dim != 1)                   */
+} gnncca_layer;
+
+typedef struct gnncca_mlp {
+    int32_t n_layers; /* 0 = MLP absent (MLPGraphIndependent passes the input through, mpn.py:133-140) */
+    gnncca_layer layers[GNNCCA_MAX_LAYERS];
+} gnncca_mlp;
+
+/* Everything MOTMPNet.__init__ derives from GRAPH_NET_PARAMS (models/mpn.py:154-247). */
+typedef struct gnncca_mpn_dims {
+    int32_t abi_version;        /* GNNCCA_ABI_VERSION */
+    int32_t node_in;            /* encoder_feats_dict.nodes[arch].node_in_dim (2048 / 512)  */
+    int32_t edge_in;            /* encoder_feats_dict.edges.edge_in_dim (4; 2 for ONLY_*)   */
+    int32_t node_dim;           /* node_out_dim = H (32) */
+    int32_t edge_dim;           /* edge_out_dim = EF (6) */
+    int32_t agg;                /* gnncca_agg */
+    int32_t num_enc_steps;      /* L, mpn.py:179 */
+    int32_t num_class_steps;    /* mpn.py:180 */
+    int32_t reattach_nodes;     /* mpn.py:207 */
+    int32_t reattach_edges;     /* mpn.py:208 */
+    gnncca_mlp enc_node;        /* encoder.node_mlp                (mpn.py:173) */
+    gnncca_mlp enc_edge;        /* encoder.edge_mlp                              */
+    gnncca_mlp edge_mlp;        /* MPNet.edge_model.edge_mlp       (mpn.py:221) */
+    gnncca_mlp node_mlp;        /* MPNet.node_model.node_mlp       (mpn.py:236) */
+    gnncca_mlp cls_edge;        /* classifier.edge_mlp             (mpn.py:174) */
+} gnncca_mpn_dims;
+
+/* Optional debug taps (all nullable): the latents the golden vectors also hold.  Row-major fp32, edges
+ * in the caller's (original) edge order. */
+typedef struct gnncca_trace {
+    float* h_enc;    /* [N][H]       encoder node output   (mpn.py:270) */
+    float* e_enc;    /* [E][EF]      encoder edge output                */
+    float* h_steps;  /* [L][N][H]    node latents after each step (mpn.py:288) */
+    float* e_steps;  /* [L][E][EF]   edge latents after each step       */
+} gnncca_trace;
+
+/* Bits of the per-call graph flag word (device side, read back with gnncca_read_graph_flags). */
+#define GNNCCA_GRAPH_UNSORTED 1u   /* `row` was not non-decreasing: the stable device sort ran     */
+#define GNNCCA_GRAPH_BAD_INDEX 2u  /* an index outside [0,N): kernels skipped, logits set to NaN   */
+
+GNNCCA_API int gnncca_abi_version(void);
+GNNCCA_API const char* gnncca_status_string(int status);
+GNNCCA_API int gnncca_last_hip_error(void); /* hipError_t of the last failed HIP call on this thread, 0 if none */
+
+/* Number of `float*` entries gnncca_pack_weights expects, and the canonical order: for each MLP in the
+ * order enc_node, enc_edge, edge_mlp, node_mlp, cls_edge, for each layer: weight[out][in], bias[out],
+ * then if has_bn: bn_weight, bn_bias, bn_running_mean, bn_running_var (each [out]).
+ * Replaces: nothing in the reference (it keeps nn.Parameters); this is the state_dict -> HBM layout step
+ * behind MOTMPNet.load_state_dict / .cuda() (main.py:78-82). */
+GNNCCA_API int gnncca_param_count(const gnncca_mpn_dims* dims);
+
+/* Bytes of the packed weight blob. 0 on invalid dims. */
+GNNCCA_API size_t gnncca_packed_weights_bytes(const gnncca_mpn_dims* dims);
+
+/* HOST function: folds eval-mode BatchNorm into the preceding Linear, splits the MPN weights by input
+ * block ([W_src|W_dst|W_edge], [W_node|W_edge], cat order of mpn.py:68 and mpn.py:97), builds the
+ * per-node projection matrix, and writes the blob into `packed_host` (the caller uploads it, or
+ * broadcasts it to the other ranks over RCCL).  `params` are host pointers in the canonical order. */
+GNNCCA_API int gnncca_pack_weights(const gnncca_mpn_dims* dims, const float* const* params, int n_params,
+                        void* packed_host, size_t packed_bytes);
+
+/* Bytes of device scratch one forward over a graph of N nodes / E edges needs. */
+GNNCCA_API size_t gnncca_workspace_bytes(const gnncca_mpn_dims* dims, int64_t n_nodes, int64_t n_edges);
+
+/* Whether this build has HIP kernels for `dims` (GNNCCA_OK) or not (GNNCCA_ERR_UNSUPPORTED). */
+GNNCCA_API int gnncca_supported(const gnncca_mpn_dims* dims);
+
+/* Replaces MOTMPNet.forward (models/mpn.py:250-299) in eval mode: encoder (mpn.py:270), L message
+ * passing steps (MetaLayer.forward mpn.py:32-54 = EdgeModel 59-69 + NodeModel 71-101 + aggregator
+ * 192-202) and the edge classifier on the last num_class_steps steps (mpn.py:290-297).
+ *   x          [N][node_in]  fp32      data.x
+ *   edge_index [2][E]        int64     data.edge_index (any order; row-sorted graphs take the fast path)
+ *   edge_attr  [E][edge_in]  fp32      data.edge_attr
+ *   logits_out [n_out][E]    fp32      n_out = gnncca_num_outputs(dims); the list 'classified_edges'
+ * Inputs are read-only.  Asynchronous on `stream`. */
+GNNCCA_API int gnncca_mpn_forward(const gnncca_mpn_dims* dims, const void* packed_dev, const float* x,
+                       const int64_t* edge_index, const float* edge_attr, int64_t n_nodes,
+                       int64_t n_edges, void* workspace, size_t workspace_bytes, float* logits_out,
+                       const gnncca_trace* trace, gnncca_stream_t stream);
+
+/* len(outputs['classified_edges']) for these dims (mpn.py:277-297). */
+GNNCCA_API int gnncca_num_outputs(const gnncca_mpn_dims* dims);
+
+/* Synchronises `stream` and returns the flag word of the last forward that used `workspace`. */
+GNNCCA_API int gnncca_read_graph_flags(const void* workspace, uint32_t* flags_out, gnncca_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GNNCCA_MPN_H */

@@ -1,0 +1,194 @@
+"""Parity tests proper: the HIP path (through the C ABI, via gnn_cca_amd.MOTMPNet) against the golden vectors
+produced by the reference and against the CPU oracle.  GPU only (`-m gpu`)."""
+import copy
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN_DIR, golden_cases
+from oracle.mpn_oracle import NumpyOracle, load_case
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4          # BASELINE.json north_star: logits within 1e-4 of the reference CPU path (fp32)
+TOL_TIGHT = 5e-6    # what fp32 kernels actually achieve on the conditioned golden weights
+
+
+class Data:
+    def __init__(self, x, edge_index, edge_attr):
+        self.x, self.edge_index, self.edge_attr = x, edge_index, edge_attr
+
+
+def build(params, arch, sd):
+    from gnn_cca_amd import MOTMPNet
+    m = MOTMPNet(copy.deepcopy(params), None, arch)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    return m.cuda().eval()
+
+
+def supported(m):
+    import ctypes as C
+    from gnn_cca_amd import _native as nat
+    return nat.lib().gnncca_supported(C.byref(m.native_dims())) == 0
+
+
+def to_data(a):
+    return Data(torch.from_numpy(a["x"]).cuda(), torch.from_numpy(a["edge_index"]).cuda(),
+                torch.from_numpy(a["edge_attr"]).cuda())
+
+
+@pytest.mark.parametrize("name", golden_cases())
+def test_hip_matches_reference_golden(name):
+    params, arch, sd, a = load_case(os.path.join(GOLDEN_DIR, name + ".npz"))
+    m = build(params, arch, sd)
+    if not supported(m):
+        with pytest.raises(NotImplementedError):
+            with torch.no_grad():
+                m(to_data(a))
+        pytest.skip("configuration outside the kernels' family: raises NotImplementedError (no fallback)")
+    trace = {}
+    with torch.no_grad():
+        out = m(to_data(a), trace=trace)["classified_edges"]
+    torch.cuda.synchronize()
+    assert len(out) == int(a["n_logits"])
+    for i, o in enumerate(out):
+        assert tuple(o.shape) == a[f"logits_{i}"].shape
+        err = np.abs(o.cpu().numpy() - a[f"logits_{i}"]).max()
+        assert err <= TOL_TIGHT, (name, i, err)
+    # intermediate latents against the reference's own (debug taps)
+    assert np.abs(trace["h_enc"].cpu().numpy() - a["h_enc"]).max() <= TOL_TIGHT
+    assert np.abs(trace["e_enc"].cpu().numpy() - a["e_enc"]).max() <= TOL_TIGHT
+    L = int(params["num_enc_steps"])
+    for s in range(1, L + 1):
+        assert np.abs(trace["e_steps"][s - 1].cpu().numpy() - a[f"e_step_{s}"]).max() <= TOL_TIGHT, (name, s)
+        assert np.abs(trace["h_steps"][s - 1].cpu().numpy() - a[f"h_step_{s}"]).max() <= TOL_TIGHT, (name, s)
+    assert m.graph_flags() in (0, 1)
+
+
+@pytest.mark.parametrize("name", ["dense64", "ragged_sum", "union3"])
+def test_untraced_equals_traced(name):
+    """The production call (no trace; last step skips the dead node update) gives the same logits bit for bit."""
+    params, arch, sd, a = load_case(os.path.join(GOLDEN_DIR, name + ".npz"))
+    m = build(params, arch, sd)
+    d = to_data(a)
+    with torch.no_grad():
+        o1 = [t.clone() for t in m(d)["classified_edges"]]
+        o2 = m(d, trace={})["classified_edges"]
+    for x, y in zip(o1, o2):
+        assert torch.equal(x, y)
+
+
+def _dense_graph(n, offset=0):
+    i, j = np.meshgrid(np.arange(n), np.arange(n), indexing="ij")
+    k = i != j
+    return np.stack([i[k] + offset, j[k] + offset]).astype(np.int64)
+
+
+def _default_model(node_mlp_scale, seed=0, **over):
+    params, arch, sd, _ = load_case(os.path.join(GOLDEN_DIR, "dense64.npz"))
+    params = copy.deepcopy(params)
+    params.update(over)
+    sd = dict(sd)
+    base = np.float32(63.0)  # dense64 stores node-MLP weights scaled by 1/63
+    for k in list(sd):
+        if k.startswith("MPNet.node_model"):
+            sd[k] = (sd[k] * base * np.float32(node_mlp_scale)).astype(np.float32)
+    return params, arch, sd
+
+
+@pytest.mark.parametrize("n", [2, 33, 64, 65, 128, 256])
+def test_dense_graphs_vs_oracle(n):
+    """Full-size named configs (BASELINE.json configs 2/3) against the CPU oracle on the same seeded inputs."""
+    params, arch, sd = _default_model(1.0 / max(n - 1, 1))
+    rng = np.random.default_rng(n)
+    x = rng.standard_normal((n, 2048)).astype(np.float32)
+    x /= np.linalg.norm(x, axis=0, keepdims=True)
+    ei = _dense_graph(n)
+    ea = rng.random((ei.shape[1], 4)).astype(np.float32)
+    ref = NumpyOracle(params, arch, sd, np.float32).forward(x, ei, ea)
+    m = build(params, arch, sd)
+    with torch.no_grad():
+        out = m(Data(torch.from_numpy(x).cuda(), torch.from_numpy(ei).cuda(), torch.from_numpy(ea).cuda()))
+    for o, r in zip(out["classified_edges"], ref):
+        err = np.abs(o.cpu().numpy() - r).max()
+        assert err <= TOL_TIGHT * 4, (n, err)
+        assert err <= TOL
+
+
+def test_batch_of_graphs_equals_per_graph():
+    """Disjoint union (Batch.from_data_list, inference.py:279) == each graph alone, bit for bit."""
+    params, arch, sd = _default_model(1.0 / 40)
+    m = build(params, arch, sd)
+    rng = np.random.default_rng(3)
+    sizes = [17, 64, 5, 90, 33]
+    xs, eis, eas, off = [], [], [], 0
+    for n in sizes:
+        xs.append(rng.standard_normal((n, 2048)).astype(np.float32) / 45.0)
+        eis.append(_dense_graph(n, off))
+        eas.append(rng.random((eis[-1].shape[1], 4)).astype(np.float32))
+        off += n
+    with torch.no_grad():
+        big = m(Data(torch.from_numpy(np.concatenate(xs)).cuda(), torch.from_numpy(np.concatenate(eis, 1)).cuda(),
+                     torch.from_numpy(np.concatenate(eas)).cuda()))["classified_edges"]
+        big = [b.clone() for b in big]
+        e0, off = 0, 0
+        for n, x, ei, ea in zip(sizes, xs, eis, eas):
+            one = m(Data(torch.from_numpy(x).cuda(), torch.from_numpy(ei - off).cuda(),
+                         torch.from_numpy(ea).cuda()))["classified_edges"]
+            for b, o in zip(big, one):
+                assert torch.equal(b[e0:e0 + ei.shape[1]], o), n
+            e0 += ei.shape[1]
+            off += n
+
+
+def test_shuffled_edges_equivariant():
+    """Unsorted `row` goes through the stable device sort; logits follow the edges (permutation equivariance)."""
+    params, arch, sd = _default_model(1.0 / 47)
+    m = build(params, arch, sd)
+    rng = np.random.default_rng(9)
+    n = 48
+    x = rng.standard_normal((n, 2048)).astype(np.float32) / 45.0
+    ei = _dense_graph(n)
+    ea = rng.random((ei.shape[1], 4)).astype(np.float32)
+    perm = rng.permutation(ei.shape[1])
+    with torch.no_grad():
+        a = [t.clone() for t in m(Data(torch.from_numpy(x).cuda(), torch.from_numpy(ei).cuda(),
+                                        torch.from_numpy(ea).cuda()))["classified_edges"]]
+        assert m.graph_flags() == 0
+        b = m(Data(torch.from_numpy(x).cuda(), torch.from_numpy(ei[:, perm].copy()).cuda(),
+                   torch.from_numpy(ea[perm].copy()).cuda()))["classified_edges"]
+        assert m.graph_flags() == 1
+    for s, t in zip(a, b):
+        # the stable sort restores exactly the sorted graph's per-segment order only up to the shuffle within a
+        # segment, so sums may differ in the last bits
+        assert np.abs(s.cpu().numpy()[perm] - t.cpu().numpy()).max() <= TOL_TIGHT
+
+
+def test_bad_index_poisons_outputs():
+    params, arch, sd = _default_model(1.0 / 7)
+    m = build(params, arch, sd)
+    ei = _dense_graph(8)
+    ei[1, 5] = 99  # out of range
+    x = torch.randn(8, 2048).cuda()
+    with torch.no_grad():
+        out = m(Data(x, torch.from_numpy(ei).cuda(), torch.rand(ei.shape[1], 4).cuda()))["classified_edges"]
+    assert m.graph_flags() & 2
+    assert all(torch.isnan(o).all() for o in out)
+
+
+def test_cpu_tensors_raise():
+    params, arch, sd = _default_model(1.0)
+    m = build(params, arch, sd)
+    with pytest.raises(RuntimeError):
+        m(Data(torch.randn(4, 2048), torch.zeros(2, 3, dtype=torch.long), torch.rand(3, 4)))
+
+
+def test_empty_graph():
+    params, arch, sd = _default_model(1.0)
+    m = build(params, arch, sd)
+    with torch.no_grad():
+        out = m(Data(torch.randn(4, 2048).cuda(), torch.zeros(2, 0, dtype=torch.long).cuda(),
+                     torch.rand(0, 4).cuda()))["classified_edges"]
+    assert len(out) == 3 and all(tuple(o.shape) == (0, 1) for o in out)
