@@ -1,0 +1,261 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the MI355X message-passing path on BASELINE.json's headline workload.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--nodes 256] [--graphs 1] [--L 4] [--mode eager|graph]
+
+A "step" is one MOTMPNet.forward (encoder + L message-passing steps + the classifier on the last 3 steps, eval
+mode, no grad) over one batch of synthetic input already resident in HBM: `--graphs` independent fully-connected
+`--nodes`-node graphs as one disjoint union (what Batch.from_data_list hands the reference, inference.py:279).
+Default = ONE 256-node dense graph (65 280 edges), L = 4: the configuration BASELINE.json's metric is quoted on.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): every rank runs the same per-GPU workload on its own
+graphs (weak scaling; independent graphs, no cross-GPU edges, no data-path collective); rank 0 packs the weights and
+broadcasts the blob over RCCL.  value = edges processed by all ranks / max-over-ranks time.
+
+Prints ONE JSON line (rank 0) with the driver's contract plus `roofline` (dominant kernel mpn_step_kernel, per-launch
+algorithmic bytes / HIP-event duration) and `cpu_baseline` (the reference-shaped torch CPU
+restatement in oracle/, timed on this box's host cores; N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
+
+
+def graph_net_params(L=4, n_cls=3, agg="sum", cls_bn=True):
+    """GRAPH_NET_PARAMS of the reference's shipped inference config (config_inference.yaml:76-163)."""
+    return {
+        "node_agg_fn": agg, "num_enc_steps": L, "num_class_steps": n_cls,
+        "reattach_initial_nodes": False, "reattach_initial_edges": False,
+        "encoder_feats_dict": {
+            "edges": {"edge_in_dim": 4, "edge_fc_dims": [], "edge_out_dim": 6},
+            "nodes": {"resnet50": {"node_in_dim": 2048, "node_fc_dims": [128], "node_out_dim": 32,
+                                   "dropout_p": 0, "use_batchnorm": False}},
+        },
+        "edge_model_feats_dict": {"fc_dims": [6], "dropout_p": 0, "use_batchnorm": False},
+        "node_model_feats_dict": {"fc_dims": [32], "dropout_p": 0, "use_batchnorm": False},
+        "classifier_feats_dict": {"edge_in_dim": 6, "edge_fc_dims": [4], "edge_out_dim": 1, "dropout_p": 0,
+                                  "use_batchnorm": cls_bn},
+    }
+
+
+def build_model(params, n_nodes, seed=0):
+    """Random-init weights of the reference architecture (no checkpoint exists offline), conditioned as SURVEY.md
+    7.3 prescribes: node-MLP weight and bias x 1/(N-1) so 'sum' aggregation keeps activations O(1)."""
+    from gnn_cca_amd import MOTMPNet
+    torch.manual_seed(seed)
+    m = MOTMPNet(params, None, "resnet50")
+    g = torch.Generator().manual_seed(seed + 1000)
+    with torch.no_grad():
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.BatchNorm1d):
+                mod.running_mean.copy_(0.1 * torch.randn(mod.num_features, generator=g))
+                mod.running_var.copy_(0.5 + torch.rand(mod.num_features, generator=g))
+                mod.weight.copy_(0.5 + torch.rand(mod.num_features, generator=g))
+                mod.bias.copy_(0.1 * torch.randn(mod.num_features, generator=g))
+        for p in m.MPNet.node_model.node_mlp.parameters():
+            p.mul_(1.0 / max(n_nodes - 1, 1))
+    return m.eval()
+
+
+def dense_union(n_nodes, n_graphs, device):
+    """edge_index of `n_graphs` disjoint fully-connected directed graphs, i-major (row sorted)."""
+    i = torch.arange(n_nodes, device=device).repeat_interleave(n_nodes)
+    j = torch.arange(n_nodes, device=device).repeat(n_nodes)
+    keep = i != j
+    ei = torch.stack([i[keep], j[keep]])  # [2, n(n-1)]
+    offs = (torch.arange(n_graphs, device=device) * n_nodes).view(-1, 1, 1)
+    return (ei.unsqueeze(0) + offs).permute(1, 0, 2).reshape(2, -1).contiguous()
+
+
+class Data:
+    pass
+
+
+def make_data(n_nodes, n_graphs, seed, device):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    x = torch.randn(n_graphs * n_nodes, 2048, generator=g)
+    x = torch.nn.functional.normalize(x, p=2, dim=0)  # inference.py:189-190
+    d = Data()
+    d.x = x.to(device)
+    d.edge_index = dense_union(n_nodes, n_graphs, device)
+    d.edge_attr = torch.rand(d.edge_index.shape[1], 4, generator=g).to(device)
+    return d
+
+
+def step_algorithmic_bytes(E, L, n_cls, msg_only=True):
+    """Algorithmic HBM bytes of the mpn_step_kernel launches of one forward (fp32):
+    read e (24 B; step 1 reads edge_attr, 16 B) + col32 (4 B) + write e' (24 B, not on the last step) + logit (4 B)."""
+    first_cls = L - n_cls + 1
+    per_launch = []
+    for s in range(1, L + 1):
+        b = (16 if s == 1 else 24) + 4 + (24 if s < L else 0) + (4 if s >= first_cls else 0)
+        if msg_only and s == L:
+            continue
+        per_launch.append(b * E)
+    return per_launch
+
+
+def cpu_baseline(params, model, n_nodes, n_graphs, budget_s=12.0):
+    """The reference-shaped CPU path (oracle.TorchOracle: index/cat/addmm/relu/index_add_, the torch CPU kernels the
+    reference itself runs) on a bounded sample of the same workload."""
+    import copy
+
+    from oracle.mpn_oracle import TorchOracle
+    sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    orc = TorchOracle(copy.deepcopy(params), "resnet50", sd)
+    g_sample = min(n_graphs, 4)
+    d = make_data(n_nodes, g_sample, 1, "cpu")
+    E = d.edge_index.shape[1]
+    for _ in range(2):
+        orc.forward(d.x, d.edge_index, d.edge_attr)
+    times = []
+    t_end = time.perf_counter() + budget_s
+    while len(times) < 40 and (time.perf_counter() < t_end or len(times) < 3):
+        t0 = time.perf_counter()
+        orc.forward(d.x, d.edge_index, d.edge_attr)
+        times.append(time.perf_counter() - t0)
+    med = float(np.median(times))
+    return {"value": E / med, "unit": "edges/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{len(times)} forwards of {g_sample} x dense{n_nodes} (E={E}), median {med * 1e3:.2f} ms, "
+                      f"torch CPU op-for-op restatement (oracle.TorchOracle), fp32"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--nodes", type=int, default=256)
+    ap.add_argument("--graphs", type=int, default=1, help="independent graphs per GPU per step")
+    ap.add_argument("--L", type=int, default=4)
+    ap.add_argument("--mode", choices=["eager", "graph"], default="eager",
+                    help="eager: one C-ABI call per step; graph: the same call captured once in a HIP graph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-reps", type=int, default=20)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path is the only implementation (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    params = graph_net_params(L=args.L)
+    model = build_model(params, args.nodes, seed=0).to(device)
+    # shared weights: rank 0 packs, everyone receives the blob over RCCL/xGMI (no other collective on the path)
+    if world > 1:
+        from gnn_cca_amd.sharding import broadcast_packed_weights
+        broadcast_packed_weights(model, src=0)
+    data = make_data(args.nodes, args.graphs, 1 + rank, device)
+    E = data.edge_index.shape[1]
+    N = data.x.shape[0]
+
+    with torch.no_grad():
+        if args.mode == "graph":
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    model(data)
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                static_out = model(data)
+            run = graph.replay
+        else:
+            static_out = None
+            run = lambda: model(data)
+
+        for _ in range(args.warmup):
+            run()
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record()
+        for _ in range(args.steps):
+            out = run()
+        ev1.record()
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        dev_s = ev0.elapsed_time(ev1) / 1e3
+        t = max(wall, dev_s)
+        if dist:
+            tt = torch.tensor([t], device=device, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            t = float(tt.item())
+        if static_out is not None:
+            out = static_out
+        ok = all(torch.isfinite(o).all().item() for o in out["classified_edges"])
+
+        # per-kernel durations (HIP events around every launch; separate pass so the timed region is undisturbed)
+        kernel_ms = {}
+        for _ in range(args.profile_reps):
+            _, times = model.forward_profiled(data)
+            for kind, ms in times:
+                kernel_ms.setdefault(kind, []).append(ms)
+
+    if rank == 0:
+        per_launch = step_algorithmic_bytes(E, args.L, 3)
+        step_ms = float(np.mean(kernel_ms["step"])) if "step" in kernel_ms else float("nan")
+        alg = float(np.mean(per_launch)) if per_launch else 0.0
+        achieved = alg / (step_ms * 1e-3) / 1e9 if step_ms == step_ms and step_ms > 0 else 0.0
+        res = {
+            "metric": "processed edges/sec (L=4 MPN steps), 256-node dense graph",
+            "value": world * E * args.steps / t,
+            "unit": "edges/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": t / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{args.graphs} x dense{args.nodes} graph(s) per GPU per step "
+                                   f"(N={N}, E={E}), feat 2048, L={args.L}, 3 classified steps, fp32, eval",
+                       "mode": args.mode, "outputs_finite": bool(ok),
+                       "edge_steps_per_s": world * E * args.L * args.steps / t},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "kernel": "mpn_step_kernel<false,true>", "avg_launch_us": step_ms * 1e3,
+                         "algorithmic_bytes_per_launch": alg,
+                         "note": "working set is L2/Infinity-Cache resident at this size: latency-bound, not HBM-bound"
+                         if E * 48 < 200e6 else ""},
+            "kernels_us": {k: float(np.mean(v)) * 1e3 for k, v in kernel_ms.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(params, model, args.nodes, args.graphs)
+            res["config"]["gpu_over_cpu"] = res["value"] / res["cpu_baseline"]["value"]
+        print(json.dumps(res), flush=True)
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

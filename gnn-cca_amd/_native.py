@@ -32,6 +32,14 @@ class Trace(C.Structure):
     _fields_ = [("h_enc", C.c_void_p), ("e_enc", C.c_void_p), ("h_steps", C.c_void_p), ("e_steps", C.c_void_p)]
 
 
+PROFILE_MAX = 64
+KERNEL_KINDS = ["plan_rows", "plan_sort", "enc_gemm", "enc_reduce", "enc_tail", "step", "step_last"]
+
+
+class Profile(C.Structure):
+    _fields_ = [("count", C.c_int32), ("kind", C.c_int32 * PROFILE_MAX), ("ms", C.c_float * PROFILE_MAX)]
+
+
 _SIGNATURES = {
     "gnncca_abi_version": (C.c_int, []),
     "gnncca_status_string": (C.c_char_p, [C.c_int]),
@@ -44,6 +52,9 @@ _SIGNATURES = {
     "gnncca_num_outputs": (C.c_int, [C.POINTER(MpnDims)]),
     "gnncca_mpn_forward": (C.c_int, [C.POINTER(MpnDims), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                      C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(Trace), C.c_void_p]),
+    "gnncca_mpn_forward_profiled": (C.c_int, [C.POINTER(MpnDims), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                              C.c_int64, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
+                                              C.POINTER(Profile)]),
     "gnncca_read_graph_flags": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.c_void_p]),
 }
 

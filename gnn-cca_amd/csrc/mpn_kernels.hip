@@ -42,6 +42,44 @@ static thread_local int g_last_hip_error = 0;
         }                                              \
     } while (0)
 
+// Per-kernel timing for bench.py / rocprof cross-checks: one hipEvent after every launch (diagnostic entry point only).
+struct Profiler {
+    gnncca_profile* out;
+    hipEvent_t ev[GNNCCA_PROFILE_MAX + 1];
+    int n;
+};
+
+static int prof_begin(Profiler* p, hipStream_t st) {
+    if (!p) return GNNCCA_OK;
+    p->n = 0;
+    for (int i = 0; i <= GNNCCA_PROFILE_MAX; ++i) HIP_TRY(hipEventCreate(&p->ev[i]));
+    HIP_TRY(hipEventRecord(p->ev[0], st));
+    return GNNCCA_OK;
+}
+
+static int prof_mark(Profiler* p, int kind, hipStream_t st) {
+    if (!p || p->n >= GNNCCA_PROFILE_MAX) return GNNCCA_OK;
+    p->out->kind[p->n] = kind;
+    p->n++;
+    HIP_TRY(hipEventRecord(p->ev[p->n], st));
+    return GNNCCA_OK;
+}
+
+static int prof_end(Profiler* p, hipStream_t st) {
+    if (!p) return GNNCCA_OK;
+    HIP_TRY(hipStreamSynchronize(st));
+    p->out->count = p->n;
+    for (int i = 0; i < p->n; ++i) HIP_TRY(hipEventElapsedTime(&p->out->ms[i], p->ev[i], p->ev[i + 1]));
+    for (int i = 0; i <= GNNCCA_PROFILE_MAX; ++i) HIP_TRY(hipEventDestroy(p->ev[i]));
+    return GNNCCA_OK;
+}
+
+#define PROF_MARK(kind)                                  \
+    do {                                                 \
+        int _s = prof_mark(prof, (kind), st);            \
+        if (_s != GNNCCA_OK) return _s;                  \
+    } while (0)
+
 // ------------------------------------------------------------------------------------------------------------
 // Graph plan, part 1 (parallel, optimistic): validates indices, narrows `col` to int32 and builds the CSR
 // offsets assuming `row` is non-decreasing -- true for every graph the reference builds (inference.py:209-216,
@@ -574,9 +612,11 @@ int gnncca_read_graph_flags(const void* workspace, uint32_t* flags_out, gnncca_s
     return GNNCCA_OK;
 }
 
-int gnncca_mpn_forward(const gnncca_mpn_dims* d, const void* packed_dev, const float* x, const int64_t* edge_index,
-                       const float* edge_attr, int64_t n_nodes, int64_t n_edges, void* workspace, size_t workspace_bytes,
-                       float* logits_out, const gnncca_trace* trace, gnncca_stream_t stream) {
+}  // extern "C"
+
+static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const float* x, const int64_t* edge_index,
+                        const float* edge_attr, int64_t n_nodes, int64_t n_edges, void* workspace, size_t workspace_bytes,
+                        float* logits_out, const gnncca_trace* trace, gnncca_stream_t stream, Profiler* prof) {
     if (!dims_valid(d) || n_nodes < 0 || n_edges < 0) return GNNCCA_ERR_INVALID_ARG;
     if (classify(d) == kFamilyNone) return GNNCCA_ERR_UNSUPPORTED;
     if (n_nodes >= (1ll << 31) - 64 || n_edges >= (1ll << 31) - 64) return GNNCCA_ERR_UNSUPPORTED;
@@ -612,9 +652,11 @@ int gnncca_mpn_forward(const gnncca_mpn_dims* d, const void* packed_dev, const f
         const long long* ei = reinterpret_cast<const long long*>(edge_index);
         hipLaunchKernelGGL(plan_rows_kernel, grid1((size_t)E, 256), dim3(256), 0, st, ei, E, N, seg_ptr, col32, flags);
         HIP_TRY(hipGetLastError());
+        PROF_MARK(GNNCCA_K_PLAN_ROWS);
         hipLaunchKernelGGL(plan_sort_fallback_kernel, dim3(1), dim3(1024), 0, st, ei, E, N, seg_ptr, col32, perm, cursor,
                            (const unsigned*)flags);
         HIP_TRY(hipGetLastError());
+        PROF_MARK(GNNCCA_K_PLAN_SORT);
     }
 
     // ---- node encoder -------------------------------------------------------------------------------------
@@ -633,12 +675,14 @@ int gnncca_mpn_forward(const gnncca_mpn_dims* d, const void* packed_dev, const f
         hipLaunchKernelGGL(dense_rows_mfma_kernel, grid, dim3(256), 0, st, cur_in, blob + hdr.enc_node_w[g], part, N, K, O,
                            kslice, vec_ok);
         HIP_TRY(hipGetLastError());
+        PROF_MARK(GNNCCA_K_ENC_GEMM);
         ks_last = ks;
         if (g < n_gemm - 1) {
             float* dst = act + (size_t)(g & 1) * N * O;
             hipLaunchKernelGGL(reduce_bias_act_kernel, grid1((size_t)N * O, 256), dim3(256), 0, st, (const float*)part,
                                blob + hdr.enc_node_b[g], dst, N, O, ks, l.relu);
             HIP_TRY(hipGetLastError());
+            PROF_MARK(GNNCCA_K_ENC_REDUCE);
             cur_in = dst;
         }
     }
@@ -674,6 +718,7 @@ int gnncca_mpn_forward(const gnncca_mpn_dims* d, const void* packed_dev, const f
         const unsigned blocks = (unsigned)std::min<size_t>(((size_t)N + 3) / 4, 2048);
         hipLaunchKernelGGL(enc_tail_kernel, dim3(blocks), dim3(256), lds, st, tp);
         HIP_TRY(hipGetLastError());
+        PROF_MARK(GNNCCA_K_ENC_TAIL);
     }
     if (E == 0) return GNNCCA_OK;
 
@@ -722,6 +767,7 @@ int gnncca_mpn_forward(const gnncca_mpn_dims* d, const void* packed_dev, const f
         sp.logits = logits_out;
         sp.trace_e_enc = trace ? trace->e_enc : nullptr;
         HIP_TRY(re ? (launch_step<true, false>(sp, st)) : (launch_step<false, false>(sp, st)));
+        PROF_MARK(GNNCCA_K_STEP_LAST);
         return GNNCCA_OK;
     }
     for (int step = 1; step <= L; ++step) {
@@ -745,8 +791,35 @@ int gnncca_mpn_forward(const gnncca_mpn_dims* d, const void* packed_dev, const f
         else
             err = msg ? launch_step<false, true>(sp, st) : launch_step<false, false>(sp, st);
         HIP_TRY(err);
+        PROF_MARK(msg ? GNNCCA_K_STEP : GNNCCA_K_STEP_LAST);
     }
     return GNNCCA_OK;
+}
+
+extern "C" {
+
+int gnncca_mpn_forward(const gnncca_mpn_dims* d, const void* packed_dev, const float* x, const int64_t* edge_index,
+                       const float* edge_attr, int64_t n_nodes, int64_t n_edges, void* workspace, size_t workspace_bytes,
+                       float* logits_out, const gnncca_trace* trace, gnncca_stream_t stream) {
+    return forward_impl(d, packed_dev, x, edge_index, edge_attr, n_nodes, n_edges, workspace, workspace_bytes, logits_out,
+                        trace, stream, nullptr);
+}
+
+int gnncca_mpn_forward_profiled(const gnncca_mpn_dims* d, const void* packed_dev, const float* x,
+                                const int64_t* edge_index, const float* edge_attr, int64_t n_nodes, int64_t n_edges,
+                                void* workspace, size_t workspace_bytes, float* logits_out, gnncca_stream_t stream,
+                                gnncca_profile* profile) {
+    if (!profile) return GNNCCA_ERR_INVALID_ARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    Profiler p;
+    p.out = profile;
+    profile->count = 0;
+    int s = prof_begin(&p, st);
+    if (s != GNNCCA_OK) return s;
+    s = forward_impl(d, packed_dev, x, edge_index, edge_attr, n_nodes, n_edges, workspace, workspace_bytes, logits_out,
+                     nullptr, stream, &p);
+    const int s2 = prof_end(&p, st);
+    return s != GNNCCA_OK ? s : s2;
 }
 
 }  // extern "C"

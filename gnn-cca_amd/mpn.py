@@ -197,8 +197,7 @@ class MOTMPNet(nn.Module):
         return ws
 
     # -- forward -----------------------------------------------------------------------------------------------
-    def forward(self, data, trace=None):
-        """See class docstring.  ``trace`` (optional dict) receives the intermediate latents for debugging."""
+    def _prepare(self, data):
         x, edge_index, edge_attr = data.x, data.edge_index, data.edge_attr
         if self.training:
             raise NotImplementedError(
@@ -223,13 +222,20 @@ class MOTMPNet(nn.Module):
         blob = self._packed_weights(dev)
         n_out = lib.gnncca_num_outputs(C.byref(d))
         logits = torch.empty((n_out, e, 1), dtype=torch.float32, device=dev)
-        if n == 0 or e == 0:
+        ws = None
+        if n > 0 and e > 0:
+            ws_bytes = lib.gnncca_workspace_bytes(C.byref(d), n, e)
+            if ws_bytes == 0:
+                nat.check(lib.gnncca_supported(C.byref(d)), "MOTMPNet configuration")
+            ws = self._scratch(ws_bytes, dev)
+            self.last_workspace_bytes = ws_bytes
+        return lib, d, dev, x, edge_index, edge_attr, n, e, blob, logits, ws
+
+    def forward(self, data, trace=None):
+        """See class docstring.  ``trace`` (optional dict) receives the intermediate latents for debugging."""
+        lib, d, dev, x, edge_index, edge_attr, n, e, blob, logits, ws = self._prepare(data)
+        if ws is None:
             return {'classified_edges': list(logits.unbind(0))}
-        ws_bytes = lib.gnncca_workspace_bytes(C.byref(d), n, e)
-        if ws_bytes == 0:
-            nat.check(lib.gnncca_supported(C.byref(d)), "MOTMPNet configuration")
-        ws = self._scratch(ws_bytes, dev)
-        self.last_workspace_bytes = ws_bytes
         tr = None
         if trace is not None:
             L = int(self.num_enc_steps)
@@ -246,6 +252,22 @@ class MOTMPNet(nn.Module):
                                         stream)
         nat.check(st, "gnncca_mpn_forward")
         return {'classified_edges': list(logits.unbind(0))}
+
+    def forward_profiled(self, data):
+        """Diagnostic (bench.py): same forward with a hipEvent after every kernel launch; synchronises.
+        Returns (outputs, [(kernel_kind, milliseconds), ...])."""
+        lib, d, dev, x, edge_index, edge_attr, n, e, blob, logits, ws = self._prepare(data)
+        if ws is None:
+            return {'classified_edges': list(logits.unbind(0))}, []
+        prof = nat.Profile()
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            st = lib.gnncca_mpn_forward_profiled(C.byref(d), blob.data_ptr(), x.data_ptr(), edge_index.data_ptr(),
+                                                 edge_attr.data_ptr(), n, e, ws.data_ptr(), ws.numel(),
+                                                 logits.data_ptr(), stream, C.byref(prof))
+        nat.check(st, "gnncca_mpn_forward_profiled")
+        times = [(nat.KERNEL_KINDS[prof.kind[i]], float(prof.ms[i])) for i in range(prof.count)]
+        return {'classified_edges': list(logits.unbind(0))}, times
 
     def graph_flags(self):
         """Synchronises and returns the flag word of the last forward (bit 0: unsorted rows, bit 1: bad index)."""

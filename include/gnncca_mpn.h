@@ -133,6 +133,21 @@ GNNCCA_API int gnncca_mpn_forward(const gnncca_mpn_dims* dims, const void* packe
                        int64_t n_edges, void* workspace, size_t workspace_bytes, float* logits_out,
                        const gnncca_trace* trace, gnncca_stream_t stream);
 
+/* Diagnostic twin of gnncca_mpn_forward for bench.py: records a hipEvent after every kernel launch,
+ * SYNCHRONISES the stream and returns the per-launch elapsed times.  Never used on the product path. */
+#define GNNCCA_PROFILE_MAX 64
+enum { GNNCCA_K_PLAN_ROWS = 0, GNNCCA_K_PLAN_SORT = 1, GNNCCA_K_ENC_GEMM = 2, GNNCCA_K_ENC_REDUCE = 3,
+       GNNCCA_K_ENC_TAIL = 4, GNNCCA_K_STEP = 5, GNNCCA_K_STEP_LAST = 6 };
+typedef struct gnncca_profile {
+    int32_t count;                      /* launches recorded */
+    int32_t kind[GNNCCA_PROFILE_MAX];   /* GNNCCA_K_* */
+    float ms[GNNCCA_PROFILE_MAX];       /* hipEventElapsedTime between the events before / after the launch */
+} gnncca_profile;
+GNNCCA_API int gnncca_mpn_forward_profiled(const gnncca_mpn_dims* dims, const void* packed_dev, const float* x,
+                                const int64_t* edge_index, const float* edge_attr, int64_t n_nodes,
+                                int64_t n_edges, void* workspace, size_t workspace_bytes, float* logits_out,
+                                gnncca_stream_t stream, gnncca_profile* profile);
+
 /* len(outputs['classified_edges']) for these dims (mpn.py:277-297). */
 GNNCCA_API int gnncca_num_outputs(const gnncca_mpn_dims* dims);
 
