@@ -106,7 +106,7 @@ def step_algorithmic_bytes(E, L, n_cls, msg_only=True):
     return per_launch
 
 
-def cpu_baseline(params, model, n_nodes, n_graphs, budget_s=12.0):
+def cpu_baseline(params, model, n_nodes, n_graphs, budget_s=20.0):
     """The reference-shaped CPU path (oracle.TorchOracle: index/cat/addmm/relu/index_add_, the torch CPU kernels the
     reference itself runs) on a bounded sample of the same workload."""
     import copy
@@ -117,18 +117,29 @@ def cpu_baseline(params, model, n_nodes, n_graphs, budget_s=12.0):
     g_sample = min(n_graphs, 4)
     d = make_data(n_nodes, g_sample, 1, "cpu")
     E = d.edge_index.shape[1]
-    for _ in range(2):
-        orc.forward(d.x, d.edge_index, d.edge_attr)
-    times = []
-    t_end = time.perf_counter() + budget_s
-    while len(times) < 40 and (time.perf_counter() < t_end or len(times) < 3):
-        t0 = time.perf_counter()
-        orc.forward(d.x, d.edge_index, d.edge_attr)
-        times.append(time.perf_counter() - t0)
-    med = float(np.median(times))
-    return {"value": E / med, "unit": "edges/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{len(times)} forwards of {g_sample} x dense{n_nodes} (E={E}), median {med * 1e3:.2f} ms, "
-                      f"torch CPU op-for-op restatement (oracle.TorchOracle), fp32"}
+    # torch's CPU kernels do not scale to every core of a big host on this small problem: time a few thread counts
+    # inside the budget and report the FASTEST (most favourable to the CPU), naming the others in `sample`.
+    ncpu = os.cpu_count() or 1
+    cands = sorted({c for c in (8, 16, 32, 64) if c <= ncpu} | ({ncpu} if ncpu <= 64 else set()))
+    results = {}
+    for c in cands:
+        torch.set_num_threads(c)
+        for _ in range(2):
+            orc.forward(d.x, d.edge_index, d.edge_attr)
+        times = []
+        t_end = time.perf_counter() + budget_s / len(cands)
+        while len(times) < 30 and (time.perf_counter() < t_end or len(times) < 3):
+            t0 = time.perf_counter()
+            orc.forward(d.x, d.edge_index, d.edge_attr)
+            times.append(time.perf_counter() - t0)
+        results[c] = (float(np.median(times)), len(times))
+    best = min(results, key=lambda c: results[c][0])
+    med, n_runs = results[best]
+    others = ", ".join(f"{c}thr {results[c][0] * 1e3:.1f}ms" for c in cands)
+    return {"value": E / med, "unit": "edges/s", "cores": best, "kind": "port",
+            "sample": f"{n_runs} forwards of {g_sample} x dense{n_nodes} (E={E}), median {med * 1e3:.2f} ms at {best} "
+                      f"threads (host has {ncpu}; medians: {others}); torch CPU op-for-op restatement "
+                      f"(oracle.TorchOracle), fp32"}
 
 
 def main():

@@ -33,7 +33,7 @@ class Trace(C.Structure):
 
 
 PROFILE_MAX = 64
-KERNEL_KINDS = ["plan_rows", "plan_sort", "enc_gemm", "enc_reduce", "enc_tail", "step", "step_last"]
+KERNEL_KINDS = ["plan", "plan_sort_unused", "enc_gemm", "enc_reduce", "enc_tail", "step", "step_last"]
 
 
 class Profile(C.Structure):

@@ -38,8 +38,22 @@ struct BlobHeader {
     int32_t proj_b;                         // [48]        biases b_e (slots 8..13) and b_n (16..47)
     int32_t cls_layers, cls_hidden;         // 1: Linear(6,1);  2: Linear(6,C1)+ReLU, Linear(C1,1)
     int32_t cls_w1, cls_b1, cls_w2, cls_b2;
-    int32_t pad[8];
+    int32_t fast_consts;                    // [kFastConsts] contiguous copy of the per-step scalars (see below), or 0
+    int32_t pad[7];
 };
+
+// Layout of the `fast_consts` block (floats): what mpn_step_fast_kernel stages into LDS in one coalesced load.
+// Present when edge_in == 4, no reattach flags and the classifier is Linear(6,4)+ReLU+Linear(4,1).
+constexpr int kFcEncW = 0;     // [6][4]
+constexpr int kFcEncB = 24;    // [6]
+constexpr int kFcWee = 32;     // [6][6]
+constexpr int kFcCw1 = 68;     // [4][6]
+constexpr int kFcCb1 = 92;     // [4]
+constexpr int kFcCw2 = 96;     // [4]
+constexpr int kFcCb2 = 100;    // [1]
+constexpr int kFcProjB = 104;  // [48]
+constexpr int kFastConsts = 152;
+bool fast_consts_ok(const gnncca_mpn_dims* d);
 
 Family classify(const gnncca_mpn_dims* d);
 bool blob_header(const gnncca_mpn_dims* d, BlobHeader* out);  // false if unsupported

@@ -81,76 +81,47 @@ static int prof_end(Profiler* p, hipStream_t st) {
     } while (0)
 
 // ------------------------------------------------------------------------------------------------------------
-// Graph plan, part 1 (parallel, optimistic): validates indices, narrows `col` to int32 and builds the CSR
-// offsets assuming `row` is non-decreasing -- true for every graph the reference builds (inference.py:209-216,
-// Batch.from_data_list keeps the order).  Sets GNNCCA_GRAPH_UNSORTED otherwise; part 2 then repairs the plan.
+// Graph plan.  Parallel, optimistic part: validates indices, narrows `col` to int32 and builds the CSR offsets
+// assuming `row` is non-decreasing -- true for every graph the reference builds (inference.py:209-216;
+// Batch.from_data_list keeps the order).  A violation raises GNNCCA_GRAPH_UNSORTED; one extra workgroup of the
+// next launch on the stream (enc_tail_kernel) then repairs the plan alone with a STABLE counting sort by `row`
+// (plan_sort_fallback), so that every segment keeps the caller's edge order -- the order torch's CPU index_add_
+// (and with it the reference on CPU) sums in.  Only correctness matters on that branch: the reference never
+// produces such graphs.  The kernel boundary orders it after this kernel's stores; no in-launch hand-off.
+// flags[0] is zeroed by the first encoder GEMM launch, which precedes this kernel on the stream.
 // ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void plan_rows_kernel(const long long* __restrict__ ei, int E, int N,
-                                                        int* __restrict__ seg_ptr, int* __restrict__ col32,
-                                                        unsigned* __restrict__ flags) {
-    const int k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= E) return;
-    const long long r = ei[k], c = ei[(size_t)E + k];
-    if (r < 0 || r >= N || c < 0 || c >= N) {
-        atomicOr(flags, GNNCCA_GRAPH_BAD_INDEX);
-        return;
-    }
-    col32[k] = (int)c;
-    long long rp = -1;
-    if (k > 0) {
-        rp = ei[k - 1];
-        if (rp < 0 || rp >= N) return;  // its owner raises the flag
-    }
-    if (r < rp) {
-        atomicOr(flags, GNNCCA_GRAPH_UNSORTED);
-    } else {
-        for (long long n = rp + 1; n <= r; ++n) seg_ptr[n] = k;
-    }
-    if (k == E - 1)
-        for (long long n = r + 1; n <= N; ++n) seg_ptr[n] = E;
-}
-
-// Graph plan, part 2 (one workgroup; exits at once for sorted graphs): STABLE counting sort of the edges by
-// `row`, so that every segment keeps the caller's edge order -- the order torch's CPU index_add_ (and with it
-// the reference on CPU) sums in.  Only correctness matters here: the reference never produces such graphs.
-__global__ __launch_bounds__(1024) void plan_sort_fallback_kernel(const long long* __restrict__ ei, int E, int N,
-                                                                  int* __restrict__ seg_ptr, int* __restrict__ col32,
-                                                                  int* __restrict__ perm, int* cursor,
-                                                                  const unsigned* __restrict__ flags) {
-    const unsigned fl = __hip_atomic_load(flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (!(fl & GNNCCA_GRAPH_UNSORTED) || (fl & GNNCCA_GRAPH_BAD_INDEX)) return;
-    __shared__ int s_rows[1024];
-    __shared__ int s_scan[1024];
-    __shared__ int s_carry;
+__device__ void plan_sort_fallback(const long long* __restrict__ ei, int E, int N, int* seg_ptr, int* col32, int* perm,
+                                   int* cursor, int* s_rows, int* s_scan, int* s_carry) {
+    constexpr int B = 256;
     const int tid = threadIdx.x;
-    for (int n = tid; n <= N; n += 1024) __hip_atomic_store(&cursor[n], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int n = tid; n <= N; n += B) __hip_atomic_store(&cursor[n], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) *s_carry = 0;
     __syncthreads();
-    for (int k = tid; k < E; k += 1024) atomicAdd(&cursor[(int)ei[k]], 1);
-    if (tid == 0) s_carry = 0;
+    for (int k = tid; k < E; k += B) atomicAdd(&cursor[(int)ei[k]], 1);
     __syncthreads();
     // exclusive scan of the histogram -> seg_ptr; cursor[n] := seg_ptr[n]
-    for (int n0 = 0; n0 <= N; n0 += 1024) {
+    for (int n0 = 0; n0 <= N; n0 += B) {
         const int n = n0 + tid;
         const int v = (n < N) ? __hip_atomic_load(&cursor[n], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
         s_scan[tid] = v;
         __syncthreads();
-        for (int d = 1; d < 1024; d <<= 1) {
+        for (int d = 1; d < B; d <<= 1) {
             const int add = (tid >= d) ? s_scan[tid - d] : 0;
             __syncthreads();
             s_scan[tid] += add;
             __syncthreads();
         }
-        const int excl = s_carry + s_scan[tid] - v;
+        const int excl = *s_carry + s_scan[tid] - v;
         if (n <= N) {
             seg_ptr[n] = excl;
             __hip_atomic_store(&cursor[n], excl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
-        if (tid == 1023) s_carry += s_scan[1023];
+        if (tid == B - 1) *s_carry += s_scan[B - 1];
         __syncthreads();
     }
-    // stable placement, 1024 edges at a time in ascending edge id
-    for (int k0 = 0; k0 < E; k0 += 1024) {
+    // stable placement, B edges at a time in ascending edge id
+    for (int k0 = 0; k0 < E; k0 += B) {
         const int k = k0 + tid;
         const int r = (k < E) ? (int)ei[k] : -1;
         s_rows[tid] = r;
@@ -168,6 +139,35 @@ __global__ __launch_bounds__(1024) void plan_sort_fallback_kernel(const long lon
     }
 }
 
+__global__ __launch_bounds__(256) void plan_rows_kernel(const long long* __restrict__ ei, int E, int N,
+                                                        int* __restrict__ seg_ptr, int* __restrict__ col32,
+                                                        unsigned* __restrict__ flags) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k < E) {
+        const long long r = ei[k], c = ei[(size_t)E + k];
+        if (r < 0 || r >= N || c < 0 || c >= N) {
+            atomicOr(&flags[0], GNNCCA_GRAPH_BAD_INDEX);
+        } else {
+            col32[k] = (int)c;
+            long long rp = -1;
+            bool prev_ok = true;
+            if (k > 0) {
+                rp = ei[k - 1];
+                prev_ok = rp >= 0 && rp < N;  // otherwise its owner raises the flag
+            }
+            if (prev_ok) {
+                if (r < rp) {
+                    atomicOr(&flags[0], GNNCCA_GRAPH_UNSORTED);
+                } else {
+                    for (long long n = rp + 1; n <= r; ++n) seg_ptr[n] = k;
+                }
+                if (k == E - 1)
+                    for (long long n = r + 1; n <= N; ++n) seg_ptr[n] = E;
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // Node encoder GEMM: part[ks][M][O] = in[M][kslice ks] . W[O][kslice ks]^T with v_mfma_f32_32x32x2_f32 (exact
 // fp32 FMA chain).  One wave = 32 rows x 32 output columns; a workgroup = 4 waves = 128 columns.
@@ -178,7 +178,9 @@ __global__ __launch_bounds__(1024) void plan_sort_fallback_kernel(const long lon
 // ------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void dense_rows_mfma_kernel(const float* __restrict__ in, const float* __restrict__ W,
                                                               float* __restrict__ part, int M, int K, int O,
-                                                              int kslice, int vec_ok) {
+                                                              int kslice, int vec_ok, unsigned* __restrict__ zero_flags) {
+    if (zero_flags && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x < 4)
+        zero_flags[threadIdx.x] = 0u;  // graph flag word + plan arrival counter of this forward
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int row0 = blockIdx.x * 32;
@@ -244,7 +246,7 @@ __global__ __launch_bounds__(256) void reduce_bias_act_kernel(const float* __res
 // With reattach_initial_nodes the input is cat((initial, latent)) -- initial first (models/mpn.py:285).
 // ------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void project_node(float h_latent, float h_init, bool reatt_n, const float* s_projT,
-                                             const float* __restrict__ projb, float* __restrict__ pd_row,
+                                             const float* projb, float* __restrict__ pd_row,
                                              float* __restrict__ psq_row, int lane) {
     const int o = min(lane, kProjOut - 1);
     float acc = projb[o];
@@ -277,7 +279,15 @@ struct TailParams {
     float* pd_out;
     float* psq_out;
     int off_prev_b, off_lastWT, off_last_b, off_projwT, off_projb;
-    int ks, F, N, has_last, relu_prev, reatt_n, hin;
+    int ks, F, N, has_last, relu_prev, reatt_n, hin, vec_reduce;
+    // graph-plan repair (runs in the extra last workgroup only when the graph was flagged unsorted)
+    const long long* ei;
+    int* seg_ptr;
+    int* col32;
+    int* perm;
+    int* cursor;
+    const unsigned* flags;
+    int E;
 };
 
 __global__ __launch_bounds__(256) void enc_tail_kernel(const TailParams p) {
@@ -285,22 +295,63 @@ __global__ __launch_bounds__(256) void enc_tail_kernel(const TailParams p) {
     float* s_proj = smem;                                    // [hin][48]
     float* s_last = s_proj + p.hin * kProjOut;               // [F][32]   (has_last)
     float* s_row = s_last + (p.has_last ? p.F * kH : 0);     // [4][F]
+    float* s_red = s_row + 4 * p.F;                          // [4][64 floats x 4]  (vec_reduce)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* __restrict__ blob = p.blob;
-    for (int i = tid; i < p.hin * kProjOut; i += 256) s_proj[i] = blob[p.off_projwT + i];
-    if (p.has_last)
-        for (int i = tid; i < p.F * kH; i += 256) s_last[i] = blob[p.off_lastWT + i];
+    if (blockIdx.x == gridDim.x - 1) {  // the plan-repair workgroup
+        if (p.E > 0) {
+            const unsigned fl = p.flags[0];
+            if ((fl & GNNCCA_GRAPH_UNSORTED) && !(fl & GNNCCA_GRAPH_BAD_INDEX)) {
+                int* si = reinterpret_cast<int*>(smem);
+                plan_sort_fallback(p.ei, p.E, p.N, p.seg_ptr, p.col32, p.perm, p.cursor, si, si + 256, si + 512);
+            }
+        }
+        return;
+    }
+    const int nblk = gridDim.x - 1;
+    {   // stage the projection and last-layer weights: 16 B per lane, all loads in flight together
+        const f32x4* __restrict__ g4 = reinterpret_cast<const f32x4*>(blob + p.off_projwT);
+        f32x4* l4 = reinterpret_cast<f32x4*>(s_proj);
+        for (int i = tid; i < p.hin * kProjOut / 4; i += 256) l4[i] = g4[i];
+        if (p.has_last) {
+            const f32x4* __restrict__ h4 = reinterpret_cast<const f32x4*>(blob + p.off_lastWT);
+            f32x4* m4 = reinterpret_cast<f32x4*>(s_last);
+            for (int i = tid; i < p.F * kH / 4; i += 256) m4[i] = h4[i];
+        }
+    }
     __syncthreads();
     const int o = lane & 31, half = lane >> 5;
     float* rowbuf = s_row + wave * p.F;
-    for (int grp = blockIdx.x; grp * 4 < p.N; grp += gridDim.x) {
+    float* redbuf = s_red + wave * 256;
+    for (int grp = blockIdx.x; grp * 4 < p.N; grp += nblk) {
         const int node = grp * 4 + wave;
         const bool active = node < p.N;
         if (active) {
-            for (int f = lane; f < p.F; f += 64) {
-                float v = blob[p.off_prev_b + f];
-                for (int s = 0; s < p.ks; ++s) v += p.part[((size_t)s * p.N + node) * p.F + f];
-                rowbuf[f] = p.relu_prev ? fmaxf(v, 0.f) : v;
+            if (p.vec_reduce) {
+                // F/4 float4 chunks per row; 64/(F/4) lane groups walk the split-K partials in an interleaved,
+                // fixed order with all loads independent (one round trip instead of ks dependent ones)
+                const int nchunk = p.F >> 2, groups = 64 / nchunk;
+                const int g = lane / nchunk, c = lane - g * nchunk;
+                f32x4 a = {0.f, 0.f, 0.f, 0.f};
+                if (g < groups) {
+                    const float* __restrict__ src = p.part + (size_t)node * p.F + 4 * c;
+                    const size_t sstride = (size_t)p.N * p.F;
+#pragma unroll 8
+                    for (int s = g; s < p.ks; s += groups) a += *reinterpret_cast<const f32x4*>(src + s * sstride);
+                    *reinterpret_cast<f32x4*>(redbuf + g * p.F + 4 * c) = a;
+                }
+                __builtin_amdgcn_wave_barrier();
+                for (int f = lane; f < p.F; f += 64) {
+                    float v = blob[p.off_prev_b + f];
+                    for (int gg = 0; gg < groups; ++gg) v += redbuf[gg * p.F + f];
+                    rowbuf[f] = p.relu_prev ? fmaxf(v, 0.f) : v;
+                }
+            } else {
+                for (int f = lane; f < p.F; f += 64) {
+                    float v = blob[p.off_prev_b + f];
+                    for (int s = 0; s < p.ks; ++s) v += p.part[((size_t)s * p.N + node) * p.F + f];
+                    rowbuf[f] = p.relu_prev ? fmaxf(v, 0.f) : v;
+                }
             }
         }
         __syncthreads();
@@ -360,47 +411,37 @@ struct StepParams {
     float* logits;
     long long e_stride;
     int off_wee, off_wneb, off_projwT, off_projb, off_encw, off_encb, off_cw1, off_cb1, off_cw2, off_cb2;
+    int off_fast;
     int cls_layers, cls_hidden;  // cls_layers == 0: this step does not classify
-    int N, E, edge_in, attr_vec, first, update, agg, reatt_n, wps, store_e, hin;
+    int N, E, edge_in, attr_vec, first, update, agg, reatt_n, wps, store_e, hin, pd_lds;
 };
 
-template <bool REATT_E, bool MSG>
+template <bool REATT_E, bool MSG, bool AGG_MAX>
 __global__ __launch_bounds__(256) void mpn_step_kernel(const StepParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int EFIN = REATT_E ? 2 * kEF : kEF;
     float* s_proj = smem;                                   // [hin][48]   (MSG)
     float* s_part = smem + (MSG ? p.hin * kProjOut : 0);    // [4][32]
+    float* s_pd = s_part + 4 * kH;                          // [N][8]      (pd_lds: small graphs keep P_dst on chip)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const float* __restrict__ blob = p.blob;
+    // Prologue: every load that does not depend on another one is issued before the first wait (flag word, CSR
+    // offsets, the node's P_src/Q row, the MFMA B operand, the projection weights for the epilogue).
     const unsigned gflags = p.flags[0];
-    if (gflags & GNNCCA_GRAPH_BAD_INDEX) {  // poisoned graph: make the failure visible in the outputs
-        if (p.logits)
-            for (size_t k = (size_t)blockIdx.x * 256 + tid; k < (size_t)p.E; k += (size_t)gridDim.x * 256)
-                p.logits[k] = __builtin_nanf("");
-        return;
-    }
-    const bool unsorted = (gflags & GNNCCA_GRAPH_UNSORTED) != 0;
-    if (MSG) {
-        for (int i = tid; i < p.hin * kProjOut; i += 256) s_proj[i] = blob[p.off_projwT + i];
-        __syncthreads();
-    }
     const int wps = p.wps;
     const int node = blockIdx.x * (4 / wps) + wave / wps;
     const int sub = wave % wps;
     const bool active = node < p.N;
-    int seg_s = 0, seg_t = 0;
-    if (active) {
-        seg_s = p.seg_ptr[node];
-        seg_t = p.seg_ptr[node + 1];
-    }
+    const int nclamp = active ? node : 0;
+    int seg_s = p.seg_ptr[nclamp];
+    int seg_t = p.seg_ptr[nclamp + 1];
     const int half = lane >> 5, ch = lane & 31;
-
     float psrc[kEF];
     float cinit = 0.f;
     float bw[3] = {0.f, 0.f, 0.f};
-    if (active) {
-        const float* __restrict__ psq = p.psq_in + (size_t)node * kPsQStride;
+    {
+        const float* __restrict__ psq = p.psq_in + (size_t)nclamp * kPsQStride;
 #pragma unroll
         for (int f = 0; f < kEF; ++f) psrc[f] = p.update ? psq[f] : 0.f;
         if (MSG) {
@@ -409,7 +450,27 @@ __global__ __launch_bounds__(256) void mpn_step_kernel(const StepParams p) {
             for (int s = 0; s < 3; ++s) bw[s] = blob[p.off_wneb + s * 64 + lane];
         }
     }
-    const bool agg_max = p.agg == GNNCCA_AGG_MAX;
+    if (MSG) {
+        const f32x4* __restrict__ g4 = reinterpret_cast<const f32x4*>(blob + p.off_projwT);
+        f32x4* l4 = reinterpret_cast<f32x4*>(s_proj);
+        for (int i = tid; i < p.hin * kProjOut / 4; i += 256) l4[i] = g4[i];
+    }
+    if (p.pd_lds) {  // the whole gather table rides along with the first round trip instead of costing a dependent one
+        const f32x4* __restrict__ g4 = reinterpret_cast<const f32x4*>(p.pd_in);
+        f32x4* l4 = reinterpret_cast<f32x4*>(s_pd);
+        for (int i = tid; i < p.N * (kPdStride / 4); i += 256) l4[i] = g4[i];
+    }
+    if (gflags & GNNCCA_GRAPH_BAD_INDEX) {  // poisoned graph: make the failure visible in the outputs
+        if (p.logits)
+            for (size_t k = (size_t)blockIdx.x * 256 + tid; k < (size_t)p.E; k += (size_t)gridDim.x * 256)
+                p.logits[k] = __builtin_nanf("");
+        return;
+    }
+    const bool unsorted = (gflags & GNNCCA_GRAPH_UNSORTED) != 0;
+    if (MSG || p.pd_lds) __syncthreads();
+    if (!active) seg_s = seg_t = 0;
+
+    constexpr bool agg_max = AGG_MAX;
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = agg_max ? -INFINITY : 0.f;
@@ -467,9 +528,16 @@ __global__ __launch_bounds__(256) void mpn_step_kernel(const StepParams p) {
         if (p.update) {
             // edge update: ReLU(W_e . cat(x[row], x[col], e) + b_e)   (models/mpn.py:48, 68-69)
             const int j = p.col32[kk];
-            const float* __restrict__ pdj = p.pd_in + (size_t)j * kPdStride;
-            const f32x4 pd0 = *reinterpret_cast<const f32x4*>(pdj);
-            const f32x2 pd1 = *reinterpret_cast<const f32x2*>(pdj + 4);
+            f32x4 pd0;
+            f32x2 pd1;
+            if (p.pd_lds) {
+                pd0 = *reinterpret_cast<const f32x4*>(s_pd + j * kPdStride);
+                pd1 = *reinterpret_cast<const f32x2*>(s_pd + j * kPdStride + 4);
+            } else {
+                const float* __restrict__ pdj = p.pd_in + (size_t)j * kPdStride;
+                pd0 = *reinterpret_cast<const f32x4*>(pdj);
+                pd1 = *reinterpret_cast<const f32x2*>(pdj + 4);
+            }
             const float pd[kEF] = {pd0[0], pd0[1], pd0[2], pd0[3], pd1[0], pd1[1]};
 #pragma unroll
             for (int f = 0; f < kEF; ++f) {
@@ -585,15 +653,230 @@ __global__ __launch_bounds__(256) void mpn_step_kernel(const StepParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// Specialised step kernel for the shipped GRAPH_NET_PARAMS shape (edge_in 4, no reattach, classifier 6->4->1 or
+// off, no debug taps): the same algorithm as mpn_step_kernel with every per-config decision made at compile
+// time, so the body is straight-line code whose loads issue back to back.  mpn_step_kernel stays as the
+// general / traced variant.
+// ------------------------------------------------------------------------------------------------------------
+template <bool FIRST, bool CLS, bool MSG, bool PD_LDS>
+__global__ __launch_bounds__(256) void mpn_step_fast_kernel(const StepParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* s_w = smem;                                      // [kFastConsts] per-step scalars (broadcast reads)
+    float* s_proj = s_w + kFastConsts;                      // [32][48]   (MSG)
+    float* s_part = s_proj + (MSG ? kH * kProjOut : 0);     // [4][32]
+    float* s_pd = s_part + 4 * kH;                          // [N][8]     (PD_LDS)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const float* __restrict__ blob = p.blob;
+
+    const unsigned gflags = p.flags[0];
+    const int wps = p.wps;
+    const int node = blockIdx.x * (4 / wps) + wave / wps;
+    const int sub = wave % wps;
+    const bool active = node < p.N;
+    const int nclamp = active ? node : 0;
+    int seg_s = p.seg_ptr[nclamp];
+    int seg_t = p.seg_ptr[nclamp + 1];
+    const int half = lane >> 5, ch = lane & 31;
+    const float* __restrict__ psq = p.psq_in + (size_t)nclamp * kPsQStride;
+    float psrc[kEF];
+#pragma unroll
+    for (int f = 0; f < kEF; ++f) psrc[f] = psq[f];
+    if (tid < kFastConsts) s_w[tid] = blob[p.off_fast + tid];
+    float cinit = 0.f;
+    float bw[3] = {0.f, 0.f, 0.f};
+    if (MSG) {
+        cinit = psq[8 + ch];
+#pragma unroll
+        for (int s = 0; s < 3; ++s) bw[s] = blob[p.off_wneb + s * 64 + lane];
+        const f32x4* __restrict__ g4 = reinterpret_cast<const f32x4*>(blob + p.off_projwT);
+        f32x4* l4 = reinterpret_cast<f32x4*>(s_proj);
+#pragma unroll
+        for (int i = 0; i < (kH * kProjOut / 4 + 255) / 256; ++i)
+            if (tid + i * 256 < kH * kProjOut / 4) l4[tid + i * 256] = g4[tid + i * 256];
+    }
+    if (PD_LDS) {
+        const f32x4* __restrict__ g4 = reinterpret_cast<const f32x4*>(p.pd_in);
+        f32x4* l4 = reinterpret_cast<f32x4*>(s_pd);
+        for (int i = tid; i < p.N * (kPdStride / 4); i += 256) l4[i] = g4[i];
+    }
+    if (gflags & GNNCCA_GRAPH_BAD_INDEX) {
+        if (CLS)
+            for (size_t k = (size_t)blockIdx.x * 256 + tid; k < (size_t)p.E; k += (size_t)gridDim.x * 256)
+                p.logits[k] = __builtin_nanf("");
+        return;
+    }
+    const bool unsorted = (gflags & GNNCCA_GRAPH_UNSORTED) != 0;
+    __syncthreads();
+    if (!active) seg_s = seg_t = 0;
+
+    f32x16 acc;  // 'sum' / 'mean' only: 'max' takes the general kernel
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    const float* wee = s_w + kFcWee;
+    const float* encw = s_w + kFcEncW;
+    const float* encb = s_w + kFcEncB;
+    const float* cw1 = s_w + kFcCw1;
+    const float* cb1 = s_w + kFcCb1;
+    const float* cw2 = s_w + kFcCw2;
+    const float* cb2 = s_w + kFcCb2;
+
+    for (int base = seg_s + 64 * sub; base < seg_t; base += 64 * wps) {
+        const int k = base + lane;
+        const bool valid = k < seg_t;
+        const int kk = valid ? k : seg_t - 1;
+        const int ko = unsorted ? p.perm[kk] : kk;
+        const int j = p.col32[kk];
+        float ein[kEF];
+        if (FIRST) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(p.edge_attr + (size_t)ko * 4);
+#pragma unroll
+            for (int f = 0; f < kEF; ++f) {
+                float s = encb[f];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) s = fmaf(encw[f * 4 + q], a[q], s);
+                ein[f] = fmaxf(s, 0.f);
+            }
+        } else {
+#pragma unroll
+            for (int f = 0; f < kEF; ++f) ein[f] = p.e[(size_t)f * p.e_stride + kk];
+        }
+        f32x4 pd0;
+        f32x2 pd1;
+        if (PD_LDS) {
+            pd0 = *reinterpret_cast<const f32x4*>(s_pd + j * kPdStride);
+            pd1 = *reinterpret_cast<const f32x2*>(s_pd + j * kPdStride + 4);
+        } else {
+            const float* __restrict__ pdj = p.pd_in + (size_t)j * kPdStride;
+            pd0 = *reinterpret_cast<const f32x4*>(pdj);
+            pd1 = *reinterpret_cast<const f32x2*>(pdj + 4);
+        }
+        const float pd[kEF] = {pd0[0], pd0[1], pd0[2], pd0[3], pd1[0], pd1[1]};
+        float en[kEF];
+#pragma unroll
+        for (int f = 0; f < kEF; ++f) {
+            float s = psrc[f] + pd[f];
+#pragma unroll
+            for (int g = 0; g < kEF; ++g) s = fmaf(wee[f * kEF + g], ein[g], s);
+            en[f] = fmaxf(s, 0.f);
+        }
+        if (p.store_e && valid) {
+#pragma unroll
+            for (int f = 0; f < kEF; ++f) p.e[(size_t)f * p.e_stride + k] = en[f];
+        }
+        if (CLS) {
+            float logit = cb2[0];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float z = cb1[q];
+#pragma unroll
+                for (int f = 0; f < kEF; ++f) z = fmaf(cw1[q * kEF + f], en[f], z);
+                logit = fmaf(cw2[q], fmaxf(z, 0.f), logit);
+            }
+            if (valid) p.logits[ko] = logit;
+        }
+        if (MSG) {
+            f32x16 d0, d1;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) d0[i] = d1[i] = cinit;
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(en[2 * s]), __float_as_uint(en[2 * s + 1]),
+                                                                false, false);
+                d0 = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(r[0]), bw[s], d0, 0, 0, 0);
+                d1 = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(r[1]), bw[s], d1, 0, 0, 0);
+            }
+            if (base + 64 <= seg_t) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    acc[i] += fmaxf(d0[i], 0.f) + fmaxf(d1[i], 0.f);
+                }
+            } else {
+                const int rem = seg_t - base - 4 * half;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int eo = (i & 3) + 8 * (i >> 2);
+                    const float m0 = (eo < rem) ? fmaxf(d0[i], 0.f) : 0.f;
+                    const float m1 = (eo + 32 < rem) ? fmaxf(d1[i], 0.f) : 0.f;
+                    acc[i] += m0 + m1;
+                }
+            }
+        }
+    }
+
+    if (MSG) {
+        float v = acc[0];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) v += acc[i];
+        v += __shfl_xor(v, 32);
+        if (wps > 1) {
+            if (lane < kH) s_part[wave * kH + lane] = v;
+            __syncthreads();
+            if (sub == 0) {
+                v = s_part[wave * kH + ch];
+                for (int u = 1; u < wps; ++u) v += s_part[(wave + u) * kH + ch];
+            }
+        }
+        if (active && sub == 0) {
+            const int deg = seg_t - seg_s;
+            if (p.agg == GNNCCA_AGG_MEAN) v = v / (float)max(deg, 1);
+            if (deg == 0) v = 0.f;
+            project_node(v, 0.f, false, s_proj, s_w + kFcProjB, p.pd_out + (size_t)node * kPdStride,
+                         p.psq_out + (size_t)node * kPsQStride, lane);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 static inline dim3 grid1(size_t n, int b) { return dim3((unsigned)((n + b - 1) / b)); }
+
+template <bool RE, bool MSG, bool MX>
+static hipError_t launch_step_t(const StepParams& sp, hipStream_t st) {
+    const int npg = 4 / sp.wps;
+    const unsigned blocks = (unsigned)((sp.N + npg - 1) / npg);
+    const size_t lds = ((MSG ? (size_t)sp.hin * kProjOut : 0) + 4 * kH + (sp.pd_lds ? (size_t)sp.N * kPdStride : 0)) * sizeof(float);
+    hipLaunchKernelGGL((mpn_step_kernel<RE, MSG, MX>), dim3(blocks), dim3(256), lds, st, sp);
+    return hipGetLastError();
+}
 
 template <bool RE, bool MSG>
 static hipError_t launch_step(const StepParams& sp, hipStream_t st) {
+    return sp.agg == GNNCCA_AGG_MAX ? launch_step_t<RE, MSG, true>(sp, st) : launch_step_t<RE, MSG, false>(sp, st);
+}
+
+template <bool FIRST, bool CLS, bool MSG, bool PDL>
+static hipError_t launch_fast(const StepParams& sp, hipStream_t st) {
     const int npg = 4 / sp.wps;
     const unsigned blocks = (unsigned)((sp.N + npg - 1) / npg);
-    const size_t lds = ((MSG ? (size_t)sp.hin * kProjOut : 0) + 4 * kH) * sizeof(float);
-    hipLaunchKernelGGL((mpn_step_kernel<RE, MSG>), dim3(blocks), dim3(256), lds, st, sp);
+    const size_t lds = (kFastConsts + (MSG ? (size_t)kH * kProjOut : 0) + 4 * kH + (PDL ? (size_t)sp.N * kPdStride : 0)) * sizeof(float);
+    hipLaunchKernelGGL((mpn_step_fast_kernel<FIRST, CLS, MSG, PDL>), dim3(blocks), dim3(256), lds, st, sp);
     return hipGetLastError();
+}
+
+static hipError_t launch_fast_dispatch(const StepParams& sp, bool msg, hipStream_t st) {
+    const int key = (sp.first ? 8 : 0) | (sp.cls_layers ? 4 : 0) | (msg ? 2 : 0) | (sp.pd_lds ? 1 : 0);
+    switch (key) {
+#define GNNCCA_FAST_CASE(K, A, B, C, D) \
+    case K: return launch_fast<A, B, C, D>(sp, st);
+        GNNCCA_FAST_CASE(0, false, false, false, false)
+        GNNCCA_FAST_CASE(1, false, false, false, true)
+        GNNCCA_FAST_CASE(2, false, false, true, false)
+        GNNCCA_FAST_CASE(3, false, false, true, true)
+        GNNCCA_FAST_CASE(4, false, true, false, false)
+        GNNCCA_FAST_CASE(5, false, true, false, true)
+        GNNCCA_FAST_CASE(6, false, true, true, false)
+        GNNCCA_FAST_CASE(7, false, true, true, true)
+        GNNCCA_FAST_CASE(8, true, false, false, false)
+        GNNCCA_FAST_CASE(9, true, false, false, true)
+        GNNCCA_FAST_CASE(10, true, false, true, false)
+        GNNCCA_FAST_CASE(11, true, false, true, true)
+        GNNCCA_FAST_CASE(12, true, true, false, false)
+        GNNCCA_FAST_CASE(13, true, true, false, true)
+        GNNCCA_FAST_CASE(14, true, true, true, false)
+        GNNCCA_FAST_CASE(15, true, true, true, true)
+#undef GNNCCA_FAST_CASE
+    }
+    return hipErrorInvalidValue;
 }
 
 }  // namespace gnncca
@@ -647,18 +930,6 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
     float* ebuf = reinterpret_cast<float*>(base + ws.e);
     float* e0buf = reinterpret_cast<float*>(base + ws.e0);
 
-    HIP_TRY(hipMemsetAsync(flags, 0, 256, st));
-    if (E > 0) {
-        const long long* ei = reinterpret_cast<const long long*>(edge_index);
-        hipLaunchKernelGGL(plan_rows_kernel, grid1((size_t)E, 256), dim3(256), 0, st, ei, E, N, seg_ptr, col32, flags);
-        HIP_TRY(hipGetLastError());
-        PROF_MARK(GNNCCA_K_PLAN_ROWS);
-        hipLaunchKernelGGL(plan_sort_fallback_kernel, dim3(1), dim3(1024), 0, st, ei, E, N, seg_ptr, col32, perm, cursor,
-                           (const unsigned*)flags);
-        HIP_TRY(hipGetLastError());
-        PROF_MARK(GNNCCA_K_PLAN_SORT);
-    }
-
     // ---- node encoder -------------------------------------------------------------------------------------
     const int nl = d->enc_node.n_layers;
     const int n_gemm = nl == 1 ? 1 : nl - 1;
@@ -673,9 +944,15 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
         const int vec_ok = (K % 4 == 0) && ((reinterpret_cast<uintptr_t>(cur_in) & 15) == 0);
         dim3 grid((N + 31) / 32, ks, (O + 127) / 128);
         hipLaunchKernelGGL(dense_rows_mfma_kernel, grid, dim3(256), 0, st, cur_in, blob + hdr.enc_node_w[g], part, N, K, O,
-                           kslice, vec_ok);
+                           kslice, vec_ok, g == 0 ? flags : (unsigned*)nullptr);
         HIP_TRY(hipGetLastError());
         PROF_MARK(GNNCCA_K_ENC_GEMM);
+        if (g == 0 && E > 0) {  // graph plan: after the launch that zeroed its flags, before anything that reads it
+            const long long* ei = reinterpret_cast<const long long*>(edge_index);
+            hipLaunchKernelGGL(plan_rows_kernel, grid1((size_t)E, 256), dim3(256), 0, st, ei, E, N, seg_ptr, col32, flags);
+            HIP_TRY(hipGetLastError());
+            PROF_MARK(GNNCCA_K_PLAN_ROWS);
+        }
         ks_last = ks;
         if (g < n_gemm - 1) {
             float* dst = act + (size_t)(g & 1) * N * O;
@@ -710,13 +987,21 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
         tp.relu_prev = lprev.relu;
         tp.reatt_n = d->reattach_nodes;
         tp.hin = hin;
-        const size_t lds = ((size_t)hin * kProjOut + (tp.has_last ? (size_t)tp.F * kH : 0) + 4 * (size_t)tp.F) * sizeof(float);
+        tp.vec_reduce = (tp.F % 4 == 0) && (tp.F / 4 <= 64) && (64 % (tp.F / 4) == 0);
+        const size_t lds = ((size_t)hin * kProjOut + (tp.has_last ? (size_t)tp.F * kH : 0) + 4 * (size_t)tp.F + 4 * 256) * sizeof(float);
         if (lds > 160 * 1024) return GNNCCA_ERR_UNSUPPORTED;
         if (lds > 64 * 1024)
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(enc_tail_kernel),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        const unsigned blocks = (unsigned)std::min<size_t>(((size_t)N + 3) / 4, 2048);
-        hipLaunchKernelGGL(enc_tail_kernel, dim3(blocks), dim3(256), lds, st, tp);
+        tp.ei = reinterpret_cast<const long long*>(edge_index);
+        tp.seg_ptr = seg_ptr;
+        tp.col32 = col32;
+        tp.perm = perm;
+        tp.cursor = cursor;
+        tp.flags = flags;
+        tp.E = E;
+        const unsigned blocks = (unsigned)std::min<size_t>(((size_t)N + 3) / 4, 2048) + 1;  // + plan-repair workgroup
+        hipLaunchKernelGGL(enc_tail_kernel, dim3(blocks), dim3(256), std::max<size_t>(lds, 4096), st, tp);
         HIP_TRY(hipGetLastError());
         PROF_MARK(GNNCCA_K_ENC_TAIL);
     }
@@ -749,6 +1034,7 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
     sp.off_cb1 = hdr.cls_b1;
     sp.off_cw2 = hdr.cls_w2;
     sp.off_cb2 = hdr.cls_b2;
+    sp.off_fast = hdr.fast_consts;
     sp.cls_hidden = hdr.cls_hidden;
     sp.N = N;
     sp.E = E;
@@ -758,6 +1044,7 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
     sp.reatt_n = d->reattach_nodes;
     sp.wps = chunks >= 4 ? 4 : (chunks >= 2 ? 2 : 1);
     sp.hin = hin;
+    sp.pd_lds = (N <= 1024) && d->num_enc_steps > 0;
     const bool re = d->reattach_edges != 0;
     int out_idx = 0;
     if (L == 0) {  // models/mpn.py:295-297: classify the encoded edge features once
@@ -786,7 +1073,10 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
         sp.trace_e = (trace && trace->e_steps) ? trace->e_steps + (size_t)(step - 1) * E * kEF : nullptr;
         sp.trace_h = want_h ? trace->h_steps + (size_t)(step - 1) * N * kH : nullptr;
         hipError_t err;
-        if (re)
+        const bool fast = hdr.fast_consts != 0 && sp.attr_vec && !trace && d->agg != GNNCCA_AGG_MAX;
+        if (fast)
+            err = launch_fast_dispatch(sp, msg, st);
+        else if (re)
             err = msg ? launch_step<true, true>(sp, st) : launch_step<true, false>(sp, st);
         else
             err = msg ? launch_step<false, true>(sp, st) : launch_step<false, false>(sp, st);

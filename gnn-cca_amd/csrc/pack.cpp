@@ -67,6 +67,11 @@ Family classify(const gnncca_mpn_dims* d) {
     return kFamilyMfma32x6;
 }
 
+bool fast_consts_ok(const gnncca_mpn_dims* d) {
+    return classify(d) == kFamilyMfma32x6 && d->edge_in == 4 && !d->reattach_nodes && !d->reattach_edges &&
+           d->cls_edge.n_layers == 2 && d->cls_edge.layers[0].out_dim == 4;
+}
+
 // ---------------------------------------------------------------------------------------------
 struct BlobPlan {
     BlobHeader h;
@@ -108,6 +113,7 @@ static BlobPlan plan_blob(const gnncca_mpn_dims* d) {
         p.h.cls_b1 = take(1);
         p.h.cls_w2 = p.h.cls_b2 = 0;
     }
+    p.h.fast_consts = fast_consts_ok(d) ? take(kFastConsts) : 0;
     p.total_floats = off;
     p.h.total_floats = (uint32_t)off;
     return p;
@@ -264,6 +270,17 @@ int gnncca_pack_weights(const gnncca_mpn_dims* d, const float* const* params, in
             std::memcpy(blob + p.h.cls_w2, f2.w.data(), f2.w.size() * sizeof(float));
             std::memcpy(blob + p.h.cls_b2, f2.b.data(), f2.b.size() * sizeof(float));
         }
+    }
+    if (p.h.fast_consts) {  // contiguous copy of the per-step scalars for the specialised kernel
+        float* fc = blob + p.h.fast_consts;
+        std::memcpy(fc + kFcEncW, blob + p.h.enc_edge_w, 24 * sizeof(float));
+        std::memcpy(fc + kFcEncB, blob + p.h.enc_edge_b, 6 * sizeof(float));
+        std::memcpy(fc + kFcWee, blob + p.h.wee, 36 * sizeof(float));
+        std::memcpy(fc + kFcCw1, blob + p.h.cls_w1, 24 * sizeof(float));
+        std::memcpy(fc + kFcCb1, blob + p.h.cls_b1, 4 * sizeof(float));
+        std::memcpy(fc + kFcCw2, blob + p.h.cls_w2, 4 * sizeof(float));
+        std::memcpy(fc + kFcCb2, blob + p.h.cls_b2, 1 * sizeof(float));
+        std::memcpy(fc + kFcProjB, blob + p.h.proj_b, kProjOut * sizeof(float));
     }
     return GNNCCA_OK;
 }
