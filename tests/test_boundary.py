@@ -1,0 +1,194 @@
+"""Boundary tests that need no GPU: the C-ABI library loads and exports every symbol the header declares, the
+module mirrors the reference's surface (constructor, state_dict keys, error behaviour), and the packed weight blob
+(csrc/pack.cpp: BN folding, weight splitting, transposes, MFMA operand layout) reproduces the oracle when the
+split-form algebra of DESIGN.md section 2 is evaluated from the blob alone (numpy, no compute calls into the library).
+"""
+import copy
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN_DIR, ROOT, golden_cases
+from oracle.mpn_oracle import NumpyOracle, load_case
+
+
+def _model(name):
+    from gnn_cca_amd import MOTMPNet
+    params, arch, sd, a = load_case(os.path.join(GOLDEN_DIR, name + ".npz"))
+    m = MOTMPNet(copy.deepcopy(params), None, arch)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    return m.eval(), params, arch, sd, a
+
+
+def test_library_exports_every_declared_symbol():
+    from gnn_cca_amd import _native as nat
+    header = open(os.path.join(ROOT, "include", "gnncca_mpn.h")).read()
+    declared = sorted(set(re.findall(r"GNNCCA_API[^;(]*?\b(gnncca_\w+)\s*\(", header)))
+    assert declared, "no declarations found in the header"
+    lib = nat.lib()
+    for name in declared:
+        assert hasattr(lib, name), f"libgnncca_mpn.so does not export {name}"
+    assert sorted(nat.exported_symbols()) == declared, "ctypes binding and header disagree"
+    assert lib.gnncca_abi_version() == nat.ABI_VERSION
+    assert lib.gnncca_status_string(2).decode().startswith("GRAPH_NET_PARAMS not supported")
+
+
+@pytest.mark.parametrize("name", golden_cases())
+def test_state_dict_keys_and_shapes_match_reference(name):
+    m, params, arch, sd, _ = _model(name)
+    mine = m.state_dict()
+    assert list(mine.keys()) == list(sd.keys())  # same keys, same order as the reference module
+    for k, v in sd.items():
+        assert tuple(mine[k].shape) == tuple(np.asarray(v).shape), k
+
+
+def test_constructor_contract():
+    from gnn_cca_amd import MOTMPNet
+    params, arch, _, _ = load_case(os.path.join(GOLDEN_DIR, "dense64.npz"))
+    p = copy.deepcopy(params)
+    MOTMPNet(p, None, arch)
+    assert p["encoder_feats_dict"]["edges"]["node_in_dim"] == 2048  # in-place merge, like mpn.py:167-169
+    bad = copy.deepcopy(params)
+    bad["node_agg_fn"] = "median"
+    with pytest.raises(AssertionError):
+        MOTMPNet(bad, None, arch)
+    bad = copy.deepcopy(params)
+    bad["edge_model_feats_dict"]["fc_dims"] = 6
+    with pytest.raises(AssertionError):
+        MOTMPNet(bad, None, arch)
+    bad = copy.deepcopy(params)
+    del bad["num_class_steps"]
+    with pytest.raises(KeyError):
+        MOTMPNet(bad, None, arch)
+    with pytest.raises(KeyError):
+        MOTMPNet(copy.deepcopy(params), None, "no_such_arch")
+
+
+def test_no_cpu_fallback_and_train_mode_refused():
+    m, _, _, _, a = _model("n8_sum")
+
+    class D:
+        x, edge_index, edge_attr = (torch.from_numpy(a[k]) for k in ("x", "edge_index", "edge_attr"))
+
+    with pytest.raises(RuntimeError):
+        m(D())
+    m.train()
+    with pytest.raises(NotImplementedError):
+        m(D())
+
+
+def test_supported_family_and_counts():
+    from gnn_cca_amd import _native as nat
+    lib = nat.lib()
+    for name in golden_cases():
+        m, params, _, sd, _ = _model(name)
+        d = m.native_dims()
+        assert lib.gnncca_param_count(C.byref(d)) == len(m.native_param_tensors())
+        n_out = 1 if params["num_enc_steps"] == 0 else min(params["num_enc_steps"], params["num_class_steps"])
+        assert lib.gnncca_num_outputs(C.byref(d)) == n_out
+        sup = lib.gnncca_supported(C.byref(d))
+        assert sup == (nat.ERR_UNSUPPORTED if name == "generic_dims" else nat.OK), name
+        if sup == nat.OK:
+            assert lib.gnncca_workspace_bytes(C.byref(d), 256, 65280) > 0
+            assert lib.gnncca_packed_weights_bytes(C.byref(d)) > 0
+        else:
+            assert lib.gnncca_workspace_bytes(C.byref(d), 256, 65280) == 0
+            with pytest.raises(NotImplementedError):
+                m.pack_weights_host()
+    bad = nat.MpnDims()
+    assert lib.gnncca_supported(C.byref(bad)) == nat.ERR_INVALID_ARG
+
+
+# ---- the packed blob, evaluated with the split-form algebra in numpy ------------------------------------------
+class BlobHeader(C.Structure):  # mirror of csrc/internal.h: BlobHeader
+    _fields_ = [("magic", C.c_uint32), ("abi_version", C.c_uint32), ("family", C.c_uint32),
+                ("total_floats", C.c_uint32), ("enc_node_layers", C.c_int32), ("enc_node_w", C.c_int32 * 8),
+                ("enc_node_b", C.c_int32 * 8), ("enc_last_wT", C.c_int32), ("enc_edge_w", C.c_int32),
+                ("enc_edge_b", C.c_int32), ("wee", C.c_int32), ("wne_b", C.c_int32), ("proj_wT", C.c_int32),
+                ("proj_b", C.c_int32), ("cls_layers", C.c_int32), ("cls_hidden", C.c_int32), ("cls_w1", C.c_int32),
+                ("cls_b1", C.c_int32), ("cls_w2", C.c_int32), ("cls_b2", C.c_int32), ("fast_consts", C.c_int32),
+                ("pad", C.c_int32 * 7)]
+
+
+def blob_forward(blob_u8, params, arch, x, edge_index, edge_attr):
+    raw = blob_u8.numpy().tobytes()
+    h = BlobHeader.from_buffer_copy(raw[:C.sizeof(BlobHeader)])
+    f = np.frombuffer(raw, dtype=np.float32)
+    assert h.magic == 0x4D504E31 and h.total_floats * 4 == len(raw)
+    enc = params["encoder_feats_dict"]["nodes"][arch]
+    dims = [enc["node_in_dim"]] + list(enc["node_fc_dims"]) + [enc["node_out_dim"]]
+    nf = 2 if params["reattach_initial_nodes"] else 1
+    ef = 2 if params["reattach_initial_edges"] else 1
+    edge_in = params["encoder_feats_dict"]["edges"]["edge_in_dim"]
+    relu = lambda v: np.maximum(v, 0)
+    hcur = x
+    for i in range(h.enc_node_layers):
+        W = f[h.enc_node_w[i]:h.enc_node_w[i] + dims[i] * dims[i + 1]].reshape(dims[i + 1], dims[i])
+        if i == h.enc_node_layers - 1:  # the transposed copy must agree with the row-major one
+            WT = f[h.enc_last_wT:h.enc_last_wT + dims[i] * 32].reshape(dims[i], 32)
+            assert np.array_equal(WT.T, W)
+        hcur = relu(hcur @ W.T + f[h.enc_node_b[i]:h.enc_node_b[i] + dims[i + 1]])
+    h0 = hcur
+    e = relu(edge_attr @ f[h.enc_edge_w:h.enc_edge_w + 6 * edge_in].reshape(6, edge_in).T + f[h.enc_edge_b:h.enc_edge_b + 6])
+    e0 = e
+    projT = f[h.proj_wT:h.proj_wT + nf * 32 * 48].reshape(nf * 32, 48)
+    projb = f[h.proj_b:h.proj_b + 48]
+    wee = f[h.wee:h.wee + 6 * ef * 6].reshape(6, ef * 6)
+    wneb = f[h.wne_b:h.wne_b + 192].reshape(3, 64)
+    wne = np.zeros((32, 6), np.float32)
+    for s in range(3):
+        for l in range(64):
+            wne[l & 31, 2 * s + (l >> 5)] = wneb[s, l]
+    row, col = edge_index
+    n = x.shape[0]
+    L, first = params["num_enc_steps"], params["num_enc_steps"] - params["num_class_steps"] + 1
+
+    def classify(ee):
+        if h.cls_layers == 2:
+            c1 = h.cls_hidden
+            z = relu(ee @ f[h.cls_w1:h.cls_w1 + c1 * 6].reshape(c1, 6).T + f[h.cls_b1:h.cls_b1 + c1])
+            return z @ f[h.cls_w2:h.cls_w2 + c1].reshape(c1, 1) + f[h.cls_b2]
+        return ee @ f[h.cls_w1:h.cls_w1 + 6].reshape(6, 1) + f[h.cls_b1]
+
+    out, hl = [], h0
+    for step in range(1, L + 1):
+        hin = np.concatenate([h0, hl], 1) if nf == 2 else hl
+        proj = hin @ projT + projb
+        pdst, psrc, q = proj[:, 0:6], proj[:, 8:14], proj[:, 16:48]
+        ein = np.concatenate([e0, e], 1) if ef == 2 else e
+        e = relu(psrc[row] + pdst[col] + ein @ wee.T)
+        m = relu(q[row] + e @ wne.T)
+        agg = params["node_agg_fn"]
+        if agg == "max":
+            full = np.full((n, 32), -np.inf, np.float32)
+            np.maximum.at(full, row, m)
+            has = np.zeros(n, bool)
+            has[row] = True
+            hl = np.where(has[:, None], full, 0).astype(np.float32)
+        else:
+            hl = np.zeros((n, 32), np.float32)
+            np.add.at(hl, row, m)
+            if agg == "mean":
+                hl = hl / np.maximum(np.bincount(row, minlength=n), 1)[:, None].astype(np.float32)
+        if step >= first:
+            out.append(classify(e))
+    if L == 0:
+        out.append(classify(e))
+    if h.fast_consts:
+        fc = f[h.fast_consts:h.fast_consts + 152]
+        assert np.array_equal(fc[32:68], f[h.wee:h.wee + 36]) and np.array_equal(fc[104:152], projb)
+        assert np.array_equal(fc[0:24], f[h.enc_edge_w:h.enc_edge_w + 24]) and fc[100] == f[h.cls_b2]
+    return out
+
+
+@pytest.mark.parametrize("name", [n for n in golden_cases() if n != "generic_dims"])
+def test_packed_blob_reproduces_reference(name):
+    m, params, arch, sd, a = _model(name)
+    out = blob_forward(m.pack_weights_host(), params, arch, a["x"], a["edge_index"], a["edge_attr"])
+    assert len(out) == int(a["n_logits"])
+    for i, o in enumerate(out):
+        assert np.abs(o - a[f"logits_{i}"]).max() <= 5e-6, (name, i)
