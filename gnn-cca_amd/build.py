@@ -35,7 +35,10 @@ def build(force=False, verbose=False):
     os.makedirs(LIB_DIR, exist_ok=True)
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-x", "hip",
            "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-Wall", "-Wno-unused-function",
-           "-fvisibility=hidden", "-DGNNCCA_BUILD"]
+           "-fvisibility=hidden", "-DGNNCCA_BUILD",
+           # keep MFMA accumulators in VGPRs: the step kernels post-process every accumulator element on the VALU
+           # (ReLU + segment sum), and AGPR results would cost one v_accvgpr_read per element
+           "-mllvm", "-amdgpu-mfma-vgpr-form"]
     cmd += [os.path.join(CSRC, s) for s in SOURCES]
     cmd += ["-o", LIB_PATH + ".tmp"]
     if verbose:

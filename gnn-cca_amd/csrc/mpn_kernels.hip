@@ -661,14 +661,18 @@ __global__ __launch_bounds__(256) void mpn_step_kernel(const StepParams p) {
 template <bool FIRST, bool CLS, bool MSG, bool PD_LDS>
 __global__ __launch_bounds__(256) void mpn_step_fast_kernel(const StepParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* s_w = smem;                                      // [kFastConsts] per-step scalars (broadcast reads)
-    float* s_proj = s_w + kFastConsts;                      // [32][48]   (MSG)
+    float* s_proj = smem;                                   // [32][48]   (MSG)
     float* s_part = s_proj + (MSG ? kH * kProjOut : 0);     // [4][32]
     float* s_pd = s_part + 4 * kH;                          // [N][8]     (PD_LDS)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const float* __restrict__ blob = p.blob;
+    // Per-step scalars (152 floats) are read through the CONSTANT address space: wave-uniform addresses there
+    // become s_load into SGPRs, which the VALU takes as operands directly -- no LDS, no VGPR copies.
+    typedef const float __attribute__((address_space(4))) cfloat;
+    cfloat* cw = (cfloat*)(unsigned long long)(blob + p.off_fast);
 
+    // ---- prologue: every independent load is issued before the first wait ----------------------------------
     const unsigned gflags = p.flags[0];
     const int wps = p.wps;
     const int node = blockIdx.x * (4 / wps) + wave / wps;
@@ -682,23 +686,36 @@ __global__ __launch_bounds__(256) void mpn_step_fast_kernel(const StepParams p) 
     float psrc[kEF];
 #pragma unroll
     for (int f = 0; f < kEF; ++f) psrc[f] = psq[f];
-    if (tid < kFastConsts) s_w[tid] = blob[p.off_fast + tid];
     float cinit = 0.f;
     float bw[3] = {0.f, 0.f, 0.f};
+    f32x4 stage_proj[2];
+    f32x4 stage_pd[8];
+    float projb_l = 0.f;
     if (MSG) {
         cinit = psq[8 + ch];
+        projb_l = blob[p.off_projb + min(lane, kProjOut - 1)];
 #pragma unroll
         for (int s = 0; s < 3; ++s) bw[s] = blob[p.off_wneb + s * 64 + lane];
         const f32x4* __restrict__ g4 = reinterpret_cast<const f32x4*>(blob + p.off_projwT);
-        f32x4* l4 = reinterpret_cast<f32x4*>(s_proj);
+        stage_proj[0] = g4[tid];                                   // 384 float4 in all
+        stage_proj[1] = g4[min(tid + 256, kH * kProjOut / 4 - 1)];
+    }
+    const int pd_n4 = p.N * (kPdStride / 4);
+    if (PD_LDS) {  // N <= 1024: at most 8 float4 per thread
+        const f32x4* __restrict__ g4 = reinterpret_cast<const f32x4*>(p.pd_in);
 #pragma unroll
-        for (int i = 0; i < (kH * kProjOut / 4 + 255) / 256; ++i)
-            if (tid + i * 256 < kH * kProjOut / 4) l4[tid + i * 256] = g4[tid + i * 256];
+        for (int i = 0; i < 8; ++i) stage_pd[i] = g4[min(tid + i * 256, pd_n4 - 1)];
+    }
+    if (MSG) {
+        f32x4* l4 = reinterpret_cast<f32x4*>(s_proj);
+        l4[tid] = stage_proj[0];
+        if (tid + 256 < kH * kProjOut / 4) l4[tid + 256] = stage_proj[1];
     }
     if (PD_LDS) {
-        const f32x4* __restrict__ g4 = reinterpret_cast<const f32x4*>(p.pd_in);
         f32x4* l4 = reinterpret_cast<f32x4*>(s_pd);
-        for (int i = tid; i < p.N * (kPdStride / 4); i += 256) l4[i] = g4[i];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (tid + i * 256 < pd_n4) l4[tid + i * 256] = stage_pd[i];
     }
     if (gflags & GNNCCA_GRAPH_BAD_INDEX) {
         if (CLS)
@@ -707,57 +724,64 @@ __global__ __launch_bounds__(256) void mpn_step_fast_kernel(const StepParams p) 
         return;
     }
     const bool unsorted = (gflags & GNNCCA_GRAPH_UNSORTED) != 0;
-    __syncthreads();
+    if (MSG || PD_LDS) __syncthreads();
     if (!active) seg_s = seg_t = 0;
 
     f32x16 acc;  // 'sum' / 'mean' only: 'max' takes the general kernel
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    const float* wee = s_w + kFcWee;
-    const float* encw = s_w + kFcEncW;
-    const float* encb = s_w + kFcEncB;
-    const float* cw1 = s_w + kFcCw1;
-    const float* cb1 = s_w + kFcCb1;
-    const float* cw2 = s_w + kFcCw2;
-    const float* cb2 = s_w + kFcCb2;
+    const int last = seg_t - 1;
 
-    for (int base = seg_s + 64 * sub; base < seg_t; base += 64 * wps) {
+    struct Chunk {
+        float raw[kEF];
+        float pd[kEF];
+        int ko;
+    };
+    auto load_chunk = [&](int base, Chunk& c) {
+        const int kk = min(base + lane, last);
+        c.ko = unsorted ? p.perm[kk] : kk;
+        const int j = p.col32[kk];
+        if (FIRST) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(p.edge_attr + (size_t)c.ko * 4);
+            c.raw[0] = a[0], c.raw[1] = a[1], c.raw[2] = a[2], c.raw[3] = a[3], c.raw[4] = 0.f, c.raw[5] = 0.f;
+        } else {
+#pragma unroll
+            for (int f = 0; f < kEF; ++f) c.raw[f] = p.e[(size_t)f * p.e_stride + kk];
+        }
+        f32x4 a;
+        f32x2 b2;
+        if (PD_LDS) {
+            a = *reinterpret_cast<const f32x4*>(s_pd + j * kPdStride);
+            b2 = *reinterpret_cast<const f32x2*>(s_pd + j * kPdStride + 4);
+        } else {
+            const float* __restrict__ pdj = p.pd_in + (size_t)j * kPdStride;
+            a = *reinterpret_cast<const f32x4*>(pdj);
+            b2 = *reinterpret_cast<const f32x2*>(pdj + 4);
+        }
+        c.pd[0] = a[0], c.pd[1] = a[1], c.pd[2] = a[2], c.pd[3] = a[3], c.pd[4] = b2[0], c.pd[5] = b2[1];
+    };
+    auto compute_chunk = [&](int base, const Chunk& c) {
         const int k = base + lane;
         const bool valid = k < seg_t;
-        const int kk = valid ? k : seg_t - 1;
-        const int ko = unsorted ? p.perm[kk] : kk;
-        const int j = p.col32[kk];
         float ein[kEF];
         if (FIRST) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(p.edge_attr + (size_t)ko * 4);
 #pragma unroll
             for (int f = 0; f < kEF; ++f) {
-                float s = encb[f];
+                float s = cw[kFcEncB + f];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) s = fmaf(encw[f * 4 + q], a[q], s);
+                for (int q = 0; q < 4; ++q) s = fmaf(cw[kFcEncW + f * 4 + q], c.raw[q], s);
                 ein[f] = fmaxf(s, 0.f);
             }
         } else {
 #pragma unroll
-            for (int f = 0; f < kEF; ++f) ein[f] = p.e[(size_t)f * p.e_stride + kk];
+            for (int f = 0; f < kEF; ++f) ein[f] = c.raw[f];
         }
-        f32x4 pd0;
-        f32x2 pd1;
-        if (PD_LDS) {
-            pd0 = *reinterpret_cast<const f32x4*>(s_pd + j * kPdStride);
-            pd1 = *reinterpret_cast<const f32x2*>(s_pd + j * kPdStride + 4);
-        } else {
-            const float* __restrict__ pdj = p.pd_in + (size_t)j * kPdStride;
-            pd0 = *reinterpret_cast<const f32x4*>(pdj);
-            pd1 = *reinterpret_cast<const f32x2*>(pdj + 4);
-        }
-        const float pd[kEF] = {pd0[0], pd0[1], pd0[2], pd0[3], pd1[0], pd1[1]};
         float en[kEF];
 #pragma unroll
         for (int f = 0; f < kEF; ++f) {
-            float s = psrc[f] + pd[f];
+            float s = psrc[f] + c.pd[f];
 #pragma unroll
-            for (int g = 0; g < kEF; ++g) s = fmaf(wee[f * kEF + g], ein[g], s);
+            for (int g = 0; g < kEF; ++g) s = fmaf(cw[kFcWee + f * kEF + g], ein[g], s);
             en[f] = fmaxf(s, 0.f);
         }
         if (p.store_e && valid) {
@@ -765,15 +789,15 @@ __global__ __launch_bounds__(256) void mpn_step_fast_kernel(const StepParams p) 
             for (int f = 0; f < kEF; ++f) p.e[(size_t)f * p.e_stride + k] = en[f];
         }
         if (CLS) {
-            float logit = cb2[0];
+            float logit = cw[kFcCb2];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                float z = cb1[q];
+                float z = cw[kFcCb1 + q];
 #pragma unroll
-                for (int f = 0; f < kEF; ++f) z = fmaf(cw1[q * kEF + f], en[f], z);
-                logit = fmaf(cw2[q], fmaxf(z, 0.f), logit);
+                for (int f = 0; f < kEF; ++f) z = fmaf(cw[kFcCw1 + q * kEF + f], en[f], z);
+                logit = fmaf(cw[kFcCw2 + q], fmaxf(z, 0.f), logit);
             }
-            if (valid) p.logits[ko] = logit;
+            if (valid) p.logits[c.ko] = logit;
         }
         if (MSG) {
             f32x16 d0, d1;
@@ -788,9 +812,7 @@ __global__ __launch_bounds__(256) void mpn_step_fast_kernel(const StepParams p) 
             }
             if (base + 64 <= seg_t) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    acc[i] += fmaxf(d0[i], 0.f) + fmaxf(d1[i], 0.f);
-                }
+                for (int i = 0; i < 16; ++i) acc[i] += fmaxf(d0[i], 0.f) + fmaxf(d1[i], 0.f);
             } else {
                 const int rem = seg_t - base - 4 * half;
 #pragma unroll
@@ -802,6 +824,17 @@ __global__ __launch_bounds__(256) void mpn_step_fast_kernel(const StepParams p) 
                 }
             }
         }
+    };
+
+    // Two chunks (128 edges, 3.6 KB of loads) are requested before the first one is consumed.
+    const int stride = 64 * wps;
+    for (int base = seg_s + 64 * sub; base < seg_t; base += 2 * stride) {
+        Chunk c0, c1;
+        const bool two = base + stride < seg_t;
+        load_chunk(base, c0);
+        if (two) load_chunk(base + stride, c1);
+        compute_chunk(base, c0);
+        if (two) compute_chunk(base + stride, c1);
     }
 
     if (MSG) {
@@ -821,8 +854,17 @@ __global__ __launch_bounds__(256) void mpn_step_fast_kernel(const StepParams p) 
             const int deg = seg_t - seg_s;
             if (p.agg == GNNCCA_AGG_MEAN) v = v / (float)max(deg, 1);
             if (deg == 0) v = 0.f;
-            project_node(v, 0.f, false, s_proj, s_w + kFcProjB, p.pd_out + (size_t)node * kPdStride,
-                         p.psq_out + (size_t)node * kPsQStride, lane);
+            // projection epilogue (project_node with the bias read through the constant address space)
+            const int o = min(lane, kProjOut - 1);
+            float pr = projb_l;
+            const float* w = s_proj + o;
+#pragma unroll
+            for (int c = 0; c < kH; ++c)
+                pr = fmaf(w[c * kProjOut], __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), c)), pr);
+            if (lane < kPdStride)
+                p.pd_out[(size_t)node * kPdStride + lane] = pr;
+            else if (lane < kProjOut)
+                p.psq_out[(size_t)node * kPsQStride + lane - kPdStride] = pr;
         }
     }
 }
@@ -848,7 +890,7 @@ template <bool FIRST, bool CLS, bool MSG, bool PDL>
 static hipError_t launch_fast(const StepParams& sp, hipStream_t st) {
     const int npg = 4 / sp.wps;
     const unsigned blocks = (unsigned)((sp.N + npg - 1) / npg);
-    const size_t lds = (kFastConsts + (MSG ? (size_t)kH * kProjOut : 0) + 4 * kH + (PDL ? (size_t)sp.N * kPdStride : 0)) * sizeof(float);
+    const size_t lds = ((MSG ? (size_t)kH * kProjOut : 0) + 4 * kH + (PDL ? (size_t)sp.N * kPdStride : 0)) * sizeof(float);
     hipLaunchKernelGGL((mpn_step_fast_kernel<FIRST, CLS, MSG, PDL>), dim3(blocks), dim3(256), lds, st, sp);
     return hipGetLastError();
 }
@@ -1042,7 +1084,15 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
     sp.attr_vec = d->edge_in == 4 && (reinterpret_cast<uintptr_t>(edge_attr) & 15) == 0;
     sp.agg = d->agg;
     sp.reatt_n = d->reattach_nodes;
-    sp.wps = chunks >= 4 ? 4 : (chunks >= 2 ? 2 : 1);
+    // waves per source-node segment: split a segment over 2 or 4 waves only while that is needed to put ~4 waves on
+    // every SIMD (small graphs are latency-bound); big batches keep one wave per node, which amortises the
+    // per-node prologue / projection epilogue over all of the node's chunks
+    {
+        const long long want = 4096 / (long long)N;  // waves per node that would fill the chip
+        int wps = chunks >= 4 ? 4 : (chunks >= 2 ? 2 : 1);
+        while (wps > 1 && wps > want) wps >>= 1;
+        sp.wps = wps;
+    }
     sp.hin = hin;
     sp.pd_lds = (N <= 1024) && d->num_enc_steps > 0;
     const bool re = d->reattach_edges != 0;
