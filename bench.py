@@ -150,7 +150,7 @@ def main():
     ap.add_argument("--nodes", type=int, default=256)
     ap.add_argument("--graphs", type=int, default=1, help="independent graphs per GPU per step")
     ap.add_argument("--L", type=int, default=4)
-    ap.add_argument("--mode", choices=["eager", "graph"], default="eager",
+    ap.add_argument("--mode", choices=["eager", "graph"], default="graph",
                     help="eager: one C-ABI call per step; graph: the same call captured once in a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-reps", type=int, default=20)
@@ -234,6 +234,16 @@ def main():
         step_ms = float(np.mean(kernel_ms["step"])) if "step" in kernel_ms else float("nan")
         alg = float(np.mean(per_launch)) if per_launch else 0.0
         achieved = alg / (step_ms * 1e-3) / 1e9 if step_ms == step_ms and step_ms > 0 else 0.0
+        # HBM bytes per launch of the dominant kernel from the PMC passes (tools/collect_profiles.py -> profiles/):
+        # separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, gfx950 correction applied
+        traffic, rocprof_us = None, None
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_index.json")) as f:
+                ent = json.load(f).get(f"{args.graphs}x{args.nodes}_L{args.L}")
+            if ent:
+                traffic, rocprof_us = ent["hbm_bytes_per_launch"], ent["rocprof_avg_us"]
+        except OSError:
+            pass
         res = {
             "metric": "processed edges/sec (L=4 MPN steps), 256-node dense graph",
             "value": world * E * args.steps / t,
@@ -252,8 +262,9 @@ def main():
                        "mode": args.mode, "outputs_finite": bool(ok),
                        "edge_steps_per_s": world * E * args.L * args.steps / t},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                         "kernel": "mpn_step_kernel<false,true>", "avg_launch_us": step_ms * 1e3,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "kernel": "mpn_step_fast_kernel<FIRST|CLS,MSG> (message-passing step, L-1 launches/forward)",
+                         "avg_launch_us": step_ms * 1e3, "rocprof_avg_launch_us": rocprof_us,
                          "algorithmic_bytes_per_launch": alg,
                          "note": "working set is L2/Infinity-Cache resident at this size: latency-bound, not HBM-bound"
                          if E * 48 < 200e6 else ""},

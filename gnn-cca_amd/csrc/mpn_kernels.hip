@@ -87,8 +87,7 @@ static int prof_end(Profiler* p, hipStream_t st) {
 // next launch on the stream (enc_tail_kernel) then repairs the plan alone with a STABLE counting sort by `row`
 // (plan_sort_fallback), so that every segment keeps the caller's edge order -- the order torch's CPU index_add_
 // (and with it the reference on CPU) sums in.  Only correctness matters on that branch: the reference never
-// produces such graphs.  The kernel boundary orders it after this kernel's stores; no in-launch hand-off.
-// flags[0] is zeroed by the first encoder GEMM launch, which precedes this kernel on the stream.
+// produces such graphs.  The kernel boundary orders it after the plan's stores; no in-launch hand-off.
 // ------------------------------------------------------------------------------------------------------------
 __device__ void plan_sort_fallback(const long long* __restrict__ ei, int E, int N, int* seg_ptr, int* col32, int* perm,
                                    int* cursor, int* s_rows, int* s_scan, int* s_carry) {
@@ -139,14 +138,18 @@ __device__ void plan_sort_fallback(const long long* __restrict__ ei, int E, int 
     }
 }
 
-__global__ __launch_bounds__(256) void plan_rows_kernel(const long long* __restrict__ ei, int E, int N,
-                                                        int* __restrict__ seg_ptr, int* __restrict__ col32,
-                                                        unsigned* __restrict__ flags) {
-    const int k = blockIdx.x * 256 + threadIdx.x;
+// Thread-per-edge part of the plan.  Every workgroup reports its findings in its OWN word (`blockflags[b]`, always
+// written, so there is no state to clear between forwards); the tail launch ORs them into flags[0].
+__device__ __forceinline__ void plan_block(int pb, const long long* __restrict__ ei, int E, int N,
+                                           int* __restrict__ seg_ptr, int* __restrict__ col32,
+                                           unsigned* __restrict__ blockflags, unsigned* s_fl) {
+    if (threadIdx.x == 0) *s_fl = 0u;
+    __syncthreads();
+    const int k = pb * 256 + threadIdx.x;
     if (k < E) {
         const long long r = ei[k], c = ei[(size_t)E + k];
         if (r < 0 || r >= N || c < 0 || c >= N) {
-            atomicOr(&flags[0], GNNCCA_GRAPH_BAD_INDEX);
+            atomicOr(s_fl, GNNCCA_GRAPH_BAD_INDEX);
         } else {
             col32[k] = (int)c;
             long long rp = -1;
@@ -157,7 +160,7 @@ __global__ __launch_bounds__(256) void plan_rows_kernel(const long long* __restr
             }
             if (prev_ok) {
                 if (r < rp) {
-                    atomicOr(&flags[0], GNNCCA_GRAPH_UNSORTED);
+                    atomicOr(s_fl, GNNCCA_GRAPH_UNSORTED);
                 } else {
                     for (long long n = rp + 1; n <= r; ++n) seg_ptr[n] = k;
                 }
@@ -166,6 +169,8 @@ __global__ __launch_bounds__(256) void plan_rows_kernel(const long long* __restr
             }
         }
     }
+    __syncthreads();
+    if (threadIdx.x == 0) blockflags[pb] = *s_fl;
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -173,19 +178,15 @@ __global__ __launch_bounds__(256) void plan_rows_kernel(const long long* __restr
 // fp32 FMA chain).  One wave = 32 rows x 32 output columns; a workgroup = 4 waves = 128 columns.
 // k-permutation: within a 64-deep chunk, lane (r, h) feeds k = kc + 32h + s at MFMA step s for BOTH operands, so
 // every lane reads 128 contiguous bytes of its own row (8 x float4) and no LDS transpose is needed.
-// Split-K over blockIdx.y fills the chip when M is small (M = 256 nodes -> 8 row tiles x 32 slices).
+// Split-K fills the chip when M is small (M = 256 nodes -> 8 row tiles x 32 slices).
 // Replaces the first nn.Linear of encoder.node_mlp (models/mpn.py:131 <- models/mlp.py:13).
 // ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void dense_rows_mfma_kernel(const float* __restrict__ in, const float* __restrict__ W,
-                                                              float* __restrict__ part, int M, int K, int O,
-                                                              int kslice, int vec_ok, unsigned* __restrict__ zero_flags) {
-    if (zero_flags && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x < 4)
-        zero_flags[threadIdx.x] = 0u;  // graph flag word + plan arrival counter of this forward
+__device__ __forceinline__ void gemm_tile(int rt, int ks, int cg, const float* __restrict__ in, const float* __restrict__ W,
+                                          float* __restrict__ part, int M, int K, int O, int kslice, int vec_ok) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const int row0 = blockIdx.x * 32;
-    const int ks = blockIdx.y;
-    const int col0 = (blockIdx.z * 4 + wave) * 32;
+    const int row0 = rt * 32;
+    const int col0 = (cg * 4 + wave) * 32;
     if (col0 >= O) return;
     const int arow = min(row0 + r, M - 1);
     const int wrow = min(col0 + r, O - 1);
@@ -226,6 +227,30 @@ __global__ __launch_bounds__(256) void dense_rows_mfma_kernel(const float* __res
     for (int i = 0; i < 16; ++i) {
         const int row = row0 + (i & 3) + 8 * (i >> 2) + 4 * h;
         if (row < M && col < O) part[((size_t)ks * M + row) * O + col] = acc[i];
+    }
+}
+
+// One launch, two roles: workgroups [0, gemm_blocks) run encoder GEMM tiles, the rest run the graph plan -- the
+// two are independent, so the plan's HBM pass over edge_index hides under the GEMM instead of costing a launch.
+struct EncPlanParams {
+    const float* in;
+    const float* W;
+    float* part;
+    const long long* ei;
+    int* seg_ptr;
+    int* col32;
+    unsigned* blockflags;
+    int M, K, O, kslice, vec_ok, nrt, nks, gemm_blocks, E, N;
+};
+
+__global__ __launch_bounds__(256) void enc_gemm_plan_kernel(const EncPlanParams p) {
+    __shared__ unsigned s_fl;
+    const int b = blockIdx.x;
+    if (b < p.gemm_blocks) {
+        const int rt = b % p.nrt, t = b / p.nrt;
+        gemm_tile(rt, t % p.nks, t / p.nks, p.in, p.W, p.part, p.M, p.K, p.O, p.kslice, p.vec_ok);
+    } else {
+        plan_block(b - p.gemm_blocks, p.ei, p.E, p.N, p.seg_ptr, p.col32, p.blockflags, &s_fl);
     }
 }
 
@@ -286,7 +311,8 @@ struct TailParams {
     int* col32;
     int* perm;
     int* cursor;
-    const unsigned* flags;
+    unsigned* flags;
+    const unsigned* blockflags;
     int E;
 };
 
@@ -298,13 +324,23 @@ __global__ __launch_bounds__(256) void enc_tail_kernel(const TailParams p) {
     float* s_red = s_row + 4 * p.F;                          // [4][64 floats x 4]  (vec_reduce)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* __restrict__ blob = p.blob;
-    if (blockIdx.x == gridDim.x - 1) {  // the plan-repair workgroup
-        if (p.E > 0) {
-            const unsigned fl = p.flags[0];
-            if ((fl & GNNCCA_GRAPH_UNSORTED) && !(fl & GNNCCA_GRAPH_BAD_INDEX)) {
-                int* si = reinterpret_cast<int*>(smem);
-                plan_sort_fallback(p.ei, p.E, p.N, p.seg_ptr, p.col32, p.perm, p.cursor, si, si + 256, si + 512);
-            }
+    if (blockIdx.x == gridDim.x - 1) {  // the plan workgroup: fold the per-block findings, repair if needed
+        unsigned* su = reinterpret_cast<unsigned*>(smem);
+        unsigned fl = 0u;
+        const int nb = (p.E + 255) / 256;
+        for (int i = tid; i < nb; i += 256) fl |= p.blockflags[i];
+        su[tid] = fl;
+        __syncthreads();
+        for (int d = 128; d > 0; d >>= 1) {
+            if (tid < d) su[tid] |= su[tid + d];
+            __syncthreads();
+        }
+        fl = su[0];
+        __syncthreads();
+        if (tid == 0) p.flags[0] = fl;
+        if ((fl & GNNCCA_GRAPH_UNSORTED) && !(fl & GNNCCA_GRAPH_BAD_INDEX)) {
+            int* si = reinterpret_cast<int*>(smem);
+            plan_sort_fallback(p.ei, p.E, p.N, p.seg_ptr, p.col32, p.perm, p.cursor, si, si + 256, si + 512);
         }
         return;
     }
@@ -964,6 +1000,7 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
     int* col32 = reinterpret_cast<int*>(base + ws.col32);
     int* perm = reinterpret_cast<int*>(base + ws.perm);
     int* cursor = reinterpret_cast<int*>(base + ws.cursor);
+    unsigned* blockflags = reinterpret_cast<unsigned*>(base + ws.blockflags);
     float* h0 = reinterpret_cast<float*>(base + ws.h0);
     float* act = reinterpret_cast<float*>(base + ws.act);
     float* part = reinterpret_cast<float*>(base + ws.partial);
@@ -983,18 +1020,32 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
         const int ks = g == 0 ? ws.ksplit : 1;
         int kslice = (K + ks - 1) / ks;
         kslice = (kslice + 63) / 64 * 64;
-        const int vec_ok = (K % 4 == 0) && ((reinterpret_cast<uintptr_t>(cur_in) & 15) == 0);
-        dim3 grid((N + 31) / 32, ks, (O + 127) / 128);
-        hipLaunchKernelGGL(dense_rows_mfma_kernel, grid, dim3(256), 0, st, cur_in, blob + hdr.enc_node_w[g], part, N, K, O,
-                           kslice, vec_ok, g == 0 ? flags : (unsigned*)nullptr);
+        EncPlanParams ep;
+        std::memset(&ep, 0, sizeof(ep));
+        ep.in = cur_in;
+        ep.W = blob + hdr.enc_node_w[g];
+        ep.part = part;
+        ep.M = N;
+        ep.K = K;
+        ep.O = O;
+        ep.kslice = kslice;
+        ep.vec_ok = (K % 4 == 0) && ((reinterpret_cast<uintptr_t>(cur_in) & 15) == 0);
+        ep.nrt = (N + 31) / 32;
+        ep.nks = ks;
+        ep.gemm_blocks = ep.nrt * ks * ((O + 127) / 128);
+        int plan_blocks = 0;
+        if (g == 0 && E > 0) {  // the graph plan rides in the first GEMM launch
+            ep.ei = reinterpret_cast<const long long*>(edge_index);
+            ep.seg_ptr = seg_ptr;
+            ep.col32 = col32;
+            ep.blockflags = blockflags;
+            ep.E = E;
+            ep.N = N;
+            plan_blocks = (E + 255) / 256;
+        }
+        hipLaunchKernelGGL(enc_gemm_plan_kernel, dim3(ep.gemm_blocks + plan_blocks), dim3(256), 0, st, ep);
         HIP_TRY(hipGetLastError());
         PROF_MARK(GNNCCA_K_ENC_GEMM);
-        if (g == 0 && E > 0) {  // graph plan: after the launch that zeroed its flags, before anything that reads it
-            const long long* ei = reinterpret_cast<const long long*>(edge_index);
-            hipLaunchKernelGGL(plan_rows_kernel, grid1((size_t)E, 256), dim3(256), 0, st, ei, E, N, seg_ptr, col32, flags);
-            HIP_TRY(hipGetLastError());
-            PROF_MARK(GNNCCA_K_PLAN_ROWS);
-        }
         ks_last = ks;
         if (g < n_gemm - 1) {
             float* dst = act + (size_t)(g & 1) * N * O;
@@ -1041,6 +1092,7 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
         tp.perm = perm;
         tp.cursor = cursor;
         tp.flags = flags;
+        tp.blockflags = blockflags;
         tp.E = E;
         const unsigned blocks = (unsigned)std::min<size_t>(((size_t)N + 3) / 4, 2048) + 1;  // + plan-repair workgroup
         hipLaunchKernelGGL(enc_tail_kernel, dim3(blocks), dim3(256), std::max<size_t>(lds, 4096), st, tp);

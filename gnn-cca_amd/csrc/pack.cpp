@@ -306,6 +306,7 @@ Workspace carve(const gnncca_mpn_dims* d, int64_t n, int64_t e) {
     for (int i = 0; i < d->enc_node.n_layers; ++i)
         fmax = fmax > (size_t)d->enc_node.layers[i].out_dim ? fmax : (size_t)d->enc_node.layers[i].out_dim;
     w.flags = take(256);
+    w.blockflags = take((E / 256 + 2) * 4);
     w.seg_ptr = take((N + 1) * 4);
     w.col32 = take(E * 4);
     w.perm = take(E * 4);
