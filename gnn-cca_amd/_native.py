@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libgnncca_mpn.so")
+LIB_PATH = os.environ.get("GNNCCA_LIB") or os.path.join(HERE, "lib", "libgnncca_mpn.so")  # GNNCCA_LIB: diagnostic builds
 
 ABI_VERSION = 1
 MAX_LAYERS = 8

@@ -29,24 +29,34 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
-    if not force and not needs_build():
+def build_stamps(verbose=False):
+    """Diagnostic twin (tools/stamps.py): same sources with -DGNNCCA_STAMPS -> lib/libgnncca_mpn_stamps.so."""
+    return build(force=True, verbose=verbose, out=os.path.join(LIB_DIR, "libgnncca_mpn_stamps.so"), defs=["-DGNNCCA_STAMPS"])
+
+
+def build(force=False, verbose=False, out=None, defs=()):
+    if out is None and not force and not needs_build():
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
+    out = out or LIB_PATH
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-x", "hip",
            "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-Wall", "-Wno-unused-function",
            "-fvisibility=hidden", "-DGNNCCA_BUILD",
            # keep MFMA accumulators in VGPRs: the step kernels post-process every accumulator element on the VALU
            # (ReLU + segment sum), and AGPR results would cost one v_accvgpr_read per element
            "-mllvm", "-amdgpu-mfma-vgpr-form"]
+    cmd += list(defs)
     cmd += [os.path.join(CSRC, s) for s in SOURCES]
-    cmd += ["-o", LIB_PATH + ".tmp"]
+    cmd += ["-o", out + ".tmp"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
-    os.replace(LIB_PATH + ".tmp", LIB_PATH)
-    return LIB_PATH
+    os.replace(out + ".tmp", out)
+    return out
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    if "--stamps" in sys.argv:
+        print(build_stamps(verbose=True))
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))

@@ -33,6 +33,23 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 static thread_local int g_last_hip_error = 0;
 
+// Diagnostic build only (-DGNNCCA_STAMPS, tools/stamps.py): s_memtime stamps of every wave at named points, written to
+// a buffer of their own that no kernel reads.  The product build compiles these to nothing.
+#ifdef GNNCCA_STAMPS
+__device__ unsigned long long* g_stamps = nullptr;
+#define GNNCCA_STAMP(kslot, id)                                                                              \
+    do {                                                                                                     \
+        if (g_stamps && (threadIdx.x & 63) == 0 && blockIdx.x < 4096) {                                      \
+            g_stamps[((((size_t)(kslot)) * 4096 + blockIdx.x) * 4 + (threadIdx.x >> 6)) * 16 + (id)] =       \
+                __builtin_amdgcn_s_memtime();                                                                \
+        }                                                                                                    \
+    } while (0)
+#else
+#define GNNCCA_STAMP(kslot, id) \
+    do {                        \
+    } while (0)
+#endif
+
 #define HIP_TRY(expr)                                  \
     do {                                               \
         hipError_t _e = (expr);                        \
@@ -245,6 +262,7 @@ struct EncPlanParams {
 
 __global__ __launch_bounds__(256) void enc_gemm_plan_kernel(const EncPlanParams p) {
     __shared__ unsigned s_fl;
+    GNNCCA_STAMP(1, 0);
     const int b = blockIdx.x;
     if (b < p.gemm_blocks) {
         const int rt = b % p.nrt, t = b / p.nrt;
@@ -252,6 +270,7 @@ __global__ __launch_bounds__(256) void enc_gemm_plan_kernel(const EncPlanParams 
     } else {
         plan_block(b - p.gemm_blocks, p.ei, p.E, p.N, p.seg_ptr, p.col32, p.blockflags, &s_fl);
     }
+    GNNCCA_STAMP(1, 1);
 }
 
 // act[M][O] = [ReLU](bias + sum_ks part[ks][M][O]) -- only for encoders deeper than two layers.
@@ -344,41 +363,63 @@ __global__ __launch_bounds__(256) void enc_tail_kernel(const TailParams p) {
         }
         return;
     }
+    GNNCCA_STAMP(0, 0);
     const int nblk = gridDim.x - 1;
-    {   // stage the projection and last-layer weights: 16 B per lane, all loads in flight together
-        const f32x4* __restrict__ g4 = reinterpret_cast<const f32x4*>(blob + p.off_projwT);
-        f32x4* l4 = reinterpret_cast<f32x4*>(s_proj);
-        for (int i = tid; i < p.hin * kProjOut / 4; i += 256) l4[i] = g4[i];
-        if (p.has_last) {
-            const f32x4* __restrict__ h4 = reinterpret_cast<const f32x4*>(blob + p.off_lastWT);
-            f32x4* m4 = reinterpret_cast<f32x4*>(s_last);
-            for (int i = tid; i < p.F * kH / 4; i += 256) m4[i] = h4[i];
-        }
-    }
-    __syncthreads();
     const int o = lane & 31, half = lane >> 5;
     float* rowbuf = s_row + wave * p.F;
     float* redbuf = s_red + wave * 256;
+    // split-K partial sum of one node row: F/4 float4 chunks per row; 64/(F/4) lane groups walk the partials in an
+    // interleaved, fixed order with all loads independent (one round trip instead of ks dependent ones)
+    const int nchunk = p.vec_reduce ? (p.F >> 2) : 64, groups = 64 / nchunk;
+    const int rg = lane / nchunk, rc = lane - rg * nchunk;
+    auto partial_sum = [&](int node) {
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        if (p.vec_reduce && node < p.N && rg < groups) {
+            const float* __restrict__ src = p.part + (size_t)node * p.F + 4 * rc;
+            const size_t sstride = (size_t)p.N * p.F;
+#pragma unroll 8
+            for (int s = rg; s < p.ks; s += groups) a += *reinterpret_cast<const f32x4*>(src + s * sstride);
+        }
+        return a;
+    };
+    // Issue order = completion order (vmcnt): weights first (consumed first, by the LDS stage), then biases, then
+    // the first node's partials, so that one round trip covers all three.
+    const int n4p = p.hin * kProjOut / 4, n4l = p.has_last ? p.F * kH / 4 : 0;
+    const f32x4* __restrict__ gp4 = reinterpret_cast<const f32x4*>(blob + p.off_projwT);
+    const f32x4* __restrict__ gl4 = reinterpret_cast<const f32x4*>(blob + p.off_lastWT);
+    f32x4 rp[3], rl[4];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) rp[u] = gp4[min(u * 256 + tid, n4p - 1)];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) rl[u] = gl4[min(u * 256 + tid, max(n4l - 1, 0))];
+    const float last_b = p.has_last ? blob[p.off_last_b + o] : 0.f;
+    const float prev_b0 = blob[p.off_prev_b + min(lane, p.F - 1)];
+    const float prev_b1 = blob[p.off_prev_b + min(lane + 64, p.F - 1)];
+    f32x4 pre = partial_sum(blockIdx.x * 4 + wave);
+    GNNCCA_STAMP(0, 1);
+    {
+        f32x4* lp4 = reinterpret_cast<f32x4*>(s_proj);
+        f32x4* ll4 = reinterpret_cast<f32x4*>(s_last);
+#pragma unroll
+        for (int u = 0; u < 3; ++u)
+            if (u * 256 + tid < n4p) lp4[u * 256 + tid] = rp[u];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (u * 256 + tid < n4l) ll4[u * 256 + tid] = rl[u];
+        for (int i = 1024 + tid; i < n4l; i += 256) ll4[i] = gl4[i];  // F > 128: the rest, plainly
+    }
+    GNNCCA_STAMP(0, 2);
+    __syncthreads();
+    GNNCCA_STAMP(0, 3);
     for (int grp = blockIdx.x; grp * 4 < p.N; grp += nblk) {
         const int node = grp * 4 + wave;
         const bool active = node < p.N;
         if (active) {
             if (p.vec_reduce) {
-                // F/4 float4 chunks per row; 64/(F/4) lane groups walk the split-K partials in an interleaved,
-                // fixed order with all loads independent (one round trip instead of ks dependent ones)
-                const int nchunk = p.F >> 2, groups = 64 / nchunk;
-                const int g = lane / nchunk, c = lane - g * nchunk;
-                f32x4 a = {0.f, 0.f, 0.f, 0.f};
-                if (g < groups) {
-                    const float* __restrict__ src = p.part + (size_t)node * p.F + 4 * c;
-                    const size_t sstride = (size_t)p.N * p.F;
-#pragma unroll 8
-                    for (int s = g; s < p.ks; s += groups) a += *reinterpret_cast<const f32x4*>(src + s * sstride);
-                    *reinterpret_cast<f32x4*>(redbuf + g * p.F + 4 * c) = a;
-                }
+                if (rg < groups) *reinterpret_cast<f32x4*>(redbuf + rg * p.F + 4 * rc) = pre;
                 __builtin_amdgcn_wave_barrier();
                 for (int f = lane; f < p.F; f += 64) {
-                    float v = blob[p.off_prev_b + f];
+                    float v = f < 64 ? prev_b0 : (f < 128 ? prev_b1 : blob[p.off_prev_b + f]);
                     for (int gg = 0; gg < groups; ++gg) v += redbuf[gg * p.F + f];
                     rowbuf[f] = p.relu_prev ? fmaxf(v, 0.f) : v;
                 }
@@ -390,26 +431,44 @@ __global__ __launch_bounds__(256) void enc_tail_kernel(const TailParams p) {
                 }
             }
         }
+        GNNCCA_STAMP(0, 4);
+        pre = partial_sum((grp + nblk) * 4 + wave);  // next node of this wave, in flight during the layer below
         __syncthreads();
+        GNNCCA_STAMP(0, 5);
         float hv = 0.f;
         if (active) {
             if (p.has_last) {
-                float acc = 0.f;
-                for (int f = half; f < p.F; f += 2) acc = fmaf(rowbuf[f], s_last[f * kH + o], acc);
+                // four independent accumulators and an 8-deep unroll keep 16 LDS reads in flight per lane
+                float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+                int f = half;
+                for (; f + 14 < p.F; f += 16) {
+#pragma unroll
+                    for (int u = 0; u < 8; u += 4) {
+                        acc0 = fmaf(rowbuf[f + 2 * u + 0], s_last[(f + 2 * u + 0) * kH + o], acc0);
+                        acc1 = fmaf(rowbuf[f + 2 * u + 2], s_last[(f + 2 * u + 2) * kH + o], acc1);
+                        acc2 = fmaf(rowbuf[f + 2 * u + 4], s_last[(f + 2 * u + 4) * kH + o], acc2);
+                        acc3 = fmaf(rowbuf[f + 2 * u + 6], s_last[(f + 2 * u + 6) * kH + o], acc3);
+                    }
+                }
+                for (; f < p.F; f += 2) acc0 = fmaf(rowbuf[f], s_last[f * kH + o], acc0);
+                float acc = (acc0 + acc1) + (acc2 + acc3);
                 acc += __shfl_xor(acc, 32);
-                hv = fmaxf(acc + blob[p.off_last_b + o], 0.f);
+                hv = fmaxf(acc + last_b, 0.f);
             } else {
                 hv = rowbuf[o];
             }
+            GNNCCA_STAMP(0, 6);
             if (lane < kH) {
                 p.h0[(size_t)node * kH + lane] = hv;
                 if (p.trace_h) p.trace_h[(size_t)node * kH + lane] = hv;
             }
             project_node(hv, hv, p.reatt_n != 0, s_proj, blob + p.off_projb, p.pd_out + (size_t)node * kPdStride,
                          p.psq_out + (size_t)node * kPsQStride, lane);
+            GNNCCA_STAMP(0, 7);
         }
         __syncthreads();
     }
+    GNNCCA_STAMP(0, 8);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -449,7 +508,7 @@ struct StepParams {
     int off_wee, off_wneb, off_projwT, off_projb, off_encw, off_encb, off_cw1, off_cb1, off_cw2, off_cb2;
     int off_fast;
     int cls_layers, cls_hidden;  // cls_layers == 0: this step does not classify
-    int N, E, edge_in, attr_vec, first, update, agg, reatt_n, wps, store_e, hin, pd_lds;
+    int N, E, edge_in, attr_vec, first, update, agg, reatt_n, wps, store_e, hin, pd_lds, stamp_slot;
 };
 
 template <bool REATT_E, bool MSG, bool AGG_MAX>
@@ -708,6 +767,7 @@ __global__ __launch_bounds__(256) void mpn_step_fast_kernel(const StepParams p) 
     typedef const float __attribute__((address_space(4))) cfloat;
     cfloat* cw = (cfloat*)(unsigned long long)(blob + p.off_fast);
 
+    GNNCCA_STAMP(p.stamp_slot, 0);
     // ---- prologue: every independent load is issued before the first wait ----------------------------------
     const unsigned gflags = p.flags[0];
     const int wps = p.wps;
@@ -760,7 +820,9 @@ __global__ __launch_bounds__(256) void mpn_step_fast_kernel(const StepParams p) 
         return;
     }
     const bool unsorted = (gflags & GNNCCA_GRAPH_UNSORTED) != 0;
+    GNNCCA_STAMP(p.stamp_slot, 1);
     if (MSG || PD_LDS) __syncthreads();
+    GNNCCA_STAMP(p.stamp_slot, 2);
     if (!active) seg_s = seg_t = 0;
 
     f32x16 acc;  // 'sum' / 'mean' only: 'max' takes the general kernel
@@ -869,9 +931,12 @@ __global__ __launch_bounds__(256) void mpn_step_fast_kernel(const StepParams p) 
         const bool two = base + stride < seg_t;
         load_chunk(base, c0);
         if (two) load_chunk(base + stride, c1);
+        GNNCCA_STAMP(p.stamp_slot, 3);
         compute_chunk(base, c0);
         if (two) compute_chunk(base + stride, c1);
+        GNNCCA_STAMP(p.stamp_slot, 4);
     }
+    GNNCCA_STAMP(p.stamp_slot, 5);
 
     if (MSG) {
         float v = acc[0];
@@ -886,6 +951,7 @@ __global__ __launch_bounds__(256) void mpn_step_fast_kernel(const StepParams p) 
                 for (int u = 1; u < wps; ++u) v += s_part[(wave + u) * kH + ch];
             }
         }
+        GNNCCA_STAMP(p.stamp_slot, 6);
         if (active && sub == 0) {
             const int deg = seg_t - seg_s;
             if (p.agg == GNNCCA_AGG_MEAN) v = v / (float)max(deg, 1);
@@ -903,6 +969,7 @@ __global__ __launch_bounds__(256) void mpn_step_fast_kernel(const StepParams p) 
                 p.psq_out[(size_t)node * kPsQStride + lane - kPdStride] = pr;
         }
     }
+    GNNCCA_STAMP(p.stamp_slot, 7);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -962,6 +1029,14 @@ static hipError_t launch_fast_dispatch(const StepParams& sp, bool msg, hipStream
 using namespace gnncca;
 
 extern "C" {
+
+#ifdef GNNCCA_STAMPS
+__attribute__((visibility("default"))) int gnncca_debug_set_stamps(void* dev_buf) {
+    unsigned long long* p = static_cast<unsigned long long*>(dev_buf);
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &p, sizeof(p)));
+    return GNNCCA_OK;
+}
+#endif
 
 int gnncca_last_hip_error(void) { return g_last_hip_error; }
 
@@ -1163,6 +1238,7 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
         const bool want_h = trace && trace->h_steps;
         const bool msg = step < L || want_h;
         sp.first = step == 1;
+        sp.stamp_slot = 2 + (step - 1 < 6 ? step - 1 : 5);
         sp.update = 1;
         sp.store_e = step < L;
         sp.cls_layers = step >= first_cls ? hdr.cls_layers : 0;
