@@ -21,6 +21,7 @@ constexpr int kMaxEdgeIn = 16;
 enum Family : uint32_t {
     kFamilyNone = 0,
     kFamilyMfma32x6 = 1,  // H = 32, EF = 6, single-layer edge/node MLPs (both shipped configs)
+    kFamilyGeneric = 2,   // any other legal GRAPH_NET_PARAMS: op-for-op kernels, correctness first
 };
 
 // Header of the packed weight blob.  All offsets are in floats from the start of the blob and are
@@ -54,6 +55,23 @@ constexpr int kFcCb2 = 100;    // [1]
 constexpr int kFcProjB = 104;  // [48]
 constexpr int kFastConsts = 152;
 bool fast_consts_ok(const gnncca_mpn_dims* d);
+
+// Blob of the generic family: every layer of every MLP as W[out][in] + b[out], BatchNorm folded.
+// MLP index: 0 encoder.node, 1 encoder.edge, 2 MPNet.edge_model, 3 MPNet.node_model, 4 classifier.edge
+struct GenBlobHeader {
+    uint32_t magic, abi_version, family, total_floats;
+    int32_t w[5][GNNCCA_MAX_LAYERS];
+    int32_t b[5][GNNCCA_MAX_LAYERS];
+};
+bool gen_blob_header(const gnncca_mpn_dims* d, GenBlobHeader* out);
+const gnncca_mlp& mlp_by_index(const gnncca_mpn_dims* d, int i);
+
+struct GenWorkspace {
+    size_t flags, blockflags, seg_ptr, col32, perm, cursor, row32o, col32o;
+    size_t node[3], h0, edge[4], e0, total;
+    int64_t node_w, edge_w;  // floats per row of the node / edge scratch buffers
+};
+GenWorkspace carve_generic(const gnncca_mpn_dims* d, int64_t n, int64_t e);
 
 Family classify(const gnncca_mpn_dims* d);
 bool blob_header(const gnncca_mpn_dims* d, BlobHeader* out);  // false if unsupported

@@ -9,6 +9,7 @@
 //       [ x[row] | x[col] | edge_attr ]  ->  W_src, W_dst (per-node projections) and W_ee (per edge)
 //   * the node MLP weight [H][nf*H + EF] is split by the cat order of models/mpn.py:97
 //       [ x[row] | edge_attr ]           ->  W_nx (per-node projection Q) and W_ne (per edge, MFMA B operand)
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -56,15 +57,56 @@ bool dims_valid(const gnncca_mpn_dims* d) {
 
 Family classify(const gnncca_mpn_dims* d) {
     if (!dims_valid(d)) return kFamilyNone;
-    if (d->node_dim != kH || d->edge_dim != kEF) return kFamilyNone;
-    if (d->edge_in > kMaxEdgeIn) return kFamilyNone;
-    if (d->enc_edge.n_layers != 1 || d->edge_mlp.n_layers != 1 || d->node_mlp.n_layers != 1) return kFamilyNone;
-    if (d->enc_node.n_layers < 1) return kFamilyNone;
+    if (d->node_dim != kH || d->edge_dim != kEF) return kFamilyGeneric;
+    if (d->edge_in > kMaxEdgeIn) return kFamilyGeneric;
+    if (d->enc_edge.n_layers != 1 || d->edge_mlp.n_layers != 1 || d->node_mlp.n_layers != 1) return kFamilyGeneric;
+    if (d->enc_node.n_layers < 1) return kFamilyGeneric;
     for (int i = 0; i < d->enc_node.n_layers; ++i)
-        if (d->enc_node.layers[i].out_dim > 1024) return kFamilyNone;
-    if (d->cls_edge.n_layers > 2) return kFamilyNone;
-    if (d->cls_edge.n_layers == 2 && d->cls_edge.layers[0].out_dim > kMaxCls) return kFamilyNone;
+        if (d->enc_node.layers[i].out_dim > 1024) return kFamilyGeneric;
+    if (d->cls_edge.n_layers > 2) return kFamilyGeneric;
+    if (d->cls_edge.n_layers == 2 && d->cls_edge.layers[0].out_dim > kMaxCls) return kFamilyGeneric;
     return kFamilyMfma32x6;
+}
+
+const gnncca_mlp& mlp_by_index(const gnncca_mpn_dims* d, int i) {
+    switch (i) {
+        case 0: return d->enc_node;
+        case 1: return d->enc_edge;
+        case 2: return d->edge_mlp;
+        case 3: return d->node_mlp;
+        default: return d->cls_edge;
+    }
+}
+
+struct GenBlobPlan {
+    GenBlobHeader h;
+    size_t total_floats;
+};
+
+static GenBlobPlan plan_gen_blob(const gnncca_mpn_dims* d) {
+    GenBlobPlan p;
+    std::memset(&p, 0, sizeof(p));
+    size_t off = align_up(sizeof(GenBlobHeader), 16) / 4;
+    auto take = [&](size_t n) { size_t o = off; off = align_up(off + n, 4); return (int32_t)o; };
+    p.h.magic = kBlobMagic;
+    p.h.abi_version = GNNCCA_ABI_VERSION;
+    p.h.family = kFamilyGeneric;
+    for (int m = 0; m < 5; ++m) {
+        const gnncca_mlp& mlp = mlp_by_index(d, m);
+        for (int l = 0; l < mlp.n_layers; ++l) {
+            p.h.w[m][l] = take((size_t)mlp.layers[l].in_dim * mlp.layers[l].out_dim);
+            p.h.b[m][l] = take(mlp.layers[l].out_dim);
+        }
+    }
+    p.total_floats = off;
+    p.h.total_floats = (uint32_t)off;
+    return p;
+}
+
+bool gen_blob_header(const gnncca_mpn_dims* d, GenBlobHeader* out) {
+    if (classify(d) != kFamilyGeneric || !out) return false;
+    *out = plan_gen_blob(d).h;
+    return true;
 }
 
 bool fast_consts_ok(const gnncca_mpn_dims* d) {
@@ -120,7 +162,7 @@ static BlobPlan plan_blob(const gnncca_mpn_dims* d) {
 }
 
 bool blob_header(const gnncca_mpn_dims* d, BlobHeader* out) {
-    if (classify(d) == kFamilyNone || !out) return false;
+    if (classify(d) != kFamilyMfma32x6 || !out) return false;
     *out = plan_blob(d).h;
     return true;
 }
@@ -198,9 +240,13 @@ int gnncca_num_outputs(const gnncca_mpn_dims* d) {
 }
 
 size_t gnncca_packed_weights_bytes(const gnncca_mpn_dims* d) {
-    if (classify(d) == kFamilyNone) return 0;
+    const Family fam = classify(d);
+    if (fam == kFamilyNone) return 0;
+    if (fam == kFamilyGeneric) return plan_gen_blob(d).total_floats * sizeof(float);
     return plan_blob(d).total_floats * sizeof(float);
 }
+
+static int pack_generic(const gnncca_mpn_dims* d, const float* const* params, void* packed_host, size_t packed_bytes);
 
 int gnncca_pack_weights(const gnncca_mpn_dims* d, const float* const* params, int n_params, void* packed_host,
                         size_t packed_bytes) {
@@ -209,6 +255,7 @@ int gnncca_pack_weights(const gnncca_mpn_dims* d, const float* const* params, in
     if (n_params != gnncca_param_count(d)) return GNNCCA_ERR_INVALID_ARG;
     for (int i = 0; i < n_params; ++i)
         if (!params[i]) return GNNCCA_ERR_INVALID_ARG;
+    if (classify(d) == kFamilyGeneric) return pack_generic(d, params, packed_host, packed_bytes);
     const BlobPlan p = plan_blob(d);
     if (packed_bytes < p.total_floats * sizeof(float)) return GNNCCA_ERR_INVALID_ARG;
     float* blob = static_cast<float*>(packed_host);
@@ -285,9 +332,61 @@ int gnncca_pack_weights(const gnncca_mpn_dims* d, const float* const* params, in
     return GNNCCA_OK;
 }
 
+static int pack_generic(const gnncca_mpn_dims* d, const float* const* params, void* packed_host, size_t packed_bytes) {
+    const GenBlobPlan p = plan_gen_blob(d);
+    if (packed_bytes < p.total_floats * sizeof(float)) return GNNCCA_ERR_INVALID_ARG;
+    float* blob = static_cast<float*>(packed_host);
+    std::memset(blob, 0, p.total_floats * sizeof(float));
+    std::memcpy(blob, &p.h, sizeof(GenBlobHeader));
+    const float* const* cur = params;
+    for (int m = 0; m < 5; ++m) {
+        const gnncca_mlp& mlp = mlp_by_index(d, m);
+        for (int l = 0; l < mlp.n_layers; ++l) {
+            Folded f = fold_layer(mlp.layers[l], cur);
+            std::memcpy(blob + p.h.w[m][l], f.w.data(), f.w.size() * sizeof(float));
+            std::memcpy(blob + p.h.b[m][l], f.b.data(), f.b.size() * sizeof(float));
+        }
+    }
+    return GNNCCA_OK;
+}
+
 }  // extern "C"
 
 namespace gnncca {
+
+GenWorkspace carve_generic(const gnncca_mpn_dims* d, int64_t n, int64_t e) {
+    GenWorkspace w;
+    std::memset(&w, 0, sizeof(w));
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    const size_t N = (size_t)(n > 0 ? n : 0), E = (size_t)(e > 0 ? e : 0);
+    int64_t nw = d->node_dim, ew = d->edge_dim;
+    for (int l = 0; l < d->enc_node.n_layers; ++l) nw = std::max<int64_t>(nw, d->enc_node.layers[l].out_dim);
+    const int edge_side[4] = {1, 2, 3, 4};
+    for (int m : edge_side) {
+        const gnncca_mlp& mlp = mlp_by_index(d, m);
+        for (int l = 0; l < mlp.n_layers; ++l) ew = std::max<int64_t>(ew, mlp.layers[l].out_dim);
+    }
+    if (d->reattach_nodes) nw = std::max<int64_t>(nw, 2 * d->node_dim);  // room for cat(initial, latent)
+    if (d->reattach_edges) ew = std::max<int64_t>(ew, 2 * d->edge_dim);
+    ew = std::max<int64_t>(ew, d->node_dim);  // per-edge messages [E][H]
+    w.node_w = nw;
+    w.edge_w = ew;
+    w.flags = take(256);
+    w.blockflags = take((E / 256 + 2) * 4);
+    w.seg_ptr = take((N + 1) * 4);
+    w.col32 = take(E * 4);
+    w.perm = take(E * 4);
+    w.cursor = take((N + 1) * 4);
+    w.row32o = take(E * 4);
+    w.col32o = take(E * 4);
+    for (int i = 0; i < 3; ++i) w.node[i] = take(N * (size_t)nw * 4);
+    w.h0 = take(N * (size_t)d->node_dim * 4);
+    for (int i = 0; i < 4; ++i) w.edge[i] = take(E * (size_t)ew * 4);
+    w.e0 = take(E * (size_t)d->edge_dim * 4);
+    w.total = off;
+    return w;
+}
 
 Workspace carve(const gnncca_mpn_dims* d, int64_t n, int64_t e) {
     Workspace w;
@@ -325,6 +424,8 @@ Workspace carve(const gnncca_mpn_dims* d, int64_t n, int64_t e) {
 }  // namespace gnncca
 
 extern "C" size_t gnncca_workspace_bytes(const gnncca_mpn_dims* d, int64_t n_nodes, int64_t n_edges) {
-    if (classify(d) == kFamilyNone || n_nodes < 0 || n_edges < 0) return 0;
+    const Family fam = classify(d);
+    if (fam == kFamilyNone || n_nodes < 0 || n_edges < 0) return 0;
+    if (fam == kFamilyGeneric) return carve_generic(d, n_nodes, n_edges).total;
     return carve(d, n_nodes, n_edges).total;
 }

@@ -289,6 +289,19 @@ def main():
                          enc_dropout=0.4, mpn_bn=True, mpn_dropout=0.3, arch="generic"),
              "generic", n, ei, 101, 102, 1.0 / 6)
 
+    # --- extra: generic family with both reattach flags, 'max', single-layer encoder, bare Linear classifier, on
+    #     an unsorted ragged graph; and the default widths with a three-layer classifier + 'mean' -------------------
+    rng = np.random.default_rng(17)
+    n = 18
+    ei = np.stack([rng.integers(0, 15, size=70), rng.integers(0, 18, size=70)]).astype(np.int64)
+    run_case(MOTMPNet, "generic_reattach_max",
+             make_params(node_in=24, node_fc=(), node_out=12, edge_in=3, edge_fc=(), edge_out=5, edge_mlp_fc=(7, 5),
+                         node_mlp_fc=(12,), cls_fc=(), cls_bn=False, agg="max", reattach_nodes=True, reattach_edges=True,
+                         arch="generic"), "generic", n, ei, 111, 112, 1.0)
+    n, ei = cross_camera_edges([5, 4, 4])
+    run_case(MOTMPNet, "generic_deepcls_mean",
+             make_params(node_in=64, cls_fc=(8, 4), agg="mean", arch="tiny64"), "tiny64", n, ei, 121, 122, 1.0)
+
 
 if __name__ == "__main__":
     main()

@@ -43,11 +43,7 @@ def to_data(a):
 def test_hip_matches_reference_golden(name):
     params, arch, sd, a = load_case(os.path.join(GOLDEN_DIR, name + ".npz"))
     m = build(params, arch, sd)
-    if not supported(m):
-        with pytest.raises(NotImplementedError):
-            with torch.no_grad():
-                m(to_data(a))
-        pytest.skip("configuration outside the kernels' family: raises NotImplementedError (no fallback)")
+    assert supported(m)
     trace = {}
     with torch.no_grad():
         out = m(to_data(a), trace=trace)["classified_edges"]
