@@ -28,6 +28,12 @@ class MpnDims(C.Structure):
                 ("enc_node", Mlp), ("enc_edge", Mlp), ("edge_mlp", Mlp), ("node_mlp", Mlp), ("cls_edge", Mlp)]
 
 
+class Frames(C.Structure):
+    _fields_ = [("xw", C.c_void_p), ("yw", C.c_void_p), ("max_dist", C.c_void_p), ("person_id", C.c_void_p),
+                ("cam", C.c_void_p), ("graph_of", C.c_void_p), ("graph_ptr", C.c_void_p), ("src_order", C.c_void_p),
+                ("edge_ptr", C.c_void_p)]
+
+
 class Trace(C.Structure):
     _fields_ = [("h_enc", C.c_void_p), ("e_enc", C.c_void_p), ("h_steps", C.c_void_p), ("e_steps", C.c_void_p)]
 
@@ -55,6 +61,9 @@ _SIGNATURES = {
     "gnncca_mpn_forward_profiled": (C.c_int, [C.POINTER(MpnDims), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                               C.c_int64, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
                                               C.POINTER(Profile)]),
+    "gnncca_normalize_columns": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gnncca_build_edges": (C.c_int, [C.POINTER(Frames), C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_int32,
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gnncca_read_graph_flags": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.c_void_p]),
 }
 

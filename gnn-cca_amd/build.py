@@ -10,7 +10,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libgnncca_mpn.so")
-SOURCES = ["pack.cpp", "mpn_kernels.hip"]
+SOURCES = ["pack.cpp", "mpn_kernels.hip", "graph_build.hip"]
 HEADERS = [os.path.join(CSRC, "internal.h"), os.path.join(ROOT, "include", "gnncca_mpn.h")]
 
 

@@ -8,6 +8,8 @@
 
 namespace gnncca {
 
+extern thread_local int g_last_hip_error;  // hipError_t of the last failed HIP call on this thread
+
 constexpr uint32_t kBlobMagic = 0x4D504E31u;  // "MPN1"
 constexpr int kH = 32;        // node latent width the MFMA step kernel is built for (node_out_dim)
 constexpr int kEF = 6;        // edge latent width (edge_out_dim): 3 k-steps of v_mfma_f32_32x32x2_f32

@@ -31,7 +31,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-static thread_local int g_last_hip_error = 0;
+thread_local int g_last_hip_error = 0;
 
 // Diagnostic build only (-DGNNCCA_STAMPS, tools/stamps.py): s_memtime stamps of every wave at named points, written to
 // a buffer of their own that no kernel reads.  The product build compiles these to nothing.

@@ -1,0 +1,119 @@
+"""Row N1 of SURVEY.md 8f: the step right before the MPN -- building the cross-camera graph and its edge attributes
+(`inference.py:189-279`, duplicated at `train.py:257-361` and `train.py:616-692`) -- on the GPU.
+
+The reference does this per frame with Python list comprehensions, sklearn on the host and several GPU<->CPU round
+trips (its real end-to-end bottleneck).  Here the host only derives the edge ENUMERATION from the camera ids (O(N)
+numpy, `plan_frames`); one HIP kernel (`gnncca_build_edges`) then writes `edge_index`, `edge_attr` and `edge_labels`
+for the whole batch of frames, and `gnncca_normalize_columns` does the `F.normalize(..., dim=0)` of the embeddings.
+"""
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import _native as nat
+from .sharding import GraphBatch
+
+MODE_FULL, MODE_ONLY_APPEARANCE, MODE_ONLY_DIST = 0, 1, 2
+
+
+@dataclass
+class FramePlan:
+    src_order: np.ndarray   # [N] int32  node ids in the order the reference emits their out-edges
+    edge_ptr: np.ndarray    # [N+1] int32 first edge of each source position
+    graph_ptr: np.ndarray   # [G+1] int32 node range of each frame graph
+    graph_of: np.ndarray    # [N] int32
+    n_edges: int
+
+
+def plan_frames(id_cam, graph_sizes):
+    """Edge enumeration of inference.py:207-212: per graph, cameras in np.unique order; within a camera its nodes in
+    ascending id; each connects to every node of the other cameras in ascending id."""
+    id_cam = np.asarray(id_cam)
+    sizes = np.asarray(graph_sizes, dtype=np.int64)
+    graph_ptr = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    n = int(graph_ptr[-1])
+    if len(id_cam) != n:
+        raise ValueError("id_cam length does not match graph_sizes")
+    graph_of = np.repeat(np.arange(len(sizes), dtype=np.int32), sizes)
+    src_order = np.empty(n, dtype=np.int32)
+    deg = np.empty(n, dtype=np.int64)
+    for g in range(len(sizes)):
+        lo, hi = graph_ptr[g], graph_ptr[g + 1]
+        cams = id_cam[lo:hi]
+        order = np.argsort(cams, kind="stable")  # camera-major, node id ascending inside a camera
+        src_order[lo:hi] = lo + order
+        _, inv, cnt = np.unique(cams, return_inverse=True, return_counts=True)
+        deg[lo:hi] = (hi - lo) - cnt[inv][order]
+    edge_ptr = np.concatenate([[0], np.cumsum(deg)])
+    if edge_ptr[-1] >= 2 ** 31 - 64:
+        raise NotImplementedError("more than 2^31 edges in one batch")
+    return FramePlan(src_order, edge_ptr.astype(np.int32), graph_ptr, graph_of, int(edge_ptr[-1]))
+
+
+def normalize_columns(x):
+    """F.normalize(x, p=2, dim=0) (inference.py:189-190) as a HIP kernel pair; returns a new tensor."""
+    if not x.is_cuda:
+        raise RuntimeError("gnn_cca_amd.graph_build runs on MI355X only (no CPU fallback)")
+    x = x.float().contiguous()
+    out = torch.empty_like(x)
+    scratch = torch.empty(((x.shape[0] + 255) // 256 + 1) * x.shape[1], dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        st = nat.lib().gnncca_normalize_columns(x.data_ptr(), x.shape[0], x.shape[1], scratch.data_ptr(), out.data_ptr(),
+                                                torch.cuda.current_stream(x.device).cuda_stream)
+    nat.check(st, "gnncca_normalize_columns")
+    return out
+
+
+def build_graph_batch(xw, yw, ids, id_cam, graph_sizes, max_dist, node_embeds, reid_embeds, only_appearance=False,
+                      only_dist=False, normalize=True):
+    """One call per batch of frames.  Host inputs (numpy, one entry per detection, frames concatenated): xw, yw, ids,
+    id_cam; graph_sizes / max_dist per frame.  Device inputs: node_embeds [N, D], reid_embeds [N, R].
+    Returns a GraphBatch (x, edge_index, edge_attr) with .edge_labels and .y, laid out exactly like the reference's
+    `Batch.from_data_list(batch)` (inference.py:279)."""
+    if not (node_embeds.is_cuda and reid_embeds.is_cuda):
+        raise RuntimeError("gnn_cca_amd.graph_build runs on MI355X only (no CPU fallback)")
+    dev = reid_embeds.device
+    plan = plan_frames(id_cam, graph_sizes)
+    n, e = len(plan.src_order), plan.n_edges
+    if reid_embeds.shape[0] != n or node_embeds.shape[0] != n:
+        raise RuntimeError("embeddings and detections disagree on the number of nodes")
+    if normalize:
+        reid_embeds = normalize_columns(reid_embeds)
+        node_embeds = normalize_columns(node_embeds)
+    else:
+        reid_embeds = reid_embeds.float().contiguous()
+    mode = MODE_ONLY_APPEARANCE if only_appearance else (MODE_ONLY_DIST if only_dist else MODE_FULL)
+    n_attr = 4 if mode == MODE_FULL else 2
+    _, dense_ids = np.unique(np.asarray(ids), return_inverse=True)
+    # one small host->device transfer with every per-node / per-graph array
+    f64 = np.concatenate([np.asarray(xw, np.float64), np.asarray(yw, np.float64), np.asarray(max_dist, np.float64)])
+    i32 = np.concatenate([dense_ids.astype(np.int32), np.asarray(id_cam).astype(np.int32), plan.graph_of, plan.graph_ptr,
+                          plan.src_order, plan.edge_ptr])
+    d64 = torch.from_numpy(f64).to(dev)
+    d32 = torch.from_numpy(i32).to(dev)
+    g = len(plan.graph_ptr) - 1
+    fr = nat.Frames()
+    fr.xw, fr.yw, fr.max_dist = d64.data_ptr(), d64.data_ptr() + 8 * n, d64.data_ptr() + 16 * n
+    base, o = d32.data_ptr(), 0
+    for name, cnt in (("person_id", n), ("cam", n), ("graph_of", n), ("graph_ptr", g + 1), ("src_order", n), ("edge_ptr", n + 1)):
+        setattr(fr, name, base + 4 * o)
+        o += cnt
+    edge_index = torch.empty((2, e), dtype=torch.int64, device=dev)
+    edge_attr = torch.empty((e, n_attr), dtype=torch.float32, device=dev)
+    edge_labels = torch.empty(e, dtype=torch.float32, device=dev)
+    if e > 0:
+        with torch.cuda.device(dev):
+            st = nat.lib().gnncca_build_edges(C.byref(fr), reid_embeds.data_ptr(), reid_embeds.shape[1], n, e, mode,
+                                              edge_index.data_ptr(), edge_attr.data_ptr(), edge_labels.data_ptr(),
+                                              torch.cuda.current_stream(dev).cuda_stream)
+        nat.check(st, "gnncca_build_edges")
+    # per-graph edge ranges: edges are emitted graph by graph, so graph g owns edge_ptr[graph_ptr[g]] .. edge_ptr[graph_ptr[g+1]]
+    edge_ptr_g = [int(plan.edge_ptr[p]) for p in plan.graph_ptr]
+    batch = GraphBatch(node_embeds, edge_index, edge_attr, edge_ptr_g, [int(p) for p in plan.graph_ptr])
+    batch.edge_labels = edge_labels
+    batch.y = torch.from_numpy(np.asarray(ids)).to(dev)
+    batch.reid_embeds = reid_embeds
+    batch._keepalive = (d64, d32)
+    return batch

@@ -151,6 +151,35 @@ GNNCCA_API int gnncca_mpn_forward_profiled(const gnncca_mpn_dims* dims, const vo
 /* len(outputs['classified_edges']) for these dims (mpn.py:277-297). */
 GNNCCA_API int gnncca_num_outputs(const gnncca_mpn_dims* dims);
 
+/* ---- the step before the MPN -- graph construction + edge attributes ------------------
+ * Replaces the per-frame Python of inference.py:189-279 (duplicated at train.py:257-361 and 616-692).
+ * All pointers are device memory; one entry per detection (node) unless noted; frames are concatenated. */
+typedef struct gnncca_frames {
+    const double* xw;          /* ground-plane x  (data_df['xw'], float64 as pandas holds it)                 */
+    const double* yw;          /* ground-plane y                                                              */
+    const double* max_dist;    /* [G]   CONFIG['CONV_TO_M'][dataset] of each frame (inference.py:239)        */
+    const int32_t* person_id;  /* data_df['id'] (any relabelling that preserves equality)                     */
+    const int32_t* cam;        /* data_df['id_cam']                                                           */
+    const int32_t* graph_of;   /* frame index of each node                                                    */
+    const int32_t* graph_ptr;  /* [G+1] node range of each frame                                              */
+    const int32_t* src_order;  /* node ids in the order the reference emits their out-edges (camera-major)     */
+    const int32_t* edge_ptr;   /* [N+1] first edge of each position of src_order                              */
+} gnncca_frames;
+enum { GNNCCA_EDGE_ATTR_FULL = 0, GNNCCA_EDGE_ATTR_ONLY_APPEARANCE = 1, GNNCCA_EDGE_ATTR_ONLY_DIST = 2 };
+
+/* out = x / max(||column||_2, 1e-12): F.normalize(x, p=2, dim=0) of inference.py:189-190.
+ * scratch: (ceil(n_rows/256) + 1) * n_cols floats. */
+GNNCCA_API int gnncca_normalize_columns(const float* x, int64_t n_rows, int64_t n_cols, float* scratch,
+                                        float* out, gnncca_stream_t stream);
+
+/* edge_index [2][E] int64, edge_attr [E][4 or 2] fp32, edge_labels [E] fp32 in the reference's edge order:
+ * cartesian_prod per camera (inference.py:207-212), ground-plane L2 and L1 distance / max_dist in float64 then
+ * cast (229-242), F.pairwise_distance and F.cosine_similarity of the reid rows (222-226), same-identity labels
+ * (262-266); node ids are the batch-global ones Batch.from_data_list produces (269-279). */
+GNNCCA_API int gnncca_build_edges(const gnncca_frames* frames, const float* reid, int32_t reid_dim, int64_t n_nodes,
+                                  int64_t n_edges, int32_t mode, int64_t* edge_index_out, float* edge_attr_out,
+                                  float* edge_labels_out, gnncca_stream_t stream);
+
 /* Synchronises `stream` and returns the flag word of the last forward that used `workspace`. */
 GNNCCA_API int gnncca_read_graph_flags(const void* workspace, uint32_t* flags_out, gnncca_stream_t stream);
 

@@ -1,0 +1,83 @@
+"""Row N1 on the GPU: gnncca_build_edges / gnncca_normalize_columns (through gnn_cca_amd.graph_build) against the golden
+vectors produced by the reference's own statements, then end to end into the MPN."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN_DIR
+from oracle import graph_oracle
+
+pytestmark = pytest.mark.gpu
+CASES = sorted(os.path.basename(p)[6:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "graph_*.npz")))
+
+
+def load(name):
+    z = np.load(os.path.join(GOLDEN_DIR, f"graph_{name}.npz"))
+    return {k: z[k] for k in z.files}
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_build_matches_reference(name):
+    from gnn_cca_amd.graph_build import build_graph_batch
+    a = load(name)
+    b = build_graph_batch(a["xw"], a["yw"], a["id"], a["id_cam"], a["graph_sizes"], a["max_dist"],
+                          torch.from_numpy(a["node_embeds_raw"]).cuda(), torch.from_numpy(a["reid_embeds_raw"]).cuda(),
+                          only_appearance=bool(a["only_appearance"]), only_dist=bool(a["only_dist"]))
+    torch.cuda.synchronize()
+    assert np.abs(b.x.cpu().numpy() - a["x"]).max() <= 2.5e-7
+    assert np.array_equal(b.edge_index.cpu().numpy(), a["edge_index"])
+    assert np.array_equal(b.edge_labels.cpu().numpy(), a["edge_labels"])
+    assert np.array_equal(b.y.cpu().numpy(), a["y"])
+    attr = b.edge_attr.cpu().numpy()
+    assert attr.shape == a["edge_attr"].shape
+    if not bool(a["only_appearance"]):
+        assert np.array_equal(attr[:, :2], a["edge_attr"][:, :2]), "float64 ground-plane distances must be bit-exact"
+    assert np.abs(attr - a["edge_attr"]).max() <= 3e-6
+
+
+def test_large_batch_vs_oracle():
+    """512 frames x 4 cameras x 8 detections against the CPU oracle (sizes the golden files do not reach)."""
+    from gnn_cca_amd.graph_build import build_graph_batch
+    rng = np.random.default_rng(0)
+    g, per = 512, 32
+    n = g * per
+    id_cam = np.tile(np.repeat(np.arange(4), 8), g)
+    ids = rng.integers(0, 12, size=n)
+    xw, yw = rng.uniform(-10, 10, n), rng.uniform(-10, 10, n)
+    max_dist = rng.uniform(10, 90, g)
+    reid = rng.standard_normal((n, 256)).astype(np.float32)
+    b = build_graph_batch(xw, yw, ids, id_cam, [per] * g, max_dist, torch.zeros(n, 8).cuda(), torch.from_numpy(reid).cuda())
+    reid_n = graph_oracle.normalize_columns(reid)
+    ei, attr, lab = graph_oracle.build(xw, yw, ids, id_cam, [per] * g, max_dist, reid_n)
+    assert np.array_equal(b.edge_index.cpu().numpy(), ei)
+    assert np.array_equal(b.edge_labels.cpu().numpy(), lab)
+    got = b.edge_attr.cpu().numpy()
+    assert np.array_equal(got[:, :2], attr[:, :2])
+    assert np.abs(got - attr).max() <= 3e-6
+
+
+def test_end_to_end_into_mpn():
+    """build_graph_batch -> MOTMPNet.forward, against oracle(graph) -> oracle(MPN)."""
+    import copy
+
+    from gnn_cca_amd import MOTMPNet
+    from gnn_cca_amd.graph_build import build_graph_batch
+    from oracle.mpn_oracle import NumpyOracle, load_case
+    a = load("terrace32")
+    params, arch, sd, _ = load_case(os.path.join(GOLDEN_DIR, "n8_sum.npz"))  # node_in 64 weights
+    rng = np.random.default_rng(5)
+    node_raw = rng.standard_normal((32, 64)).astype(np.float32)
+    m = MOTMPNet(copy.deepcopy(params), None, arch)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    m = m.cuda().eval()
+    b = build_graph_batch(a["xw"], a["yw"], a["id"], a["id_cam"], a["graph_sizes"], a["max_dist"],
+                          torch.from_numpy(node_raw).cuda(), torch.from_numpy(a["reid_embeds_raw"]).cuda())
+    with torch.no_grad():
+        out = m(b)["classified_edges"]
+    ref = NumpyOracle(params, arch, sd, np.float32).forward(graph_oracle.normalize_columns(node_raw), a["edge_index"],
+                                                            a["edge_attr"])
+    for o, r in zip(out, ref):
+        assert np.abs(o.cpu().numpy() - r).max() <= 1e-5
