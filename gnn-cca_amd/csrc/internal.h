@@ -42,7 +42,8 @@ struct BlobHeader {
     int32_t cls_layers, cls_hidden;         // 1: Linear(6,1);  2: Linear(6,C1)+ReLU, Linear(C1,1)
     int32_t cls_w1, cls_b1, cls_w2, cls_b2;
     int32_t fast_consts;                    // [kFastConsts] contiguous copy of the per-step scalars (see below), or 0
-    int32_t pad[7];
+    int32_t enc_w3;                         // first encoder weight split into 3 bf16 planes [3][out][in], or 0
+    int32_t pad[6];
 };
 
 // Layout of the `fast_consts` block (floats): what mpn_step_fast_kernel stages into LDS in one coalesced load.
@@ -57,6 +58,7 @@ constexpr int kFcCb2 = 100;    // [1]
 constexpr int kFcProjB = 104;  // [48]
 constexpr int kFastConsts = 152;
 bool fast_consts_ok(const gnncca_mpn_dims* d);
+bool enc_split_ok(const gnncca_mpn_dims* d);  // first encoder layer eligible for the split-bf16 MFMA GEMM
 
 // Blob of the generic family: every layer of every MLP as W[out][in] + b[out], BatchNorm folded.
 // MLP index: 0 encoder.node, 1 encoder.edge, 2 MPNet.edge_model, 3 MPNet.node_model, 4 classifier.edge

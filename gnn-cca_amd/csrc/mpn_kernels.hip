@@ -296,6 +296,140 @@ __global__ __launch_bounds__(256) void enc_gemm_plan_kernel(const EncPlanParams 
     GNNCCA_STAMP(1, 1);
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Large-N encoder GEMM on the bf16 MFMA pipe with fp32-level accuracy ("split-bf16"):  x = x0 + x1 + x2 and
+// w = w0 + w1 + w2 with bf16 pieces (3 x 8 = 24 mantissa bits, the pieces of w prepared at pack time, those of x
+// on the fly while staging), and  x.w ~= x2w0 + x1w1 + x0w2 + x1w0 + x0w1 + x0w0  -- the dropped terms are
+// <= 2^-24 relative.  Every product of two bf16 values is exact in fp32 and the MFMA accumulates in fp32, so the
+// result differs from an fp32 FMA chain only by rounding of the same order as fp32 itself, while the six
+// v_mfma_f32_32x32x16_bf16 cost 6/16 of the v_mfma_f32_32x32x2_f32 time: the GEMM becomes HBM-bound on the
+// x read (8 KB per node) instead of MFMA-bound.
+// Workgroup = 64 rows x 128 columns, 4 waves as 2 x 2 (32 rows x 64 columns each), K in chunks of 32 through LDS
+// (rows padded to 80 B: conflict-free ds_read_b128); the next chunk's global loads are in flight during the MFMAs.
+// ------------------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+template <int WM>  // rows per wave: 32 (workgroup 64 x 128) or 64 (workgroup 128 x 128)
+__global__ __launch_bounds__(256) void enc_gemm_split_kernel(const float* __restrict__ x, const unsigned short* __restrict__ w3,
+                                                             float* __restrict__ out, int M, int K, int O, int kslice) {
+    constexpr int BM = 2 * WM, BN = 128, BK = 32, LDK = 40;  // LDK: padded row length in bf16 elements (80 B)
+    constexpr int RT = WM / 32;                              // 32-row MFMA tiles per wave
+    constexpr int XU = BM * BK / 4 / 256;                    // float4 loads of x per thread per chunk
+    __shared__ __attribute__((aligned(16))) __bf16 xs[3][BM][LDK];
+    __shared__ __attribute__((aligned(16))) __bf16 wsm[3][BN][LDK];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int row0 = blockIdx.x * BM;
+    const int kbeg = blockIdx.y * kslice;
+    const size_t plane = (size_t)O * K;
+    int xr[XU], xc[XU];
+#pragma unroll
+    for (int u = 0; u < XU; ++u) {
+        const int idx = tid + 256 * u;
+        xr[u] = idx >> 3;
+        xc[u] = (idx & 7) * 4;
+    }
+    int wp[6], wcol[6], wk[6];
+#pragma unroll
+    for (int u = 0; u < 6; ++u) {
+        const int idx = tid + 256 * u;
+        wp[u] = idx >> 9;
+        wcol[u] = (idx & 511) >> 2;
+        wk[u] = (idx & 3) * 8;
+    }
+    f32x4 xreg[XU];
+    bf16x8 wreg[6];
+    auto load_tile = [&](int kt) {
+#pragma unroll
+        for (int u = 0; u < XU; ++u) {
+            const int r = min(row0 + xr[u], M - 1);
+            xreg[u] = *reinterpret_cast<const f32x4*>(x + (size_t)r * K + kbeg + kt * BK + xc[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 6; ++u)
+            wreg[u] = *reinterpret_cast<const bf16x8*>(w3 + wp[u] * plane + (size_t)wcol[u] * K + kbeg + kt * BK + wk[u]);
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int u = 0; u < XU; ++u) {
+            bf16x4 p0, p1, p2;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float v = xreg[u][q];
+                const __bf16 h0 = (__bf16)v;
+                const float r1 = v - (float)h0;
+                const __bf16 h1 = (__bf16)r1;
+                const float r2 = r1 - (float)h1;
+                p0[q] = h0;
+                p1[q] = h1;
+                p2[q] = (__bf16)r2;
+            }
+            *reinterpret_cast<bf16x4*>(&xs[0][xr[u]][xc[u]]) = p0;
+            *reinterpret_cast<bf16x4*>(&xs[1][xr[u]][xc[u]]) = p1;
+            *reinterpret_cast<bf16x4*>(&xs[2][xr[u]][xc[u]]) = p2;
+        }
+#pragma unroll
+        for (int u = 0; u < 6; ++u) *reinterpret_cast<bf16x8*>(&wsm[wp[u]][wcol[u]][wk[u]]) = wreg[u];
+    };
+    f32x16 acc[RT][2];
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[r][c][i] = 0.f;
+    const int nk = min(kslice, K - kbeg) / BK;
+    load_tile(0);
+    store_tile();
+    __syncthreads();
+    const int k8 = 8 * (lane >> 5);
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) load_tile(kt + 1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 a[RT][3], b[2][3];
+#pragma unroll
+            for (int r = 0; r < RT; ++r)
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    a[r][p] = *reinterpret_cast<const bf16x8*>(&xs[p][wr * WM + r * 32 + (lane & 31)][ks * 16 + k8]);
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    b[c][p] = *reinterpret_cast<const bf16x8*>(&wsm[p][wc * 64 + c * 32 + (lane & 31)][ks * 16 + k8]);
+#pragma unroll
+            for (int r = 0; r < RT; ++r)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    // smallest terms first
+                    acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[r][2], b[c][0], acc[r][c], 0, 0, 0);
+                    acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[r][1], b[c][1], acc[r][c], 0, 0, 0);
+                    acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[r][0], b[c][2], acc[r][c], 0, 0, 0);
+                    acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[r][1], b[c][0], acc[r][c], 0, 0, 0);
+                    acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[r][0], b[c][1], acc[r][c], 0, 0, 0);
+                    acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[r][0], b[c][0], acc[r][c], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+        if (kt + 1 < nk) store_tile();
+        __syncthreads();
+    }
+    float* __restrict__ dst = out + (size_t)blockIdx.y * M * O;  // split-K partial slab
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int col = wc * 64 + c * 32 + (lane & 31);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = row0 + wr * WM + r * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+                if (row < M) dst[(size_t)row * O + col] = acc[r][c][i];
+            }
+        }
+}
+
 // act[M][O] = [ReLU](bias + sum_ks part[ks][M][O]) -- only for encoders deeper than two layers.
 __global__ __launch_bounds__(256) void reduce_bias_act_kernel(const float* __restrict__ part, const float* __restrict__ bias,
                                                               float* __restrict__ act, int M, int O, int ks, int relu) {
@@ -1361,6 +1495,7 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
         const int ks = g == 0 ? ws.ksplit : 1;
         int kslice = (K + ks - 1) / ks;
         kslice = (kslice + 63) / 64 * 64;
+        const bool split = g == 0 && hdr.enc_w3 != 0 && N >= 4096 && (reinterpret_cast<uintptr_t>(cur_in) & 15) == 0;
         EncPlanParams ep;
         std::memset(&ep, 0, sizeof(ep));
         ep.in = cur_in;
@@ -1373,7 +1508,21 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
         ep.vec_ok = (K % 4 == 0) && ((reinterpret_cast<uintptr_t>(cur_in) & 15) == 0);
         ep.nrt = (N + 31) / 32;
         ep.nks = ks;
-        ep.gemm_blocks = ep.nrt * ks * ((O + 127) / 128);
+        ep.gemm_blocks = split ? 0 : ep.nrt * ks * ((O + 127) / 128);
+        int ks_split = 1;
+        if (split) {  // big batches: split-bf16 MFMA GEMM; the plan gets its own launch
+            const unsigned short* w3 = reinterpret_cast<const unsigned short*>(blob + hdr.enc_w3);
+            if (N >= 32768) {  // 128-row workgroups: the weight tile is amortised over twice the rows
+                hipLaunchKernelGGL((enc_gemm_split_kernel<64>), dim3((N + 127) / 128, 1), dim3(256), 0, st, cur_in, w3, part, N,
+                                   K, O, K);
+            } else {           // 64-row workgroups + split-K so that >= 512 workgroups are in flight
+                while (ks_split < ws.ksplit && ((N + 63) / 64) * ks_split < 512 && (K / (ks_split * 2)) % 32 == 0) ks_split *= 2;
+                hipLaunchKernelGGL((enc_gemm_split_kernel<32>), dim3((N + 63) / 64, ks_split), dim3(256), 0, st, cur_in, w3,
+                                   part, N, K, O, K / ks_split);
+            }
+            HIP_TRY(hipGetLastError());
+            PROF_MARK(GNNCCA_K_ENC_GEMM);
+        }
         int plan_blocks = 0;
         if (g == 0 && E > 0) {  // the graph plan rides in the first GEMM launch
             ep.ei = reinterpret_cast<const long long*>(edge_index);
@@ -1384,10 +1533,12 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
             ep.N = N;
             plan_blocks = (E + 255) / 256;
         }
-        hipLaunchKernelGGL(enc_gemm_plan_kernel, dim3(ep.gemm_blocks + plan_blocks), dim3(256), 0, st, ep);
-        HIP_TRY(hipGetLastError());
-        PROF_MARK(GNNCCA_K_ENC_GEMM);
-        ks_last = ks;
+        if (ep.gemm_blocks + plan_blocks > 0) {
+            hipLaunchKernelGGL(enc_gemm_plan_kernel, dim3(ep.gemm_blocks + plan_blocks), dim3(256), 0, st, ep);
+            HIP_TRY(hipGetLastError());
+            PROF_MARK(split ? GNNCCA_K_PLAN_ROWS : GNNCCA_K_ENC_GEMM);
+        }
+        ks_last = split ? ks_split : ks;
         if (g < n_gemm - 1) {
             float* dst = act + (size_t)(g & 1) * N * O;
             hipLaunchKernelGGL(reduce_bias_act_kernel, grid1((size_t)N * O, 256), dim3(256), 0, st, (const float*)part,

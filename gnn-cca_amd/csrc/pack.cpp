@@ -114,6 +114,25 @@ bool fast_consts_ok(const gnncca_mpn_dims* d) {
            d->cls_edge.n_layers == 2 && d->cls_edge.layers[0].out_dim == 4;
 }
 
+bool enc_split_ok(const gnncca_mpn_dims* d) {
+    return classify(d) == kFamilyMfma32x6 && d->enc_node.n_layers >= 2 && d->enc_node.layers[0].out_dim == 128 &&
+           d->enc_node.layers[0].in_dim % 32 == 0;
+}
+
+// fp32 -> bf16, round to nearest even (finite inputs; weights are finite)
+static inline uint16_t bf16_rne(float f) {
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+static inline float bf16_to_float(uint16_t h) {
+    const uint32_t u = (uint32_t)h << 16;
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+}
+
 // ---------------------------------------------------------------------------------------------
 struct BlobPlan {
     BlobHeader h;
@@ -156,6 +175,7 @@ static BlobPlan plan_blob(const gnncca_mpn_dims* d) {
         p.h.cls_w2 = p.h.cls_b2 = 0;
     }
     p.h.fast_consts = fast_consts_ok(d) ? take(kFastConsts) : 0;
+    p.h.enc_w3 = enc_split_ok(d) ? take((size_t)3 * d->enc_node.layers[0].in_dim * d->enc_node.layers[0].out_dim / 2) : 0;
     p.total_floats = off;
     p.h.total_floats = (uint32_t)off;
     return p;
@@ -269,6 +289,22 @@ int gnncca_pack_weights(const gnncca_mpn_dims* d, const float* const* params, in
         Folded f = fold_layer(d->enc_node.layers[i], cur);
         std::memcpy(blob + p.h.enc_node_w[i], f.w.data(), f.w.size() * sizeof(float));
         std::memcpy(blob + p.h.enc_node_b[i], f.b.data(), f.b.size() * sizeof(float));
+        if (i == 0 && p.h.enc_w3) {
+            // w = w0 + w1 + w2 with bf16 pieces (24 mantissa bits in all): the split-bf16 GEMM multiplies the
+            // pieces on the bf16 MFMA pipe and recovers fp32-level accuracy
+            uint16_t* w3 = reinterpret_cast<uint16_t*>(blob + p.h.enc_w3);
+            const size_t n = f.w.size();
+            for (size_t k = 0; k < n; ++k) {
+                const float v = f.w[k];
+                const uint16_t h0 = bf16_rne(v);
+                const float r1 = v - bf16_to_float(h0);
+                const uint16_t h1 = bf16_rne(r1);
+                const float r2 = r1 - bf16_to_float(h1);
+                w3[k] = h0;
+                w3[n + k] = h1;
+                w3[2 * n + k] = bf16_rne(r2);
+            }
+        }
         if (i == d->enc_node.n_layers - 1)
             for (int o = 0; o < kH; ++o)
                 for (int k = 0; k < f.in; ++k) blob[p.h.enc_last_wT + (size_t)k * kH + o] = f.w[(size_t)o * f.in + k];
@@ -400,6 +436,9 @@ Workspace carve(const gnncca_mpn_dims* d, int64_t n, int64_t e) {
     const size_t row_tiles = (N + 31) / 32;
     int ks = 1;
     while (ks < 32 && row_tiles * (size_t)ks < 512 && k0 / (ks * 2) >= 64) ks *= 2;
+    // mid-size batches run the split-bf16 GEMM with 64-row workgroups: room for its split-K factor too
+    if (N >= 4096 && N < 32768)
+        while (ks < 8 && ((N + 63) / 64) * (size_t)ks < 512 && k0 / (ks * 2) >= 64) ks *= 2;
     w.ksplit = ks;
     size_t fmax = 0;
     for (int i = 0; i < d->enc_node.n_layers; ++i)

@@ -188,3 +188,31 @@ def test_empty_graph():
         out = m(Data(torch.randn(4, 2048).cuda(), torch.zeros(2, 0, dtype=torch.long).cuda(),
                      torch.rand(0, 4).cuda()))["classified_edges"]
     assert len(out) == 3 and all(tuple(o.shape) == (0, 1) for o in out)
+
+
+def test_big_batch_split_bf16_encoder_vs_oracle():
+    """64 x dense128 (N = 8192 nodes, E = 1.04 M edges: the per-GPU share of BASELINE config 4).  At this size the
+    first encoder layer runs on the split-bf16 MFMA GEMM; its fp32-level accuracy is checked on the encoder output
+    itself and on the logits."""
+    params, arch, sd = _default_model(1.0 / 127)
+    rng = np.random.default_rng(11)
+    g, n = 64, 128
+    x = rng.standard_normal((g * n, 2048)).astype(np.float32)
+    x /= np.linalg.norm(x, axis=0, keepdims=True)
+    ei = np.concatenate([_dense_graph(n, k * n) for k in range(g)], axis=1)
+    ea = rng.random((ei.shape[1], 4)).astype(np.float32)
+    orc = NumpyOracle(params, arch, sd, np.float32)
+    tr = {}
+    ref = orc.forward(x, ei, ea, tr)
+    m = build(params, arch, sd)
+    d = Data(torch.from_numpy(x).cuda(), torch.from_numpy(ei).cuda(), torch.from_numpy(ea).cuda())
+    trace = {}
+    with torch.no_grad():
+        out = [t.clone() for t in m(d)["classified_edges"]]
+        m(d, trace=trace)
+    h64 = NumpyOracle(params, arch, sd, np.float64)._mlp("encoder.node_mlp", x.astype(np.float64))
+    err_gpu = np.abs(trace["h_enc"].cpu().numpy() - h64).max()
+    err_ref = np.abs(tr["h_enc"] - h64).max()
+    assert err_gpu <= max(4 * err_ref, 2e-7), (err_gpu, err_ref)  # as accurate as an fp32 GEMM, judged against fp64
+    for o, r in zip(out, ref):
+        assert np.abs(o.cpu().numpy() - r).max() <= TOL_TIGHT * 2
