@@ -10,8 +10,8 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libgnncca_mpn.so")
-SOURCES = ["pack.cpp", "mpn_kernels.hip", "graph_build.hip"]
-HEADERS = [os.path.join(CSRC, "internal.h"), os.path.join(ROOT, "include", "gnncca_mpn.h")]
+SOURCES = ["pack.cpp", "mpn_forward.hip", "graph_build.hip"]
+HEADERS = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".cuh"))] + [os.path.join(ROOT, "include", "gnncca_mpn.h")]
 
 
 def _hipcc():

@@ -1,0 +1,408 @@
+#pragma once
+// Part of the single translation unit mpn_forward.hip (kernels share device helpers and the launch code below
+// instantiates their templates); see that file for the overall picture.
+namespace gnncca {
+
+// ------------------------------------------------------------------------------------------------------------
+// Node encoder GEMM: part[ks][M][O] = in[M][kslice ks] . W[O][kslice ks]^T with v_mfma_f32_32x32x2_f32 (exact
+// fp32 FMA chain).  One wave = 32 rows x 32 output columns; a workgroup = 4 waves = 128 columns.
+// k-permutation: within a 64-deep chunk, lane (r, h) feeds k = kc + 32h + s at MFMA step s for BOTH operands, so
+// every lane reads 128 contiguous bytes of its own row (8 x float4) and no LDS transpose is needed.
+// Split-K fills the chip when M is small (M = 256 nodes -> 8 row tiles x 32 slices).
+// Replaces the first nn.Linear of encoder.node_mlp (models/mpn.py:131 <- models/mlp.py:13).
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void gemm_tile(int rt, int ks, int cg, const float* __restrict__ in, const float* __restrict__ W,
+                                          float* __restrict__ part, int M, int K, int O, int kslice, int vec_ok) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int row0 = rt * 32;
+    const int col0 = (cg * 4 + wave) * 32;
+    if (col0 >= O) return;
+    const int arow = min(row0 + r, M - 1);
+    const int wrow = min(col0 + r, O - 1);
+    const float* __restrict__ ap = in + (size_t)arow * K;
+    const float* __restrict__ wp = W + (size_t)wrow * K;
+    const int kbeg = ks * kslice;
+    const int kend = min(kbeg + kslice, K);
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int kc = kbeg; kc < kend; kc += 64) {
+        float a[32], b[32];
+        const int k0 = kc + 32 * h;
+        if (vec_ok && kc + 64 <= kend) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const f32x4 av = *reinterpret_cast<const f32x4*>(ap + k0 + 4 * j);
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(wp + k0 + 4 * j);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    a[4 * j + q] = av[q];
+                    b[4 * j + q] = bv[q];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < 32; ++s) {
+                const int k = k0 + s;
+                a[s] = (k < kend) ? ap[k] : 0.f;
+                b[s] = (k < kend) ? wp[k] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 32; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], acc, 0, 0, 0);
+    }
+    const int col = col0 + r;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int row = row0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        if (row < M && col < O) part[((size_t)ks * M + row) * O + col] = acc[i];
+    }
+}
+
+// Second half of the plan, run by ONE 256-thread workgroup of the launch that follows the plan blocks on the stream:
+// One launch, two roles: workgroups [0, gemm_blocks) run encoder GEMM tiles, the rest run the graph plan -- the
+// two are independent, so the plan's HBM pass over edge_index hides under the GEMM instead of costing a launch.
+struct EncPlanParams {
+    const float* in;
+    const float* W;
+    float* part;
+    const long long* ei;
+    int* seg_ptr;
+    int* col32;
+    unsigned* blockflags;
+    int M, K, O, kslice, vec_ok, nrt, nks, gemm_blocks, E, N;
+};
+
+__global__ __launch_bounds__(256) void enc_gemm_plan_kernel(const EncPlanParams p) {
+    __shared__ unsigned s_fl;
+    GNNCCA_STAMP(1, 0);
+    const int b = blockIdx.x;
+    if (b < p.gemm_blocks) {
+        const int rt = b % p.nrt, t = b / p.nrt;
+        gemm_tile(rt, t % p.nks, t / p.nks, p.in, p.W, p.part, p.M, p.K, p.O, p.kslice, p.vec_ok);
+    } else {
+        plan_block(b - p.gemm_blocks, p.ei, p.E, p.N, p.seg_ptr, p.col32, p.blockflags, &s_fl);
+    }
+    GNNCCA_STAMP(1, 1);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Large-N encoder GEMM on the bf16 MFMA pipe with fp32-level accuracy ("split-bf16"):  x = x0 + x1 + x2 and
+// w = w0 + w1 + w2 with bf16 pieces (3 x 8 = 24 mantissa bits, the pieces of w prepared at pack time, those of x
+// on the fly while staging), and  x.w ~= x2w0 + x1w1 + x0w2 + x1w0 + x0w1 + x0w0  -- the dropped terms are
+// <= 2^-24 relative.  Every product of two bf16 values is exact in fp32 and the MFMA accumulates in fp32, so the
+// result differs from an fp32 FMA chain only by rounding of the same order as fp32 itself, while the six
+// v_mfma_f32_32x32x16_bf16 cost 6/16 of the v_mfma_f32_32x32x2_f32 time: the GEMM becomes HBM-bound on the
+// x read (8 KB per node) instead of MFMA-bound.
+// Workgroup = 64 rows x 128 columns, 4 waves as 2 x 2 (32 rows x 64 columns each), K in chunks of 32 through LDS
+// (rows padded to 80 B: conflict-free ds_read_b128); the next chunk's global loads are in flight during the MFMAs.
+// ------------------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+template <int WM>  // rows per wave: 32 (workgroup 64 x 128) or 64 (workgroup 128 x 128)
+__global__ __launch_bounds__(256) void enc_gemm_split_kernel(const float* __restrict__ x, const unsigned short* __restrict__ w3,
+                                                             float* __restrict__ out, int M, int K, int O, int kslice) {
+    constexpr int BM = 2 * WM, BN = 128, BK = 32, LDK = 40;  // LDK: padded row length in bf16 elements (80 B)
+    constexpr int RT = WM / 32;                              // 32-row MFMA tiles per wave
+    constexpr int XU = BM * BK / 4 / 256;                    // float4 loads of x per thread per chunk
+    __shared__ __attribute__((aligned(16))) __bf16 xs[3][BM][LDK];
+    __shared__ __attribute__((aligned(16))) __bf16 wsm[3][BN][LDK];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int row0 = blockIdx.x * BM;
+    const int kbeg = blockIdx.y * kslice;
+    const size_t plane = (size_t)O * K;
+    int xr[XU], xc[XU];
+#pragma unroll
+    for (int u = 0; u < XU; ++u) {
+        const int idx = tid + 256 * u;
+        xr[u] = idx >> 3;
+        xc[u] = (idx & 7) * 4;
+    }
+    int wp[6], wcol[6], wk[6];
+#pragma unroll
+    for (int u = 0; u < 6; ++u) {
+        const int idx = tid + 256 * u;
+        wp[u] = idx >> 9;
+        wcol[u] = (idx & 511) >> 2;
+        wk[u] = (idx & 3) * 8;
+    }
+    f32x4 xreg[XU];
+    bf16x8 wreg[6];
+    auto load_tile = [&](int kt) {
+#pragma unroll
+        for (int u = 0; u < XU; ++u) {
+            const int r = min(row0 + xr[u], M - 1);
+            xreg[u] = *reinterpret_cast<const f32x4*>(x + (size_t)r * K + kbeg + kt * BK + xc[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 6; ++u)
+            wreg[u] = *reinterpret_cast<const bf16x8*>(w3 + wp[u] * plane + (size_t)wcol[u] * K + kbeg + kt * BK + wk[u]);
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int u = 0; u < XU; ++u) {
+            bf16x4 p0, p1, p2;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float v = xreg[u][q];
+                const __bf16 h0 = (__bf16)v;
+                const float r1 = v - (float)h0;
+                const __bf16 h1 = (__bf16)r1;
+                const float r2 = r1 - (float)h1;
+                p0[q] = h0;
+                p1[q] = h1;
+                p2[q] = (__bf16)r2;
+            }
+            *reinterpret_cast<bf16x4*>(&xs[0][xr[u]][xc[u]]) = p0;
+            *reinterpret_cast<bf16x4*>(&xs[1][xr[u]][xc[u]]) = p1;
+            *reinterpret_cast<bf16x4*>(&xs[2][xr[u]][xc[u]]) = p2;
+        }
+#pragma unroll
+        for (int u = 0; u < 6; ++u) *reinterpret_cast<bf16x8*>(&wsm[wp[u]][wcol[u]][wk[u]]) = wreg[u];
+    };
+    f32x16 acc[RT][2];
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[r][c][i] = 0.f;
+    const int nk = min(kslice, K - kbeg) / BK;
+    load_tile(0);
+    store_tile();
+    __syncthreads();
+    const int k8 = 8 * (lane >> 5);
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) load_tile(kt + 1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 a[RT][3], b[2][3];
+#pragma unroll
+            for (int r = 0; r < RT; ++r)
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    a[r][p] = *reinterpret_cast<const bf16x8*>(&xs[p][wr * WM + r * 32 + (lane & 31)][ks * 16 + k8]);
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    b[c][p] = *reinterpret_cast<const bf16x8*>(&wsm[p][wc * 64 + c * 32 + (lane & 31)][ks * 16 + k8]);
+#pragma unroll
+            for (int r = 0; r < RT; ++r)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    // smallest terms first
+                    acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[r][2], b[c][0], acc[r][c], 0, 0, 0);
+                    acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[r][1], b[c][1], acc[r][c], 0, 0, 0);
+                    acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[r][0], b[c][2], acc[r][c], 0, 0, 0);
+                    acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[r][1], b[c][0], acc[r][c], 0, 0, 0);
+                    acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[r][0], b[c][1], acc[r][c], 0, 0, 0);
+                    acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[r][0], b[c][0], acc[r][c], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+        if (kt + 1 < nk) store_tile();
+        __syncthreads();
+    }
+    float* __restrict__ dst = out + (size_t)blockIdx.y * M * O;  // split-K partial slab
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int col = wc * 64 + c * 32 + (lane & 31);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = row0 + wr * WM + r * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+                if (row < M) dst[(size_t)row * O + col] = acc[r][c][i];
+            }
+        }
+}
+
+// act[M][O] = [ReLU](bias + sum_ks part[ks][M][O]) -- only for encoders deeper than two layers.
+__global__ __launch_bounds__(256) void reduce_bias_act_kernel(const float* __restrict__ part, const float* __restrict__ bias,
+                                                              float* __restrict__ act, int M, int O, int ks, int relu) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)M * O) return;
+    float v = bias[idx % O];
+    for (int s = 0; s < ks; ++s) v += part[(size_t)s * M * O + idx];
+    act[idx] = relu ? fmaxf(v, 0.f) : v;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Per-node projection for the NEXT message-passing step.  Called by one whole wave that holds the node's latent
+// h[c] in lane c (c < 32, mirrored in lanes 32..63).  Lane o < 48 produces projection slot o:
+//   [0,6) P_dst   [8,14) P_src + b_e   [16,48) Q + b_n          (weights transposed in LDS: [c][48])
+// With reattach_initial_nodes the input is cat((initial, latent)) -- initial first (models/mpn.py:285).
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void project_node(float h_latent, float h_init, bool reatt_n, const float* s_projT,
+                                             const float* projb, float* __restrict__ pd_row,
+                                             float* __restrict__ psq_row, int lane) {
+    const int o = min(lane, kProjOut - 1);
+    float acc = projb[o];
+    const float* w = s_projT + o;
+    if (reatt_n) {
+#pragma unroll
+        for (int c = 0; c < kH; ++c)
+            acc = fmaf(w[c * kProjOut], __int_as_float(__builtin_amdgcn_readlane(__float_as_int(h_init), c)), acc);
+        w += kH * kProjOut;
+    }
+#pragma unroll
+    for (int c = 0; c < kH; ++c)
+        acc = fmaf(w[c * kProjOut], __int_as_float(__builtin_amdgcn_readlane(__float_as_int(h_latent), c)), acc);
+    if (lane < kPdStride)
+        pd_row[lane] = acc;
+    else if (lane < kProjOut)
+        psq_row[lane - kPdStride] = acc;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Encoder tail: finishes the previous GEMM layer (sum of split-K partials in fixed order + bias + ReLU), applies
+// the last encoder layer F -> 32 (+ReLU), stores h0 and emits the step-1 projections.  One wave per node.
+// Replaces the rest of encoder.node_mlp (models/mpn.py:131) and the x[row]/x[col] gathers of step 1.
+// ------------------------------------------------------------------------------------------------------------
+struct TailParams {
+    const float* blob;
+    const float* part;
+    float* h0;
+    float* trace_h;
+    float* pd_out;
+    float* psq_out;
+    int off_prev_b, off_lastWT, off_last_b, off_projwT, off_projb;
+    int ks, F, N, has_last, relu_prev, reatt_n, hin, vec_reduce;
+    // graph-plan repair (runs in the extra last workgroup only when the graph was flagged unsorted)
+    const long long* ei;
+    int* seg_ptr;
+    int* col32;
+    int* perm;
+    int* cursor;
+    unsigned* flags;
+    const unsigned* blockflags;
+    int E;
+};
+
+__global__ __launch_bounds__(256) void enc_tail_kernel(const TailParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* s_proj = smem;                                    // [hin][48]
+    float* s_last = s_proj + p.hin * kProjOut;               // [F][32]   (has_last)
+    float* s_row = s_last + (p.has_last ? p.F * kH : 0);     // [4][F]
+    float* s_red = s_row + 4 * p.F;                          // [4][64 floats x 4]  (vec_reduce)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* __restrict__ blob = p.blob;
+    if (blockIdx.x == gridDim.x - 1) {  // the plan workgroup: fold the per-block findings, repair if needed
+        plan_finish(p.ei, p.E, p.N, p.seg_ptr, p.col32, p.perm, p.cursor, p.flags, p.blockflags,
+                    reinterpret_cast<unsigned*>(smem));
+        return;
+    }
+    GNNCCA_STAMP(0, 0);
+    const int nblk = gridDim.x - 1;
+    const int o = lane & 31, half = lane >> 5;
+    float* rowbuf = s_row + wave * p.F;
+    float* redbuf = s_red + wave * 256;
+    // split-K partial sum of one node row: F/4 float4 chunks per row; 64/(F/4) lane groups walk the partials in an
+    // interleaved, fixed order with all loads independent (one round trip instead of ks dependent ones)
+    const int nchunk = p.vec_reduce ? (p.F >> 2) : 64, groups = 64 / nchunk;
+    const int rg = lane / nchunk, rc = lane - rg * nchunk;
+    auto partial_sum = [&](int node) {
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        if (p.vec_reduce && node < p.N && rg < groups) {
+            const float* __restrict__ src = p.part + (size_t)node * p.F + 4 * rc;
+            const size_t sstride = (size_t)p.N * p.F;
+#pragma unroll 8
+            for (int s = rg; s < p.ks; s += groups) a += *reinterpret_cast<const f32x4*>(src + s * sstride);
+        }
+        return a;
+    };
+    // Issue order = completion order (vmcnt): weights first (consumed first, by the LDS stage), then biases, then
+    // the first node's partials, so that one round trip covers all three.
+    const int n4p = p.hin * kProjOut / 4, n4l = p.has_last ? p.F * kH / 4 : 0;
+    const f32x4* __restrict__ gp4 = reinterpret_cast<const f32x4*>(blob + p.off_projwT);
+    const f32x4* __restrict__ gl4 = reinterpret_cast<const f32x4*>(blob + p.off_lastWT);
+    f32x4 rp[3], rl[4];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) rp[u] = gp4[min(u * 256 + tid, n4p - 1)];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) rl[u] = gl4[min(u * 256 + tid, max(n4l - 1, 0))];
+    const float last_b = p.has_last ? blob[p.off_last_b + o] : 0.f;
+    const float prev_b0 = blob[p.off_prev_b + min(lane, p.F - 1)];
+    const float prev_b1 = blob[p.off_prev_b + min(lane + 64, p.F - 1)];
+    f32x4 pre = partial_sum(blockIdx.x * 4 + wave);
+    GNNCCA_STAMP(0, 1);
+    {
+        f32x4* lp4 = reinterpret_cast<f32x4*>(s_proj);
+        f32x4* ll4 = reinterpret_cast<f32x4*>(s_last);
+#pragma unroll
+        for (int u = 0; u < 3; ++u)
+            if (u * 256 + tid < n4p) lp4[u * 256 + tid] = rp[u];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (u * 256 + tid < n4l) ll4[u * 256 + tid] = rl[u];
+        for (int i = 1024 + tid; i < n4l; i += 256) ll4[i] = gl4[i];  // F > 128: the rest, plainly
+    }
+    GNNCCA_STAMP(0, 2);
+    __syncthreads();
+    GNNCCA_STAMP(0, 3);
+    for (int grp = blockIdx.x; grp * 4 < p.N; grp += nblk) {
+        const int node = grp * 4 + wave;
+        const bool active = node < p.N;
+        if (active) {
+            if (p.vec_reduce) {
+                if (rg < groups) *reinterpret_cast<f32x4*>(redbuf + rg * p.F + 4 * rc) = pre;
+                __builtin_amdgcn_wave_barrier();
+                for (int f = lane; f < p.F; f += 64) {
+                    float v = f < 64 ? prev_b0 : (f < 128 ? prev_b1 : blob[p.off_prev_b + f]);
+                    for (int gg = 0; gg < groups; ++gg) v += redbuf[gg * p.F + f];
+                    rowbuf[f] = p.relu_prev ? fmaxf(v, 0.f) : v;
+                }
+            } else {
+                for (int f = lane; f < p.F; f += 64) {
+                    float v = blob[p.off_prev_b + f];
+                    for (int s = 0; s < p.ks; ++s) v += p.part[((size_t)s * p.N + node) * p.F + f];
+                    rowbuf[f] = p.relu_prev ? fmaxf(v, 0.f) : v;
+                }
+            }
+        }
+        GNNCCA_STAMP(0, 4);
+        pre = partial_sum((grp + nblk) * 4 + wave);  // next node of this wave, in flight during the layer below
+        __syncthreads();
+        GNNCCA_STAMP(0, 5);
+        float hv = 0.f;
+        if (active) {
+            if (p.has_last) {
+                // four independent accumulators and an 8-deep unroll keep 16 LDS reads in flight per lane
+                float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+                int f = half;
+                for (; f + 14 < p.F; f += 16) {
+#pragma unroll
+                    for (int u = 0; u < 8; u += 4) {
+                        acc0 = fmaf(rowbuf[f + 2 * u + 0], s_last[(f + 2 * u + 0) * kH + o], acc0);
+                        acc1 = fmaf(rowbuf[f + 2 * u + 2], s_last[(f + 2 * u + 2) * kH + o], acc1);
+                        acc2 = fmaf(rowbuf[f + 2 * u + 4], s_last[(f + 2 * u + 4) * kH + o], acc2);
+                        acc3 = fmaf(rowbuf[f + 2 * u + 6], s_last[(f + 2 * u + 6) * kH + o], acc3);
+                    }
+                }
+                for (; f < p.F; f += 2) acc0 = fmaf(rowbuf[f], s_last[f * kH + o], acc0);
+                float acc = (acc0 + acc1) + (acc2 + acc3);
+                acc += __shfl_xor(acc, 32);
+                hv = fmaxf(acc + last_b, 0.f);
+            } else {
+                hv = rowbuf[o];
+            }
+            GNNCCA_STAMP(0, 6);
+            if (lane < kH) {
+                p.h0[(size_t)node * kH + lane] = hv;
+                if (p.trace_h) p.trace_h[(size_t)node * kH + lane] = hv;
+            }
+            project_node(hv, hv, p.reatt_n != 0, s_proj, blob + p.off_projb, p.pd_out + (size_t)node * kPdStride,
+                         p.psq_out + (size_t)node * kPsQStride, lane);
+            GNNCCA_STAMP(0, 7);
+        }
+        __syncthreads();
+    }
+    GNNCCA_STAMP(0, 8);
+}
+
+
+}  // namespace gnncca

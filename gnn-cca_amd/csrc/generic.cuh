@@ -1,0 +1,260 @@
+#pragma once
+// Part of the single translation unit mpn_forward.hip (kernels share device helpers and the launch code below
+// instantiates their templates); see that file for the overall picture.
+namespace gnncca {
+
+// ============================================================================================================
+// Generic family: any legal GRAPH_NET_PARAMS outside the MFMA family (node latent != 32, edge latent != 6,
+// multi-layer edge / node MLPs, deeper classifiers ...).  None of the shipped configs needs it; it exists so
+// that the module is a drop-in for the whole constructor contract (models/mpn.py:154-247).  It follows the
+// reference op for op -- virtual concatenation, Linear(+folded BN)(+ReLU) layer by layer, aggregation over the
+// CSR segments in the caller's edge order (the order torch's CPU index_add_ sums in) -- with plain one-thread-
+// per-output kernels: correctness first, no tuning.
+// ============================================================================================================
+struct GenSeg {
+    const float* ptr;   // [rows][ld]
+    const int* idx;     // optional row gather (row32 / col32 in the caller's edge order), or null
+    int ld, width;
+};
+
+// out[r][o] = [ReLU](b[o] + sum over the concatenated segments of W[o][:] . in[r][:])
+__global__ __launch_bounds__(256) void gen_dense_kernel(GenSeg s0, GenSeg s1, GenSeg s2, const float* __restrict__ W,
+                                                        const float* __restrict__ b, float* __restrict__ out, long long M,
+                                                        int K, int O, int ld_out, int relu) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= M * O) return;
+    const long long r = t / O;
+    const int o = (int)(t - r * O);
+    const float* __restrict__ w = W + (size_t)o * K;
+    float acc = b[o];
+    const GenSeg segs[3] = {s0, s1, s2};
+    int koff = 0;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const GenSeg& sg = segs[q];
+        if (sg.width == 0) continue;
+        const long long rr = sg.idx ? (long long)sg.idx[r] : r;
+        const float* __restrict__ src = sg.ptr + (size_t)rr * sg.ld;
+        for (int k = 0; k < sg.width; ++k) acc = fmaf(w[koff + k], src[k], acc);
+        koff += sg.width;
+    }
+    out[(size_t)r * ld_out + o] = relu ? fmaxf(acc, 0.f) : acc;
+}
+
+__global__ __launch_bounds__(256) void gen_index32_kernel(const long long* __restrict__ ei, int E, int N,
+                                                          int* __restrict__ row32, int* __restrict__ col32) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= E) return;
+    const long long r = ei[k], c = ei[(size_t)E + k];
+    row32[k] = (r >= 0 && r < N) ? (int)r : 0;  // out-of-range ids are flagged by the plan; keep gathers in bounds
+    col32[k] = (c >= 0 && c < N) ? (int)c : 0;
+}
+
+__global__ __launch_bounds__(256) void gen_plan_finish_kernel(const long long* __restrict__ ei, int E, int N, int* seg_ptr,
+                                                              int* col32, int* perm, int* cursor, unsigned* flags,
+                                                              const unsigned* __restrict__ blockflags) {
+    __shared__ unsigned smem[1024];
+    plan_finish(ei, E, N, seg_ptr, col32, perm, cursor, flags, blockflags, smem);
+}
+
+// h[i][c] = agg over the segment of node i of m[k][c], k in the caller's edge order (models/mpn.py:99,192-202)
+__global__ __launch_bounds__(256) void gen_aggregate_kernel(const float* __restrict__ m, const int* __restrict__ seg_ptr,
+                                                            const int* __restrict__ perm, const unsigned* __restrict__ flags,
+                                                            float* __restrict__ h, int N, int H, int agg) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long long)N * H) return;
+    const int i = (int)(t / H), c = (int)(t - (long long)i * H);
+    const unsigned fl = flags[0];
+    if (fl & GNNCCA_GRAPH_BAD_INDEX) {
+        h[t] = __builtin_nanf("");
+        return;
+    }
+    const bool unsorted = (fl & GNNCCA_GRAPH_UNSORTED) != 0;
+    const int s = seg_ptr[i], e = seg_ptr[i + 1];
+    float v = agg == GNNCCA_AGG_MAX ? -INFINITY : 0.f;
+    for (int p = s; p < e; ++p) {
+        const int k = unsorted ? perm[p] : p;
+        const float x = m[(size_t)k * H + c];
+        v = agg == GNNCCA_AGG_MAX ? fmaxf(v, x) : v + x;
+    }
+    if (agg == GNNCCA_AGG_MEAN) v = v / (float)max(e - s, 1);
+    if (e == s) v = 0.f;
+    h[t] = v;
+}
+
+__global__ __launch_bounds__(256) void gen_poison_kernel(float* __restrict__ out, long long n, const unsigned* __restrict__ flags) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t < n && (flags[0] & GNNCCA_GRAPH_BAD_INDEX)) out[t] = __builtin_nanf("");
+}
+
+static int gen_run_mlp(const gnncca_mlp& mlp, const float* blob, const int32_t* woff, const int32_t* boff, GenSeg in0,
+                       GenSeg in1, GenSeg in2, long long M, float* out_final, int ld_final, float* tmp_a, float* tmp_b,
+                       int ld_tmp, hipStream_t st) {
+    GenSeg none = {nullptr, nullptr, 0, 0};
+    GenSeg a = in0, b = in1, c = in2;
+    float* bufs[2] = {tmp_a, tmp_b};
+    for (int l = 0; l < mlp.n_layers; ++l) {
+        const gnncca_layer& L = mlp.layers[l];
+        const bool last = l == mlp.n_layers - 1;
+        float* dst = last ? out_final : bufs[l & 1];
+        const int ld = last ? ld_final : ld_tmp;
+        const long long total = M * L.out_dim;
+        if (total > 0) {
+            hipLaunchKernelGGL(gen_dense_kernel, grid1((size_t)total, 256), dim3(256), 0, st, a, b, c, blob + woff[l],
+                               blob + boff[l], dst, M, L.in_dim, L.out_dim, ld, L.relu);
+            HIP_TRY(hipGetLastError());
+        }
+        a = GenSeg{dst, nullptr, ld, L.out_dim};
+        b = c = none;
+    }
+    return GNNCCA_OK;
+}
+
+static int forward_generic(const gnncca_mpn_dims* d, const void* packed_dev, const float* x, const int64_t* edge_index,
+                           const float* edge_attr, int64_t n_nodes, int64_t n_edges, void* workspace, size_t workspace_bytes,
+                           float* logits_out, const gnncca_trace* trace, hipStream_t st) {
+    const GenWorkspace ws = carve_generic(d, n_nodes, n_edges);
+    if (workspace_bytes < ws.total) return GNNCCA_ERR_WORKSPACE;
+    GenBlobHeader hdr;
+    if (!gen_blob_header(d, &hdr)) return GNNCCA_ERR_UNSUPPORTED;
+    const float* blob = static_cast<const float*>(packed_dev);
+    char* base = static_cast<char*>(workspace);
+    const int N = (int)n_nodes, E = (int)n_edges;
+    const int H = d->node_dim, EF = d->edge_dim;
+    unsigned* flags = reinterpret_cast<unsigned*>(base + ws.flags);
+    unsigned* blockflags = reinterpret_cast<unsigned*>(base + ws.blockflags);
+    int* seg_ptr = reinterpret_cast<int*>(base + ws.seg_ptr);
+    int* col32 = reinterpret_cast<int*>(base + ws.col32);
+    int* perm = reinterpret_cast<int*>(base + ws.perm);
+    int* cursor = reinterpret_cast<int*>(base + ws.cursor);
+    int* row32o = reinterpret_cast<int*>(base + ws.row32o);
+    int* col32o = reinterpret_cast<int*>(base + ws.col32o);
+    float* nb[3] = {reinterpret_cast<float*>(base + ws.node[0]), reinterpret_cast<float*>(base + ws.node[1]),
+                    reinterpret_cast<float*>(base + ws.node[2])};
+    // edge scratch: eb[0], eb[1] are layer temporaries; eb[2] / eb[3] alternate between "latent edge features" and
+    // "per-edge messages" so that no launch reads and writes the same buffer
+    float* eb[4] = {reinterpret_cast<float*>(base + ws.edge[0]), reinterpret_cast<float*>(base + ws.edge[1]),
+                    reinterpret_cast<float*>(base + ws.edge[2]), reinterpret_cast<float*>(base + ws.edge[3])};
+    float* h0 = reinterpret_cast<float*>(base + ws.h0);
+    float* e0 = reinterpret_cast<float*>(base + ws.e0);
+    const int nw = (int)ws.node_w, ew = (int)ws.edge_w;
+    const GenSeg none = {nullptr, nullptr, 0, 0};
+    const long long* ei = reinterpret_cast<const long long*>(edge_index);
+
+    // graph plan (same kernels as the MFMA family: plan blocks, then one finishing workgroup)
+    if (E > 0) {
+        EncPlanParams ep;
+        std::memset(&ep, 0, sizeof(ep));
+        ep.ei = ei;
+        ep.seg_ptr = seg_ptr;
+        ep.col32 = col32;
+        ep.blockflags = blockflags;
+        ep.E = E;
+        ep.N = N;
+        hipLaunchKernelGGL(enc_gemm_plan_kernel, dim3((E + 255) / 256), dim3(256), 0, st, ep);
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(gen_index32_kernel, dim3((E + 255) / 256), dim3(256), 0, st, ei, E, N, row32o, col32o);
+        HIP_TRY(hipGetLastError());
+    }
+    hipLaunchKernelGGL(gen_plan_finish_kernel, dim3(1), dim3(256), 0, st, ei, E, N, seg_ptr, col32, perm, cursor, flags,
+                       (const unsigned*)blockflags);
+    HIP_TRY(hipGetLastError());
+
+    // encoder (models/mpn.py:270): node MLP on x, edge MLP on edge_attr
+    int s;
+    if (d->enc_node.n_layers > 0) {
+        s = gen_run_mlp(d->enc_node, blob, hdr.w[0], hdr.b[0], GenSeg{x, nullptr, d->node_in, d->node_in}, none, none, N, h0, H,
+                        nb[0], nb[1], nw, st);
+        if (s != GNNCCA_OK) return s;
+    } else {
+        HIP_TRY(hipMemcpyAsync(h0, x, (size_t)N * H * sizeof(float), hipMemcpyDeviceToDevice, st));
+    }
+    if (trace && trace->h_enc) HIP_TRY(hipMemcpyAsync(trace->h_enc, h0, (size_t)N * H * 4, hipMemcpyDeviceToDevice, st));
+    if (E == 0) return GNNCCA_OK;
+    if (d->enc_edge.n_layers > 0) {
+        s = gen_run_mlp(d->enc_edge, blob, hdr.w[1], hdr.b[1], GenSeg{edge_attr, nullptr, d->edge_in, d->edge_in}, none, none, E,
+                        e0, EF, eb[0], eb[1], ew, st);
+        if (s != GNNCCA_OK) return s;
+    } else {
+        HIP_TRY(hipMemcpyAsync(e0, edge_attr, (size_t)E * EF * sizeof(float), hipMemcpyDeviceToDevice, st));
+    }
+    if (trace && trace->e_enc) HIP_TRY(hipMemcpyAsync(trace->e_enc, e0, (size_t)E * EF * 4, hipMemcpyDeviceToDevice, st));
+
+    const int L = d->num_enc_steps, first_cls = L - d->num_class_steps + 1;
+    const float* h_cur = h0;  // latent node feats (== initial before step 1); every h buffer is dense [N][H]
+    const float* e_cur = e0;  // latent edge feats (== initial before step 1)
+    int e_ld = EF;
+    float* h_lat[2] = {nb[2], nb[0]};
+    int out_idx = 0;
+    auto classify_edges = [&](const float* ee, int ld) -> int {
+        float* dst = logits_out + (size_t)(out_idx++) * E;
+        int r = gen_run_mlp(d->cls_edge, blob, hdr.w[4], hdr.b[4], GenSeg{ee, nullptr, ld, EF}, none, none, E, dst, 1, eb[0],
+                            eb[1], ew, st);
+        if (r != GNNCCA_OK) return r;
+        hipLaunchKernelGGL(gen_poison_kernel, grid1((size_t)E, 256), dim3(256), 0, st, dst, (long long)E, (const unsigned*)flags);
+        return hipGetLastError() == hipSuccess ? GNNCCA_OK : GNNCCA_ERR_HIP;
+    };
+    if (L == 0) return classify_edges(e0, EF);
+    for (int step = 1; step <= L; ++step) {
+        float* e_new = eb[2 + (step & 1)];        // this step's latent edge features
+        float* msg = eb[2 + ((step + 1) & 1)];    // this step's per-edge messages (the previous latent is dead by then)
+        // x = cat(initial, latent) when reattach_initial_nodes (models/mpn.py:285): materialised in nb[1]
+        const float* hin = h_cur;
+        int hin_w = H, hin_ld = H;
+        if (d->reattach_nodes) {
+            float* cat = nb[1];
+            HIP_TRY(hipMemcpy2DAsync(cat, (size_t)nw * 4, h0, (size_t)H * 4, (size_t)H * 4, N, hipMemcpyDeviceToDevice, st));
+            HIP_TRY(hipMemcpy2DAsync(cat + H, (size_t)nw * 4, h_cur, (size_t)H * 4, (size_t)H * 4, N, hipMemcpyDeviceToDevice, st));
+            hin = cat;
+            hin_w = 2 * H;
+            hin_ld = nw;
+        }
+        // e = cat(initial, latent) when reattach_initial_edges (models/mpn.py:283): materialised in eb[0]
+        const float* ein = e_cur;
+        int ein_w = EF, ein_ld = e_ld;
+        float* tmp_a = eb[0];
+        float* tmp_b = eb[1];
+        if (d->reattach_edges) {
+            HIP_TRY(hipMemcpy2DAsync(eb[0], (size_t)ew * 4, e0, (size_t)EF * 4, (size_t)EF * 4, E, hipMemcpyDeviceToDevice, st));
+            HIP_TRY(hipMemcpy2DAsync(eb[0] + EF, (size_t)ew * 4, e_cur, (size_t)e_ld * 4, (size_t)EF * 4, E,
+                                     hipMemcpyDeviceToDevice, st));
+            ein = eb[0];
+            ein_w = 2 * EF;
+            ein_ld = ew;
+            std::swap(tmp_a, tmp_b);  // layer 0 reads eb[0]: its output must go to eb[1]
+        }
+        // edge update: edge_mlp(cat[x[row], x[col], e])   (models/mpn.py:48, 68-69)
+        s = gen_run_mlp(d->edge_mlp, blob, hdr.w[2], hdr.b[2], GenSeg{hin, row32o, hin_ld, hin_w},
+                        GenSeg{hin, col32o, hin_ld, hin_w}, GenSeg{ein, nullptr, ein_ld, ein_w}, E, e_new, ew, tmp_a, tmp_b, ew,
+                        st);
+        if (s != GNNCCA_OK) return s;
+        e_cur = e_new;
+        e_ld = ew;
+        if (trace && trace->e_steps)
+            HIP_TRY(hipMemcpy2DAsync(trace->e_steps + (size_t)(step - 1) * E * EF, (size_t)EF * 4, e_new, (size_t)ew * 4,
+                                     (size_t)EF * 4, E, hipMemcpyDeviceToDevice, st));
+        // node update: aggregate over `row` of node_mlp(cat[x[row], e'])   (models/mpn.py:97-99)
+        const bool need_h = step < L || (trace && trace->h_steps);
+        if (need_h) {
+            s = gen_run_mlp(d->node_mlp, blob, hdr.w[3], hdr.b[3], GenSeg{hin, row32o, hin_ld, hin_w},
+                            GenSeg{e_new, nullptr, ew, EF}, none, E, msg, H, eb[0], eb[1], ew, st);
+            if (s != GNNCCA_OK) return s;
+            float* hn = h_lat[step & 1];
+            hipLaunchKernelGGL(gen_aggregate_kernel, grid1((size_t)N * H, 256), dim3(256), 0, st, (const float*)msg,
+                               (const int*)seg_ptr, (const int*)perm, (const unsigned*)flags, hn, N, H, d->agg);
+            HIP_TRY(hipGetLastError());
+            h_cur = hn;
+            if (trace && trace->h_steps)
+                HIP_TRY(hipMemcpyAsync(trace->h_steps + (size_t)(step - 1) * N * H, hn, (size_t)N * H * 4,
+                                       hipMemcpyDeviceToDevice, st));
+        }
+        if (step >= first_cls) {
+            s = classify_edges(e_new, ew);
+            if (s != GNNCCA_OK) return s;
+        }
+    }
+    return GNNCCA_OK;
+}
+
+
+}  // namespace gnncca

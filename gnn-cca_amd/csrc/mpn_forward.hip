@@ -1,0 +1,312 @@
+// mpn_kernels.hip -- gfx950 (MI355X / CDNA4) kernels and the C-ABI forward of the GNN-CCA message-passing path.
+//
+// Algebra (derived from models/mpn.py:48,68-69,97-99): with the edge-MLP weight split by the
+// cat order [x[row] | x[col] | e] and the node-MLP weight by [x[row] | e'],
+//     P_src = h W_src^T + b_e,  P_dst = h W_dst^T,  Q = h W_nx^T + b_n            (per node, tiny)
+//     e'[k] = ReLU(P_src[row k] + P_dst[col k] + W_ee e[k])                         (per edge, VALU)
+//     m[k]  = ReLU(Q[row k] + W_ne e'[k])                                           (per edge, MFMA 32x32x2 f32)
+//     h'[i] = agg_{k : row k = i} m[k]                                              (in-register, per segment)
+// so no [E,70] / [E,38] concatenation is ever materialised.  The aggregation index is `row` (the SOURCE node),
+// exactly as the reference does it (mpn.py:99).
+//
+// Data layout in HBM (all fp32):
+//   edge state   e      : 6 feature planes [6][E_pad]  in ROW-SORTED edge order  -> coalesced 256-B wave loads
+//   gather table Pd     : [N][8]   (P_dst, 32-B rows)                             -> L1/L2-resident random reads
+//   segment table PsQ   : [N][40]  (P_src | pad | Q)                              -> wave-uniform reads
+//   topology     seg_ptr: [N+1] int32 CSR offsets by source node;  col32 [E] int32 (sorted order)
+// One wave owns (a share of) one source node's contiguous edge segment, so the per-destination reduction needs
+// no atomics and is bitwise reproducible.
+#include "common.cuh"
+#include "plan.cuh"
+#include "encoder.cuh"
+#include "step_general.cuh"
+#include "step_fast.cuh"
+#include "generic.cuh"
+
+using namespace gnncca;
+
+extern "C" {
+
+#ifdef GNNCCA_STAMPS
+__attribute__((visibility("default"))) int gnncca_debug_set_stamps(void* dev_buf) {
+    unsigned long long* p = static_cast<unsigned long long*>(dev_buf);
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &p, sizeof(p)));
+    return GNNCCA_OK;
+}
+#endif
+
+int gnncca_last_hip_error(void) { return g_last_hip_error; }
+
+int gnncca_read_graph_flags(const void* workspace, uint32_t* flags_out, gnncca_stream_t stream) {
+    if (!workspace || !flags_out) return GNNCCA_ERR_INVALID_ARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    HIP_TRY(hipMemcpyAsync(flags_out, workspace, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return GNNCCA_OK;
+}
+
+}  // extern "C"
+
+static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const float* x, const int64_t* edge_index,
+                        const float* edge_attr, int64_t n_nodes, int64_t n_edges, void* workspace, size_t workspace_bytes,
+                        float* logits_out, const gnncca_trace* trace, gnncca_stream_t stream, Profiler* prof) {
+    if (!dims_valid(d) || n_nodes < 0 || n_edges < 0) return GNNCCA_ERR_INVALID_ARG;
+    const Family fam = classify(d);
+    if (fam == kFamilyNone) return GNNCCA_ERR_UNSUPPORTED;
+    if (n_nodes >= (1ll << 31) - 64 || n_edges >= (1ll << 31) - 64) return GNNCCA_ERR_UNSUPPORTED;
+    if (n_nodes == 0) return n_edges == 0 ? GNNCCA_OK : GNNCCA_ERR_INVALID_ARG;
+    if (!packed_dev || !x || !workspace) return GNNCCA_ERR_INVALID_ARG;
+    if (n_edges > 0 && (!edge_index || !edge_attr || !logits_out)) return GNNCCA_ERR_INVALID_ARG;
+    if (fam == kFamilyGeneric)
+        return forward_generic(d, packed_dev, x, edge_index, edge_attr, n_nodes, n_edges, workspace, workspace_bytes,
+                               logits_out, trace, static_cast<hipStream_t>(stream));
+    const Workspace ws = carve(d, n_nodes, n_edges);
+    if (workspace_bytes < ws.total) return GNNCCA_ERR_WORKSPACE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    char* base = static_cast<char*>(workspace);
+    const int N = (int)n_nodes, E = (int)n_edges;
+    const float* blob = static_cast<const float*>(packed_dev);
+
+    // The blob header is a pure function of dims: recompute it on the host instead of reading it back.
+    BlobHeader hdr;
+    if (!blob_header(d, &hdr)) return GNNCCA_ERR_UNSUPPORTED;
+
+    unsigned* flags = reinterpret_cast<unsigned*>(base + ws.flags);
+    int* seg_ptr = reinterpret_cast<int*>(base + ws.seg_ptr);
+    int* col32 = reinterpret_cast<int*>(base + ws.col32);
+    int* perm = reinterpret_cast<int*>(base + ws.perm);
+    int* cursor = reinterpret_cast<int*>(base + ws.cursor);
+    unsigned* blockflags = reinterpret_cast<unsigned*>(base + ws.blockflags);
+    float* h0 = reinterpret_cast<float*>(base + ws.h0);
+    float* act = reinterpret_cast<float*>(base + ws.act);
+    float* part = reinterpret_cast<float*>(base + ws.partial);
+    float* pd[2] = {reinterpret_cast<float*>(base + ws.pd[0]), reinterpret_cast<float*>(base + ws.pd[1])};
+    float* psq[2] = {reinterpret_cast<float*>(base + ws.psq[0]), reinterpret_cast<float*>(base + ws.psq[1])};
+    float* ebuf = reinterpret_cast<float*>(base + ws.e);
+    float* e0buf = reinterpret_cast<float*>(base + ws.e0);
+
+    // ---- node encoder -------------------------------------------------------------------------------------
+    const int nl = d->enc_node.n_layers;
+    const int n_gemm = nl == 1 ? 1 : nl - 1;
+    const float* cur_in = x;
+    int ks_last = 1;
+    for (int g = 0; g < n_gemm; ++g) {
+        const gnncca_layer& l = d->enc_node.layers[g];
+        const int K = l.in_dim, O = l.out_dim;
+        const int ks = g == 0 ? ws.ksplit : 1;
+        int kslice = (K + ks - 1) / ks;
+        kslice = (kslice + 63) / 64 * 64;
+        const bool split = g == 0 && hdr.enc_w3 != 0 && N >= 4096 && (reinterpret_cast<uintptr_t>(cur_in) & 15) == 0;
+        EncPlanParams ep;
+        std::memset(&ep, 0, sizeof(ep));
+        ep.in = cur_in;
+        ep.W = blob + hdr.enc_node_w[g];
+        ep.part = part;
+        ep.M = N;
+        ep.K = K;
+        ep.O = O;
+        ep.kslice = kslice;
+        ep.vec_ok = (K % 4 == 0) && ((reinterpret_cast<uintptr_t>(cur_in) & 15) == 0);
+        ep.nrt = (N + 31) / 32;
+        ep.nks = ks;
+        ep.gemm_blocks = split ? 0 : ep.nrt * ks * ((O + 127) / 128);
+        int ks_split = 1;
+        if (split) {  // big batches: split-bf16 MFMA GEMM; the plan gets its own launch
+            const unsigned short* w3 = reinterpret_cast<const unsigned short*>(blob + hdr.enc_w3);
+            if (N >= 32768) {  // 128-row workgroups: the weight tile is amortised over twice the rows
+                hipLaunchKernelGGL((enc_gemm_split_kernel<64>), dim3((N + 127) / 128, 1), dim3(256), 0, st, cur_in, w3, part, N,
+                                   K, O, K);
+            } else {           // 64-row workgroups + split-K so that >= 512 workgroups are in flight
+                while (ks_split < ws.ksplit && ((N + 63) / 64) * ks_split < 512 && (K / (ks_split * 2)) % 32 == 0) ks_split *= 2;
+                hipLaunchKernelGGL((enc_gemm_split_kernel<32>), dim3((N + 63) / 64, ks_split), dim3(256), 0, st, cur_in, w3,
+                                   part, N, K, O, K / ks_split);
+            }
+            HIP_TRY(hipGetLastError());
+            PROF_MARK(GNNCCA_K_ENC_GEMM);
+        }
+        int plan_blocks = 0;
+        if (g == 0 && E > 0) {  // the graph plan rides in the first GEMM launch
+            ep.ei = reinterpret_cast<const long long*>(edge_index);
+            ep.seg_ptr = seg_ptr;
+            ep.col32 = col32;
+            ep.blockflags = blockflags;
+            ep.E = E;
+            ep.N = N;
+            plan_blocks = (E + 255) / 256;
+        }
+        if (ep.gemm_blocks + plan_blocks > 0) {
+            hipLaunchKernelGGL(enc_gemm_plan_kernel, dim3(ep.gemm_blocks + plan_blocks), dim3(256), 0, st, ep);
+            HIP_TRY(hipGetLastError());
+            PROF_MARK(split ? GNNCCA_K_PLAN_ROWS : GNNCCA_K_ENC_GEMM);
+        }
+        ks_last = split ? ks_split : ks;
+        if (g < n_gemm - 1) {
+            float* dst = act + (size_t)(g & 1) * N * O;
+            hipLaunchKernelGGL(reduce_bias_act_kernel, grid1((size_t)N * O, 256), dim3(256), 0, st, (const float*)part,
+                               blob + hdr.enc_node_b[g], dst, N, O, ks, l.relu);
+            HIP_TRY(hipGetLastError());
+            PROF_MARK(GNNCCA_K_ENC_REDUCE);
+            cur_in = dst;
+        }
+    }
+    const int nf = d->reattach_nodes ? 2 : 1;
+    const int hin = nf * kH;
+    {
+        const gnncca_layer& lprev = d->enc_node.layers[n_gemm - 1];
+        TailParams tp;
+        std::memset(&tp, 0, sizeof(tp));
+        tp.blob = blob;
+        tp.part = part;
+        tp.h0 = h0;
+        tp.trace_h = trace ? trace->h_enc : nullptr;
+        tp.pd_out = pd[0];
+        tp.psq_out = psq[0];
+        tp.off_prev_b = hdr.enc_node_b[n_gemm - 1];
+        tp.off_lastWT = hdr.enc_last_wT;
+        tp.off_last_b = hdr.enc_node_b[nl - 1];
+        tp.off_projwT = hdr.proj_wT;
+        tp.off_projb = hdr.proj_b;
+        tp.ks = ks_last;
+        tp.F = lprev.out_dim;
+        tp.N = N;
+        tp.has_last = nl >= 2;
+        tp.relu_prev = lprev.relu;
+        tp.reatt_n = d->reattach_nodes;
+        tp.hin = hin;
+        tp.vec_reduce = (tp.F % 4 == 0) && (tp.F / 4 <= 64) && (64 % (tp.F / 4) == 0);
+        const size_t lds = ((size_t)hin * kProjOut + (tp.has_last ? (size_t)tp.F * kH : 0) + 4 * (size_t)tp.F + 4 * 256) * sizeof(float);
+        if (lds > 160 * 1024) return GNNCCA_ERR_UNSUPPORTED;
+        if (lds > 64 * 1024)
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(enc_tail_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        tp.ei = reinterpret_cast<const long long*>(edge_index);
+        tp.seg_ptr = seg_ptr;
+        tp.col32 = col32;
+        tp.perm = perm;
+        tp.cursor = cursor;
+        tp.flags = flags;
+        tp.blockflags = blockflags;
+        tp.E = E;
+        const unsigned blocks = (unsigned)std::min<size_t>(((size_t)N + 3) / 4, 2048) + 1;  // + plan-repair workgroup
+        hipLaunchKernelGGL(enc_tail_kernel, dim3(blocks), dim3(256), std::max<size_t>(lds, 4096), st, tp);
+        HIP_TRY(hipGetLastError());
+        PROF_MARK(GNNCCA_K_ENC_TAIL);
+    }
+    if (E == 0) return GNNCCA_OK;
+
+    // ---- message passing steps ----------------------------------------------------------------------------
+    const int L = d->num_enc_steps;
+    const int first_cls = L - d->num_class_steps + 1;  // models/mpn.py:277
+    const long long avg_deg = (E + (long long)N - 1) / N;
+    const int chunks = (int)((avg_deg + 63) / 64);
+    StepParams sp;
+    std::memset(&sp, 0, sizeof(sp));
+    sp.blob = blob;
+    sp.seg_ptr = seg_ptr;
+    sp.col32 = col32;
+    sp.perm = perm;
+    sp.flags = flags;
+    sp.edge_attr = edge_attr;
+    sp.e = ebuf;
+    sp.e0 = e0buf;
+    sp.h0 = h0;
+    sp.e_stride = ws.e_stride;
+    sp.off_wee = hdr.wee;
+    sp.off_wneb = hdr.wne_b;
+    sp.off_projwT = hdr.proj_wT;
+    sp.off_projb = hdr.proj_b;
+    sp.off_encw = hdr.enc_edge_w;
+    sp.off_encb = hdr.enc_edge_b;
+    sp.off_cw1 = hdr.cls_w1;
+    sp.off_cb1 = hdr.cls_b1;
+    sp.off_cw2 = hdr.cls_w2;
+    sp.off_cb2 = hdr.cls_b2;
+    sp.off_fast = hdr.fast_consts;
+    sp.cls_hidden = hdr.cls_hidden;
+    sp.N = N;
+    sp.E = E;
+    sp.edge_in = d->edge_in;
+    sp.attr_vec = d->edge_in == 4 && (reinterpret_cast<uintptr_t>(edge_attr) & 15) == 0;
+    sp.agg = d->agg;
+    sp.reatt_n = d->reattach_nodes;
+    // waves per source-node segment: split a segment over 2 or 4 waves only while that is needed to put ~4 waves on
+    // every SIMD (small graphs are latency-bound); big batches keep one wave per node, which amortises the
+    // per-node prologue / projection epilogue over all of the node's chunks
+    {
+        const long long want = 4096 / (long long)N;  // waves per node that would fill the chip
+        int wps = chunks >= 4 ? 4 : (chunks >= 2 ? 2 : 1);
+        while (wps > 1 && wps > want) wps >>= 1;
+        sp.wps = wps;
+    }
+    sp.hin = hin;
+    sp.pd_lds = (N <= 1024) && d->num_enc_steps > 0;
+    const bool re = d->reattach_edges != 0;
+    int out_idx = 0;
+    if (L == 0) {  // models/mpn.py:295-297: classify the encoded edge features once
+        sp.first = 1;
+        sp.update = 0;
+        sp.cls_layers = hdr.cls_layers;
+        sp.logits = logits_out;
+        sp.trace_e_enc = trace ? trace->e_enc : nullptr;
+        HIP_TRY(re ? (launch_step<true, false>(sp, st)) : (launch_step<false, false>(sp, st)));
+        PROF_MARK(GNNCCA_K_STEP_LAST);
+        return GNNCCA_OK;
+    }
+    for (int step = 1; step <= L; ++step) {
+        const bool want_h = trace && trace->h_steps;
+        const bool msg = step < L || want_h;
+        sp.first = step == 1;
+        sp.stamp_slot = 2 + (step - 1 < 6 ? step - 1 : 5);
+        sp.update = 1;
+        sp.store_e = step < L;
+        sp.cls_layers = step >= first_cls ? hdr.cls_layers : 0;
+        sp.logits = step >= first_cls ? logits_out + (size_t)(out_idx++) * E : nullptr;
+        sp.pd_in = pd[(step - 1) & 1];
+        sp.psq_in = psq[(step - 1) & 1];
+        sp.pd_out = step < L ? pd[step & 1] : nullptr;
+        sp.psq_out = step < L ? psq[step & 1] : nullptr;
+        sp.trace_e_enc = (trace && step == 1) ? trace->e_enc : nullptr;
+        sp.trace_e = (trace && trace->e_steps) ? trace->e_steps + (size_t)(step - 1) * E * kEF : nullptr;
+        sp.trace_h = want_h ? trace->h_steps + (size_t)(step - 1) * N * kH : nullptr;
+        hipError_t err;
+        const bool fast = hdr.fast_consts != 0 && sp.attr_vec && !trace && d->agg != GNNCCA_AGG_MAX;
+        if (fast)
+            err = launch_fast_dispatch(sp, msg, st);
+        else if (re)
+            err = msg ? launch_step<true, true>(sp, st) : launch_step<true, false>(sp, st);
+        else
+            err = msg ? launch_step<false, true>(sp, st) : launch_step<false, false>(sp, st);
+        HIP_TRY(err);
+        PROF_MARK(msg ? GNNCCA_K_STEP : GNNCCA_K_STEP_LAST);
+    }
+    return GNNCCA_OK;
+}
+
+extern "C" {
+
+int gnncca_mpn_forward(const gnncca_mpn_dims* d, const void* packed_dev, const float* x, const int64_t* edge_index,
+                       const float* edge_attr, int64_t n_nodes, int64_t n_edges, void* workspace, size_t workspace_bytes,
+                       float* logits_out, const gnncca_trace* trace, gnncca_stream_t stream) {
+    return forward_impl(d, packed_dev, x, edge_index, edge_attr, n_nodes, n_edges, workspace, workspace_bytes, logits_out,
+                        trace, stream, nullptr);
+}
+
+int gnncca_mpn_forward_profiled(const gnncca_mpn_dims* d, const void* packed_dev, const float* x,
+                                const int64_t* edge_index, const float* edge_attr, int64_t n_nodes, int64_t n_edges,
+                                void* workspace, size_t workspace_bytes, float* logits_out, gnncca_stream_t stream,
+                                gnncca_profile* profile) {
+    if (!profile) return GNNCCA_ERR_INVALID_ARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    Profiler p;
+    p.out = profile;
+    profile->count = 0;
+    int s = prof_begin(&p, st);
+    if (s != GNNCCA_OK) return s;
+    s = forward_impl(d, packed_dev, x, edge_index, edge_attr, n_nodes, n_edges, workspace, workspace_bytes, logits_out,
+                     nullptr, stream, &p);
+    const int s2 = prof_end(&p, st);
+    return s != GNNCCA_OK ? s : s2;
+}
+
+}  // extern "C"
+

@@ -1,0 +1,267 @@
+#pragma once
+// Part of the single translation unit mpn_forward.hip (kernels share device helpers and the launch code below
+// instantiates their templates); see that file for the overall picture.
+namespace gnncca {
+
+// ------------------------------------------------------------------------------------------------------------
+// Specialised step kernel for the shipped GRAPH_NET_PARAMS shape (edge_in 4, no reattach, classifier 6->4->1 or
+// off, no debug taps): the same algorithm as mpn_step_kernel with every per-config decision made at compile
+// time, so the body is straight-line code whose loads issue back to back.  mpn_step_kernel stays as the
+// general / traced variant.
+// ------------------------------------------------------------------------------------------------------------
+template <bool FIRST, bool CLS, bool MSG, bool PD_LDS>
+__global__ __launch_bounds__(256) void mpn_step_fast_kernel(const StepParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* s_proj = smem;                                   // [32][48]   (MSG)
+    float* s_part = s_proj + (MSG ? kH * kProjOut : 0);     // [4][32]
+    float* s_pd = s_part + 4 * kH;                          // [N][8]     (PD_LDS)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const float* __restrict__ blob = p.blob;
+    // Per-step scalars (152 floats) are read through the CONSTANT address space: wave-uniform addresses there
+    // become s_load into SGPRs, which the VALU takes as operands directly -- no LDS, no VGPR copies.
+    typedef const float __attribute__((address_space(4))) cfloat;
+    cfloat* cw = (cfloat*)(unsigned long long)(blob + p.off_fast);
+
+    GNNCCA_STAMP(p.stamp_slot, 0);
+    // ---- prologue: every independent load is issued before the first wait ----------------------------------
+    const unsigned gflags = p.flags[0];
+    const int wps = p.wps;
+    const int node = blockIdx.x * (4 / wps) + wave / wps;
+    const int sub = wave % wps;
+    const bool active = node < p.N;
+    const int nclamp = active ? node : 0;
+    int seg_s = p.seg_ptr[nclamp];
+    int seg_t = p.seg_ptr[nclamp + 1];
+    const int half = lane >> 5, ch = lane & 31;
+    const float* __restrict__ psq = p.psq_in + (size_t)nclamp * kPsQStride;
+    float psrc[kEF];
+#pragma unroll
+    for (int f = 0; f < kEF; ++f) psrc[f] = psq[f];
+    float cinit = 0.f;
+    float bw[3] = {0.f, 0.f, 0.f};
+    f32x4 stage_proj[2];
+    f32x4 stage_pd[8];
+    float projb_l = 0.f;
+    if (MSG) {
+        cinit = psq[8 + ch];
+        projb_l = blob[p.off_projb + min(lane, kProjOut - 1)];
+#pragma unroll
+        for (int s = 0; s < 3; ++s) bw[s] = blob[p.off_wneb + s * 64 + lane];
+        const f32x4* __restrict__ g4 = reinterpret_cast<const f32x4*>(blob + p.off_projwT);
+        stage_proj[0] = g4[tid];                                   // 384 float4 in all
+        stage_proj[1] = g4[min(tid + 256, kH * kProjOut / 4 - 1)];
+    }
+    const int pd_n4 = p.N * (kPdStride / 4);
+    if (PD_LDS) {  // N <= 1024: at most 8 float4 per thread
+        const f32x4* __restrict__ g4 = reinterpret_cast<const f32x4*>(p.pd_in);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) stage_pd[i] = g4[min(tid + i * 256, pd_n4 - 1)];
+    }
+    if (MSG) {
+        f32x4* l4 = reinterpret_cast<f32x4*>(s_proj);
+        l4[tid] = stage_proj[0];
+        if (tid + 256 < kH * kProjOut / 4) l4[tid + 256] = stage_proj[1];
+    }
+    if (PD_LDS) {
+        f32x4* l4 = reinterpret_cast<f32x4*>(s_pd);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (tid + i * 256 < pd_n4) l4[tid + i * 256] = stage_pd[i];
+    }
+    if (gflags & GNNCCA_GRAPH_BAD_INDEX) {
+        if (CLS)
+            for (size_t k = (size_t)blockIdx.x * 256 + tid; k < (size_t)p.E; k += (size_t)gridDim.x * 256)
+                p.logits[k] = __builtin_nanf("");
+        return;
+    }
+    const bool unsorted = (gflags & GNNCCA_GRAPH_UNSORTED) != 0;
+    GNNCCA_STAMP(p.stamp_slot, 1);
+    if (MSG || PD_LDS) __syncthreads();
+    GNNCCA_STAMP(p.stamp_slot, 2);
+    if (!active) seg_s = seg_t = 0;
+
+    f32x16 acc;  // 'sum' / 'mean' only: 'max' takes the general kernel
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    const int last = seg_t - 1;
+
+    struct Chunk {
+        float raw[kEF];
+        float pd[kEF];
+        int ko;
+    };
+    auto load_chunk = [&](int base, Chunk& c) {
+        const int kk = min(base + lane, last);
+        c.ko = unsorted ? p.perm[kk] : kk;
+        const int j = p.col32[kk];
+        if (FIRST) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(p.edge_attr + (size_t)c.ko * 4);
+            c.raw[0] = a[0], c.raw[1] = a[1], c.raw[2] = a[2], c.raw[3] = a[3], c.raw[4] = 0.f, c.raw[5] = 0.f;
+        } else {
+#pragma unroll
+            for (int f = 0; f < kEF; ++f) c.raw[f] = p.e[(size_t)f * p.e_stride + kk];
+        }
+        f32x4 a;
+        f32x2 b2;
+        if (PD_LDS) {
+            a = *reinterpret_cast<const f32x4*>(s_pd + j * kPdStride);
+            b2 = *reinterpret_cast<const f32x2*>(s_pd + j * kPdStride + 4);
+        } else {
+            const float* __restrict__ pdj = p.pd_in + (size_t)j * kPdStride;
+            a = *reinterpret_cast<const f32x4*>(pdj);
+            b2 = *reinterpret_cast<const f32x2*>(pdj + 4);
+        }
+        c.pd[0] = a[0], c.pd[1] = a[1], c.pd[2] = a[2], c.pd[3] = a[3], c.pd[4] = b2[0], c.pd[5] = b2[1];
+    };
+    auto compute_chunk = [&](int base, const Chunk& c) {
+        const int k = base + lane;
+        const bool valid = k < seg_t;
+        float ein[kEF];
+        if (FIRST) {
+#pragma unroll
+            for (int f = 0; f < kEF; ++f) {
+                float s = cw[kFcEncB + f];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) s = fmaf(cw[kFcEncW + f * 4 + q], c.raw[q], s);
+                ein[f] = fmaxf(s, 0.f);
+            }
+        } else {
+#pragma unroll
+            for (int f = 0; f < kEF; ++f) ein[f] = c.raw[f];
+        }
+        float en[kEF];
+#pragma unroll
+        for (int f = 0; f < kEF; ++f) {
+            float s = psrc[f] + c.pd[f];
+#pragma unroll
+            for (int g = 0; g < kEF; ++g) s = fmaf(cw[kFcWee + f * kEF + g], ein[g], s);
+            en[f] = fmaxf(s, 0.f);
+        }
+        if (p.store_e && valid) {
+#pragma unroll
+            for (int f = 0; f < kEF; ++f) p.e[(size_t)f * p.e_stride + k] = en[f];
+        }
+        if (CLS) {
+            float logit = cw[kFcCb2];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float z = cw[kFcCb1 + q];
+#pragma unroll
+                for (int f = 0; f < kEF; ++f) z = fmaf(cw[kFcCw1 + q * kEF + f], en[f], z);
+                logit = fmaf(cw[kFcCw2 + q], fmaxf(z, 0.f), logit);
+            }
+            if (valid) p.logits[c.ko] = logit;
+        }
+        if (MSG) {
+            f32x16 d0, d1;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) d0[i] = d1[i] = cinit;
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(en[2 * s]), __float_as_uint(en[2 * s + 1]),
+                                                                false, false);
+                d0 = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(r[0]), bw[s], d0, 0, 0, 0);
+                d1 = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(r[1]), bw[s], d1, 0, 0, 0);
+            }
+            if (base + 64 <= seg_t) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[i] += fmaxf(d0[i], 0.f) + fmaxf(d1[i], 0.f);
+            } else {
+                const int rem = seg_t - base - 4 * half;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int eo = (i & 3) + 8 * (i >> 2);
+                    const float m0 = (eo < rem) ? fmaxf(d0[i], 0.f) : 0.f;
+                    const float m1 = (eo + 32 < rem) ? fmaxf(d1[i], 0.f) : 0.f;
+                    acc[i] += m0 + m1;
+                }
+            }
+        }
+    };
+
+    // Two chunks (128 edges, 3.6 KB of loads) are requested before the first one is consumed.
+    const int stride = 64 * wps;
+    for (int base = seg_s + 64 * sub; base < seg_t; base += 2 * stride) {
+        Chunk c0, c1;
+        const bool two = base + stride < seg_t;
+        load_chunk(base, c0);
+        if (two) load_chunk(base + stride, c1);
+        GNNCCA_STAMP(p.stamp_slot, 3);
+        compute_chunk(base, c0);
+        if (two) compute_chunk(base + stride, c1);
+        GNNCCA_STAMP(p.stamp_slot, 4);
+    }
+    GNNCCA_STAMP(p.stamp_slot, 5);
+
+    if (MSG) {
+        float v = acc[0];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) v += acc[i];
+        v += __shfl_xor(v, 32);
+        if (wps > 1) {
+            if (lane < kH) s_part[wave * kH + lane] = v;
+            __syncthreads();
+            if (sub == 0) {
+                v = s_part[wave * kH + ch];
+                for (int u = 1; u < wps; ++u) v += s_part[(wave + u) * kH + ch];
+            }
+        }
+        GNNCCA_STAMP(p.stamp_slot, 6);
+        if (active && sub == 0) {
+            const int deg = seg_t - seg_s;
+            if (p.agg == GNNCCA_AGG_MEAN) v = v / (float)max(deg, 1);
+            if (deg == 0) v = 0.f;
+            // projection epilogue (project_node with the bias read through the constant address space)
+            const int o = min(lane, kProjOut - 1);
+            float pr = projb_l;
+            const float* w = s_proj + o;
+#pragma unroll
+            for (int c = 0; c < kH; ++c)
+                pr = fmaf(w[c * kProjOut], __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), c)), pr);
+            if (lane < kPdStride)
+                p.pd_out[(size_t)node * kPdStride + lane] = pr;
+            else if (lane < kProjOut)
+                p.psq_out[(size_t)node * kPsQStride + lane - kPdStride] = pr;
+        }
+    }
+    GNNCCA_STAMP(p.stamp_slot, 7);
+}
+
+template <bool FIRST, bool CLS, bool MSG, bool PDL>
+static hipError_t launch_fast(const StepParams& sp, hipStream_t st) {
+    const int npg = 4 / sp.wps;
+    const unsigned blocks = (unsigned)((sp.N + npg - 1) / npg);
+    const size_t lds = ((MSG ? (size_t)kH * kProjOut : 0) + 4 * kH + (PDL ? (size_t)sp.N * kPdStride : 0)) * sizeof(float);
+    hipLaunchKernelGGL((mpn_step_fast_kernel<FIRST, CLS, MSG, PDL>), dim3(blocks), dim3(256), lds, st, sp);
+    return hipGetLastError();
+}
+
+static hipError_t launch_fast_dispatch(const StepParams& sp, bool msg, hipStream_t st) {
+    const int key = (sp.first ? 8 : 0) | (sp.cls_layers ? 4 : 0) | (msg ? 2 : 0) | (sp.pd_lds ? 1 : 0);
+    switch (key) {
+#define GNNCCA_FAST_CASE(K, A, B, C, D) \
+    case K: return launch_fast<A, B, C, D>(sp, st);
+        GNNCCA_FAST_CASE(0, false, false, false, false)
+        GNNCCA_FAST_CASE(1, false, false, false, true)
+        GNNCCA_FAST_CASE(2, false, false, true, false)
+        GNNCCA_FAST_CASE(3, false, false, true, true)
+        GNNCCA_FAST_CASE(4, false, true, false, false)
+        GNNCCA_FAST_CASE(5, false, true, false, true)
+        GNNCCA_FAST_CASE(6, false, true, true, false)
+        GNNCCA_FAST_CASE(7, false, true, true, true)
+        GNNCCA_FAST_CASE(8, true, false, false, false)
+        GNNCCA_FAST_CASE(9, true, false, false, true)
+        GNNCCA_FAST_CASE(10, true, false, true, false)
+        GNNCCA_FAST_CASE(11, true, false, true, true)
+        GNNCCA_FAST_CASE(12, true, true, false, false)
+        GNNCCA_FAST_CASE(13, true, true, false, true)
+        GNNCCA_FAST_CASE(14, true, true, true, false)
+        GNNCCA_FAST_CASE(15, true, true, true, true)
+#undef GNNCCA_FAST_CASE
+    }
+    return hipErrorInvalidValue;
+}
+
+
+}  // namespace gnncca
