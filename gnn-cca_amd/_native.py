@@ -64,6 +64,10 @@ _SIGNATURES = {
     "gnncca_normalize_columns": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gnncca_build_edges": (C.c_int, [C.POINTER(Frames), C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_int32,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gnncca_post_threshold": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gnncca_post_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64]),
+    "gnncca_post_prune_cluster": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_size_t,
+                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gnncca_read_graph_flags": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.c_void_p]),
 }
 

@@ -22,6 +22,7 @@
 #include "step_general.cuh"
 #include "step_fast.cuh"
 #include "generic.cuh"
+#include "postprocess.cuh"
 
 using namespace gnncca;
 
@@ -308,5 +309,83 @@ int gnncca_mpn_forward_profiled(const gnncca_mpn_dims* d, const void* packed_dev
     return s != GNNCCA_OK ? s : s2;
 }
 
-}  // extern "C"
 
+// ---- SURVEY.md 8f row N2 ------------------------------------------------------------------------------------
+size_t gnncca_post_workspace_bytes(int64_t n_nodes, int64_t n_edges) {
+    if (n_nodes < 0 || n_edges < 0) return 0;
+    const size_t N = (size_t)n_nodes, E = (size_t)n_edges;
+    auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+    return up(256) + up((E / 256 + 2) * 4) + up((N + 1) * 4) + up(E * 4) + up(E * 4) + up((N + 1) * 4);
+}
+
+int gnncca_post_threshold(const float* logits, int64_t n_edges, float* probs_out, int64_t* predictions_out,
+                          gnncca_stream_t stream) {
+    if (n_edges < 0) return GNNCCA_ERR_INVALID_ARG;
+    if (n_edges == 0) return GNNCCA_OK;
+    if (!logits || !probs_out || !predictions_out) return GNNCCA_ERR_INVALID_ARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(post_threshold_kernel, grid1((size_t)n_edges, 256), dim3(256), 0, st, logits, (long long)n_edges, probs_out,
+                       reinterpret_cast<long long*>(predictions_out));
+    HIP_TRY(hipGetLastError());
+    return GNNCCA_OK;
+}
+
+int gnncca_post_prune_cluster(const int64_t* edge_index, const int64_t* predictions, int64_t n_nodes, int64_t n_edges,
+                              void* workspace, size_t workspace_bytes, int64_t* pruned_out, int32_t* flow_out,
+                              int32_t* flow_in, int32_t* labels_out, int32_t* n_clusters_out, gnncca_stream_t stream) {
+    if (n_nodes < 0 || n_edges < 0) return GNNCCA_ERR_INVALID_ARG;
+    if (n_nodes >= (1ll << 31) - 64 || n_edges >= (1ll << 31) - 64) return GNNCCA_ERR_UNSUPPORTED;
+    if (n_nodes == 0) return GNNCCA_OK;
+    if (!workspace || !flow_out || !flow_in || !labels_out || !n_clusters_out) return GNNCCA_ERR_INVALID_ARG;
+    if (n_edges > 0 && (!edge_index || !predictions || !pruned_out)) return GNNCCA_ERR_INVALID_ARG;
+    if (workspace_bytes < gnncca_post_workspace_bytes(n_nodes, n_edges)) return GNNCCA_ERR_WORKSPACE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int N = (int)n_nodes, E = (int)n_edges;
+    auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+    char* base = static_cast<char*>(workspace);
+    unsigned* flags = reinterpret_cast<unsigned*>(base);
+    size_t off = up(256);
+    unsigned* blockflags = reinterpret_cast<unsigned*>(base + off);
+    off += up(((size_t)E / 256 + 2) * 4);
+    int* seg_ptr = reinterpret_cast<int*>(base + off);
+    off += up(((size_t)N + 1) * 4);
+    int* col32 = reinterpret_cast<int*>(base + off);
+    off += up((size_t)E * 4);
+    int* perm = reinterpret_cast<int*>(base + off);
+    off += up((size_t)E * 4);
+    int* cursor = reinterpret_cast<int*>(base + off);
+    const long long* ei = reinterpret_cast<const long long*>(edge_index);
+    const long long* pred = reinterpret_cast<const long long*>(predictions);
+    long long* pruned = reinterpret_cast<long long*>(pruned_out);
+    HIP_TRY(hipMemsetAsync(flow_out, 0, (size_t)N * 4, st));
+    HIP_TRY(hipMemsetAsync(flow_in, 0, (size_t)N * 4, st));
+    if (E > 0) {
+        EncPlanParams ep;
+        std::memset(&ep, 0, sizeof(ep));
+        ep.ei = ei;
+        ep.seg_ptr = seg_ptr;
+        ep.col32 = col32;
+        ep.blockflags = blockflags;
+        ep.E = E;
+        ep.N = N;
+        hipLaunchKernelGGL(enc_gemm_plan_kernel, dim3((E + 255) / 256), dim3(256), 0, st, ep);
+        HIP_TRY(hipGetLastError());
+    }
+    hipLaunchKernelGGL(gen_plan_finish_kernel, dim3(1), dim3(256), 0, st, ei, E, N, seg_ptr, col32, perm, cursor, flags,
+                       (const unsigned*)blockflags);
+    HIP_TRY(hipGetLastError());
+    if (E > 0) {
+        hipLaunchKernelGGL(post_prune_kernel, grid1((size_t)E, 256), dim3(256), 0, st, ei, pred, (long long)E, (const int*)seg_ptr,
+                           (const int*)col32, (const int*)perm, (const unsigned*)flags, pruned);
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(post_flow_kernel, grid1((size_t)E, 256), dim3(256), 0, st, ei, (const long long*)pruned, (long long)E, N,
+                           flow_out, flow_in);
+        HIP_TRY(hipGetLastError());
+    }
+    hipLaunchKernelGGL(post_cc_kernel, dim3(1), dim3(1024), 0, st, ei, (const long long*)pruned, (long long)E, N, labels_out,
+                       n_clusters_out);
+    HIP_TRY(hipGetLastError());
+    return GNNCCA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,96 @@
+#pragma once
+// the step right after the MPN on the GPU -- sigmoid / threshold (inference.py:286-291), pruning
+// of edges that are active in one direction only (libs/utils.py:387-404), per-node flow counts (libs/utils.py:54-59)
+// and the identity clusters of the pruned, now symmetric, edge set (libs/utils.py:295-317: strongly connected
+// components of a symmetric digraph == connected components).  The bridge-based rounding / splitting heuristics
+// (libs/utils.py:25-173, 319-386) stay on the host, as SURVEY.md 8f prescribes.
+// Part of the single translation unit mpn_forward.hip.
+namespace gnncca {
+
+__global__ __launch_bounds__(256) void post_threshold_kernel(const float* __restrict__ logits, long long E,
+                                                             float* __restrict__ probs, long long* __restrict__ preds) {
+    const long long k = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (k >= E) return;
+    const float p = 1.f / (1.f + expf(-logits[k]));  // torch.nn.Sigmoid
+    probs[k] = p;
+    preds[k] = p >= 0.5f ? 1 : 0;                    // (preds_prob >= 0.5) * 1
+}
+
+// out[k] = pred[k] && the reverse edge (col k, row k) exists and is active too.  The reverse edge is searched in the
+// CSR segment of node col[k] (plan of the MPN forward: seg_ptr / col32 / perm), any column order.
+__global__ __launch_bounds__(256) void post_prune_kernel(const long long* __restrict__ ei, const long long* __restrict__ pred,
+                                                         long long E, const int* __restrict__ seg_ptr,
+                                                         const int* __restrict__ col32, const int* __restrict__ perm,
+                                                         const unsigned* __restrict__ flags, long long* __restrict__ out) {
+    const long long k = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (k >= E) return;
+    const unsigned fl = flags[0];
+    if (fl & GNNCCA_GRAPH_BAD_INDEX) {
+        out[k] = 0;
+        return;
+    }
+    long long keep = 0;
+    if (pred[k] == 1) {
+        const bool unsorted = (fl & GNNCCA_GRAPH_UNSORTED) != 0;
+        const int i = (int)ei[k], j = (int)ei[E + k];
+        for (int q = seg_ptr[j]; q < seg_ptr[j + 1]; ++q) {
+            if (col32[q] == i && pred[unsorted ? perm[q] : q] == 1) {
+                keep = 1;
+                break;
+            }
+        }
+    }
+    out[k] = keep;
+}
+
+__global__ __launch_bounds__(256) void post_flow_kernel(const long long* __restrict__ ei, const long long* __restrict__ pred,
+                                                        long long E, int N, int* __restrict__ flow_out, int* __restrict__ flow_in) {
+    const long long k = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (k >= E || pred[k] != 1) return;
+    const long long i = ei[k], j = ei[E + k];
+    if (i < 0 || i >= N || j < 0 || j >= N) return;
+    atomicAdd(&flow_out[i], 1);  // integer counts: order-independent
+    atomicAdd(&flow_in[j], 1);
+}
+
+// Connected components of the active edges by hooking + pointer jumping inside ONE workgroup (frame graphs are small;
+// a batch is processed in one launch).  labels[v] = smallest node id of v's component.
+__global__ __launch_bounds__(1024) void post_cc_kernel(const long long* __restrict__ ei, const long long* __restrict__ pred,
+                                                       long long E, int N, int* labels, int* n_clusters) {
+    __shared__ int s_changed;
+    const int tid = threadIdx.x;
+    auto ld = [&](int v) { return __hip_atomic_load(&labels[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    for (int v = tid; v < N; v += 1024) __hip_atomic_store(&labels[v], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    for (int round = 0; round <= N; ++round) {  // terminates when a sweep hooks nothing; N bounds it
+        if (tid == 0) s_changed = 0;
+        __syncthreads();
+        for (long long k = tid; k < E; k += 1024) {
+            if (pred[k] != 1) continue;
+            const long long a = ei[k], b = ei[E + k];
+            if (a < 0 || a >= N || b < 0 || b >= N) continue;
+            int ra = (int)a, rb = (int)b;
+            for (int p = ld(ra); p != ra; p = ld(ra)) ra = p;  // find roots
+            for (int p = ld(rb); p != rb; p = ld(rb)) rb = p;
+            if (ra != rb) {
+                atomicMin(&labels[max(ra, rb)], min(ra, rb));   // hook the larger root under the smaller
+                s_changed = 1;
+            }
+        }
+        __syncthreads();
+        for (int v = tid; v < N; v += 1024) {                  // pointer jumping
+            int r = v;
+            for (int p = ld(r); p != r; p = ld(r)) r = p;
+            __hip_atomic_store(&labels[v], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        if (!s_changed) break;
+        __syncthreads();
+    }
+    if (tid == 0) *n_clusters = 0;
+    __syncthreads();
+    for (int v = tid; v < N; v += 1024)
+        if (ld(v) == v) atomicAdd(n_clusters, 1);
+}
+
+}  // namespace gnncca

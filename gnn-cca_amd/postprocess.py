@@ -1,0 +1,54 @@
+"""Row N2 of SURVEY.md 8f: the step right after the MPN on the GPU.
+
+`threshold` = inference.py:286-291 (sigmoid, >= 0.5); `prune_and_cluster` = utils.remove_edges_single_direction
+(libs/utils.py:387-404) + the flow counts of utils.compute_rounding (libs/utils.py:54-59) + the clusters
+utils.compute_SCC_and_Clusters (libs/utils.py:295-317) returns for the pruned edge set -- without the networkx /
+Python-list round trips through the host.  The bridge-based rounding and splitting heuristics are not reproduced here.
+"""
+import ctypes as C
+
+import torch
+
+from . import _native as nat
+
+
+def _stream(dev):
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+def threshold(logits):
+    """logits: Tensor[E] or [E,1] on the GPU -> (probs float32 [E], predictions int64 [E])."""
+    if not logits.is_cuda:
+        raise RuntimeError("gnn_cca_amd.postprocess runs on MI355X only (no CPU fallback)")
+    x = logits.reshape(-1).float().contiguous()
+    probs = torch.empty_like(x)
+    preds = torch.empty(x.shape[0], dtype=torch.int64, device=x.device)
+    with torch.cuda.device(x.device):
+        nat.check(nat.lib().gnncca_post_threshold(x.data_ptr(), x.shape[0], probs.data_ptr(), preds.data_ptr(),
+                                                  _stream(x.device)), "gnncca_post_threshold")
+    return probs, preds
+
+
+def prune_and_cluster(edge_index, predictions, n_nodes):
+    """-> dict(pruned int64 [E], flow_out / flow_in int32 [N], labels int32 [N] (smallest node id of the component),
+    n_clusters int32 [1] on the device)."""
+    if not (edge_index.is_cuda and predictions.is_cuda):
+        raise RuntimeError("gnn_cca_amd.postprocess runs on MI355X only (no CPU fallback)")
+    dev = edge_index.device
+    ei = edge_index.long().contiguous()
+    pred = predictions.reshape(-1).long().contiguous()
+    e = ei.shape[1]
+    lib = nat.lib()
+    ws = torch.empty(lib.gnncca_post_workspace_bytes(n_nodes, e) + 256, dtype=torch.uint8, device=dev)
+    out = {"pruned": torch.empty(e, dtype=torch.int64, device=dev),
+           "flow_out": torch.empty(n_nodes, dtype=torch.int32, device=dev),
+           "flow_in": torch.empty(n_nodes, dtype=torch.int32, device=dev),
+           "labels": torch.empty(n_nodes, dtype=torch.int32, device=dev),
+           "n_clusters": torch.zeros(1, dtype=torch.int32, device=dev)}
+    with torch.cuda.device(dev):
+        st = lib.gnncca_post_prune_cluster(ei.data_ptr(), pred.data_ptr(), n_nodes, e, ws.data_ptr(), ws.numel(),
+                                           out["pruned"].data_ptr(), out["flow_out"].data_ptr(), out["flow_in"].data_ptr(),
+                                           out["labels"].data_ptr(), out["n_clusters"].data_ptr(), _stream(dev))
+    nat.check(st, "gnncca_post_prune_cluster")
+    out["_workspace"] = ws
+    return out

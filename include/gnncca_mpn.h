@@ -180,6 +180,22 @@ GNNCCA_API int gnncca_build_edges(const gnncca_frames* frames, const float* reid
                                   int64_t n_edges, int32_t mode, int64_t* edge_index_out, float* edge_attr_out,
                                   float* edge_labels_out, gnncca_stream_t stream);
 
+/* ---- the step after the MPN -- threshold, pruning, flow counts, identity clusters --------
+ * probs = sigmoid(logits), predictions = (probs >= 0.5) as int64 0/1 (inference.py:286-291). */
+GNNCCA_API int gnncca_post_threshold(const float* logits, int64_t n_edges, float* probs_out,
+                                     int64_t* predictions_out, gnncca_stream_t stream);
+GNNCCA_API size_t gnncca_post_workspace_bytes(int64_t n_nodes, int64_t n_edges);
+/* pruned_out[k] = predictions[k] && the reverse edge is active too (utils.remove_edges_single_direction,
+ * libs/utils.py:387-404); flow_out / flow_in [N] int32 = active pruned edges leaving / entering each node
+ * (scatter_add at libs/utils.py:54-55); labels_out [N] int32 = smallest node id of the node's connected component
+ * over the pruned edges, *n_clusters_out = number of components incl. isolated nodes (the partition
+ * utils.compute_SCC_and_Clusters, libs/utils.py:295-317, returns on the pruned graph).  edge_index may be in any
+ * order.  The bridge-based rounding / splitting heuristics stay on the host. */
+GNNCCA_API int gnncca_post_prune_cluster(const int64_t* edge_index, const int64_t* predictions, int64_t n_nodes,
+                                         int64_t n_edges, void* workspace, size_t workspace_bytes,
+                                         int64_t* pruned_out, int32_t* flow_out, int32_t* flow_in,
+                                         int32_t* labels_out, int32_t* n_clusters_out, gnncca_stream_t stream);
+
 /* Synchronises `stream` and returns the flag word of the last forward that used `workspace`. */
 GNNCCA_API int gnncca_read_graph_flags(const void* workspace, uint32_t* flags_out, gnncca_stream_t stream);
 

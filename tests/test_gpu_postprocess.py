@@ -1,0 +1,70 @@
+"""Row N2 on the GPU against golden vectors produced by the reference's own utils functions."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN_DIR
+
+pytestmark = pytest.mark.gpu
+CASES = sorted(os.path.basename(p)[5:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "post_*.npz")))
+
+
+def same_partition(a, b):
+    return np.array_equal(a[:, None] == a[None, :], b[:, None] == b[None, :])
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_threshold_prune_cluster(name):
+    from gnn_cca_amd.postprocess import prune_and_cluster, threshold
+    z = np.load(os.path.join(GOLDEN_DIR, f"post_{name}.npz"))
+    n = int(z["n_nodes"])
+    probs, preds = threshold(torch.from_numpy(z["logits"]).cuda().view(-1, 1))
+    assert np.abs(probs.cpu().numpy() - z["probs"]).max() <= 2e-7
+    assert np.array_equal(preds.cpu().numpy(), z["predictions"])
+    out = prune_and_cluster(torch.from_numpy(z["edge_index"]).cuda(), preds, n)
+    torch.cuda.synchronize()
+    assert np.array_equal(out["pruned"].cpu().numpy(), z["pruned"])
+    assert np.array_equal(out["flow_out"].cpu().numpy(), z["flow_out"])
+    assert np.array_equal(out["flow_in"].cpu().numpy(), z["flow_in"])
+    assert int(out["n_clusters"].item()) == int(z["n_clusters_pruned"])
+    assert same_partition(out["labels"].cpu().numpy(), z["id_pruned"])  # cluster ids are arbitrary, the partition is not
+
+
+def test_cluster_large_batch_property():
+    """256 frames of 4 x 8 detections: planted identities with symmetric active edges -> the clusters are the identities."""
+    from gnn_cca_amd.postprocess import prune_and_cluster
+    rng = np.random.default_rng(2)
+    frames, per = 256, 32
+    n = frames * per
+    cam = np.tile(np.repeat(np.arange(4), 8), frames)
+    ident = np.concatenate([f * 100 + rng.integers(0, 10, per) for f in range(frames)])
+    rows, cols = [], []
+    for f in range(frames):
+        idx = np.arange(f * per, (f + 1) * per)
+        i, j = np.meshgrid(idx, idx, indexing="ij")
+        m = cam[i] != cam[j]
+        rows.append(i[m])
+        cols.append(j[m])
+    ei = np.stack([np.concatenate(rows), np.concatenate(cols)])
+    pred = (ident[ei[0]] == ident[ei[1]]).astype(np.int64)
+    extra = rng.random(ei.shape[1]) < 0.02          # spurious one-directional activations: pruning must remove them
+    lower = ei[0] < ei[1]
+    pred_noisy = pred | (extra & lower & (pred == 0))
+    out = prune_and_cluster(torch.from_numpy(ei).cuda(), torch.from_numpy(pred_noisy).cuda(), n)
+    assert np.array_equal(out["pruned"].cpu().numpy(), pred)
+    lab = out["labels"].cpu().numpy()
+    # two detections share a cluster iff they are connected through same-identity cross-camera pairs
+    import scipy.sparse as sp
+    from scipy.sparse.csgraph import connected_components
+    act = pred == 1  # csgraph looks at the sparsity structure: pass the active edges only
+    a = sp.coo_matrix((np.ones(int(act.sum())), (ei[0][act], ei[1][act])), shape=(n, n))
+    k, ref = connected_components(a, directed=False)
+    assert int(out["n_clusters"].item()) == k
+    assert np.array_equal(lab == lab[0], ref == ref[0]) and len(np.unique(lab)) == k
+    _, inv = np.unique(lab, return_inverse=True)
+    _, inv_ref = np.unique(ref, return_inverse=True)
+    first = {}
+    assert all(first.setdefault(a_, b_) == b_ for a_, b_ in zip(inv, inv_ref))
