@@ -153,6 +153,9 @@ def main():
     ap.add_argument("--mode", choices=["eager", "graph"], default="graph",
                     help="eager: one C-ABI call per step; graph: the same call captured once in a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for rehearsals)")
+    ap.add_argument("--single-device", action="store_true",
+                    help="rehearsal on a 1-GPU box: every rank uses cuda:0 (use with --backend gloo)")
     ap.add_argument("--profile-reps", type=int, default=20)
     args = ap.parse_args()
 
@@ -161,13 +164,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path is the only implementation (no CPU fallback)")
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     params = graph_net_params(L=args.L)
     model = build_model(params, args.nodes, seed=0).to(device)
@@ -215,7 +223,7 @@ def main():
         dev_s = ev0.elapsed_time(ev1) / 1e3
         t = max(wall, dev_s)
         if dist:
-            tt = torch.tensor([t], device=device, dtype=torch.float64)
+            tt = torch.tensor([t], device=device if args.backend == "nccl" else "cpu", dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             t = float(tt.item())
         if static_out is not None:

@@ -60,6 +60,18 @@ def broadcast_packed_weights(model, src=0, group=None):
     latency-bound (about 1 MB), issued once at start-up or after load_state_dict."""
     import torch.distributed as dist
     dev = next(model.parameters()).device
+    if dist.get_backend(group) != "nccl" and dev.type == "cuda":
+        # rehearsal backends (gloo) move host tensors: broadcast the host blob, then upload
+        import ctypes as C
+        from . import _native as nat
+        if dist.get_rank(group) == src:
+            host = model.pack_weights_host()
+        else:
+            host = torch.empty(nat.lib().gnncca_packed_weights_bytes(C.byref(model.native_dims())), dtype=torch.uint8)
+        dist.broadcast(host, src=src, group=group)
+        blob = host.to(dev)
+        model.set_packed_weights(blob)
+        return blob
     if dist.get_rank(group) == src:
         blob = model.pack_weights_host().to(dev)
     else:
