@@ -243,3 +243,69 @@ def load_case(path):
     sd.update({k[4:]: z[k] for k in z.files if k.startswith("sd::")})
     arrays = {k: z[k] for k in z.files if not k.startswith("sd::") and k not in ("params_json", "weights_file")}
     return meta["model_params"], meta["arch"], sd, arrays
+
+
+# --------------------------------------------------------------------------------------------------
+# train-mode flavour with autograd (row N3): the reference's forward under torch autograd
+# --------------------------------------------------------------------------------------------------
+class TorchTrainOracle(TorchOracle):
+    """TorchOracle with gradients: parameters are autograd leaves, BatchNorm1d runs in TRAIN mode (batch statistics,
+    running buffers updated with momentum 0.1 as torch.nn.BatchNorm1d does, models/mlp.py:15), Dropout must be 0.
+    `loss_and_grads` forms the loss exactly as train.py:80-97 does with LOSS NAME 'BCE' (sum over the classified
+    steps of BCEWithLogitsLoss(reduction='mean'))."""
+
+    def __init__(self, model_params, arch, sd):
+        super().__init__(model_params, arch, sd)
+        self.buffers = {k: v.clone() for k, v in self.sd.items() if "running_" in k}
+        self.sd = {k: (v.clone().requires_grad_(True) if "running_" not in k else v) for k, v in self.sd.items()}
+
+    def _mlp(self, prefix, x):
+        torch = self.torch
+        for lin, _in, _out, bn, relu in self.lay[prefix]:
+            p = f"{prefix}.fc_layers.{lin}."
+            x = torch.nn.functional.linear(x, self.sd[p + "weight"], self.sd[p + "bias"])
+            if bn is not None:
+                q = f"{prefix}.fc_layers.{bn}."
+                x = torch.nn.functional.batch_norm(x, self.buffers[q + "running_mean"], self.buffers[q + "running_var"],
+                                                   self.sd[q + "weight"], self.sd[q + "bias"], True, 0.1, BN_EPS)
+            if relu:
+                x = torch.relu(x)
+        return x
+
+    def forward(self, x, edge_index, edge_attr):
+        torch = self.torch
+        lay = self.lay
+        x = torch.as_tensor(x).float()
+        e = torch.as_tensor(edge_attr).float()
+        edge_index = torch.as_tensor(edge_index).long()
+        row, col = edge_index[0], edge_index[1]
+        n = x.shape[0]
+        if lay["encoder.edge_mlp"] is not None:
+            e = self._mlp("encoder.edge_mlp", e)
+        h = self._mlp("encoder.node_mlp", x) if lay["encoder.node_mlp"] is not None else x
+        e0, h0 = e, h
+        L, first = lay["L"], lay["L"] - lay["n_cls"] + 1
+        logits = []
+        for step in range(1, L + 1):
+            if lay["reattach_edges"]:
+                e = torch.cat((e0, e), dim=1)
+            if lay["reattach_nodes"]:
+                h = torch.cat((h0, h), dim=1)
+            e = self._mlp("MPNet.edge_model.edge_mlp", torch.cat([h[row], h[col], e], dim=1))
+            flow = self._mlp("MPNet.node_model.node_mlp", torch.cat([h[row], e], dim=1))
+            h = self._aggregate(flow, row, n)
+            if step >= first:
+                logits.append(self._mlp("classifier.edge_mlp", e))
+        if L == 0:
+            logits.append(self._mlp("classifier.edge_mlp", e))
+        return logits
+
+    def loss_and_grads(self, x, edge_index, edge_attr, labels):
+        torch = self.torch
+        logits = self.forward(x, edge_index, edge_attr)
+        lab = torch.as_tensor(labels).float()
+        crit = torch.nn.BCEWithLogitsLoss(reduction="mean")
+        loss = sum(crit(t.view(-1), lab) for t in logits)
+        keys = [k for k, v in self.sd.items() if v.requires_grad]
+        grads = torch.autograd.grad(loss, [self.sd[k] for k in keys], allow_unused=True)
+        return float(loss), [t.detach() for t in logits], {k: (g if g is not None else torch.zeros_like(self.sd[k])) for k, g in zip(keys, grads)}
