@@ -1,0 +1,232 @@
+#pragma once
+// backward pass of the message-passing path (training through the HIP kernels).
+//
+// Forward quantities are NOT re-derived from scratch: the traced forward saves the latents the reference's autograd
+// would keep alive (encoder outputs, node / edge latents after every step); ReLU masks come from those (y > 0), the
+// node-message pre-activation is recomputed per edge from a per-node table Q = h W_nx^T + b_n.  Per step, in reverse:
+//   classifier      (models/mpn.py:292)   d logits -> d e_s, d W_cls
+//   node update     (models/mpn.py:97-99) d h_s[row] (/ deg for 'mean') -> ReLU' -> d W_ne, d b_n, d Q[row], d e_s
+//   edge update     (models/mpn.py:48,68-69) d e_s -> ReLU' -> d W_ee, d b_e, d P_src[row], d P_dst[col], d e_{s-1}
+//   projections     d (P_src | P_dst | Q) -> d h_{s-1}, d W_src, d W_dst, d W_nx
+// then the two encoders.  Parameter gradients are sums over edges / nodes: contributions are reduced across the wave
+// first (DPP shuffles) and then added with one float atomic per wave, so the result depends on arrival order in the
+// last bits exactly like the reference on CUDA (cuBLAS / torch_scatter atomics).  Correctness first; this path is
+// not tuned (the reference trains on batches of a few 10^4 edges).
+// Supported: the MFMA family without reattach flags, without BatchNorm, 'sum' / 'mean', two-layer node encoder.
+// Part of the single translation unit mpn_forward.hip.
+namespace gnncca {
+
+__device__ __forceinline__ float wave_reduce_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// one atomic per wave for a contribution every lane holds
+__device__ __forceinline__ void wave_atomic_add(float* dst, float v) {
+    v = wave_reduce_sum(v);
+    if ((threadIdx.x & 63) == 0 && v != 0.f) atomicAdd(dst, v);
+}
+
+__global__ __launch_bounds__(256) void bwd_degree_kernel(const long long* __restrict__ ei, long long E, int N, int* __restrict__ deg) {
+    const long long k = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (k >= E) return;
+    const long long r = ei[k];
+    if (r >= 0 && r < N) atomicAdd(&deg[r], 1);
+}
+
+// Q[i][c] = b_n[c] + sum_c' W_n[c][c'] h[i][c']   (W_n row-major [32][38], node part = columns 0..31)
+__global__ __launch_bounds__(256) void bwd_q_kernel(const float* __restrict__ h, const float* __restrict__ Wn,
+                                                    const float* __restrict__ bn, float* __restrict__ Q, int N) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= N * kH) return;
+    const int i = t / kH, c = t - i * kH;
+    float acc = bn[c];
+#pragma unroll
+    for (int d = 0; d < kH; ++d) acc = fmaf(Wn[c * (kH + kEF) + d], h[(size_t)i * kH + d], acc);
+    Q[t] = acc;
+}
+
+struct BwdEdgeParams {
+    const long long* ei;
+    const float* e_cur;    // [E][6] latent after this step
+    const float* e_prev;   // [E][6] latent before this step (encoder output for step 1)
+    const float* Q;        // [N][32]
+    const float* g_h;      // [N][32] d loss / d h_s, or null on the last step (its node update is dead)
+    const int* deg;        // [N] (mean) or null
+    const float* g_logit;  // [E] or null
+    const float* ge_in;    // [E][6] from step s+1, or null
+    float* ge_out;         // [E][6] d loss / d e_{s-1}
+    float* dP;             // [N][44]: [0,6) dP_src, [6,12) dP_dst, [12,44) dQ   (zeroed before the launch)
+    const float* We;       // [6][70]
+    const float* Wn;       // [32][38]
+    const float* Wc1;      // [C1][6] or [1][6]
+    const float* bc1;
+    const float* Wc2;      // [1][C1] (two-layer classifier) or null
+    float* gWe;            // [6][70]
+    float* gbe;
+    float* gWn;            // [32][38]
+    float* gbn;
+    float* gWc1;
+    float* gbc1;
+    float* gWc2;
+    float* gbc2;
+    long long E;
+    int N, cls_hidden;     // cls_hidden == 0: single Linear(6,1)
+};
+
+__global__ __launch_bounds__(256) void bwd_edge_kernel(const BwdEdgeParams p) {
+    const long long k0 = (long long)blockIdx.x * 256 + threadIdx.x;
+    const bool valid = k0 < p.E;
+    const long long k = valid ? k0 : p.E - 1;  // every lane takes part in the wave reductions; invalid lanes add zeros
+    const float live = valid ? 1.f : 0.f;
+    const int i = (int)p.ei[k], j = (int)p.ei[p.E + k];
+    float es[kEF], ep[kEF], ge[kEF];
+#pragma unroll
+    for (int f = 0; f < kEF; ++f) {
+        es[f] = p.e_cur[k * kEF + f];
+        ep[f] = p.e_prev[k * kEF + f];
+        ge[f] = p.ge_in ? p.ge_in[k * kEF + f] * live : 0.f;
+    }
+    // ---- classifier ------------------------------------------------------------------------------------------
+    if (p.g_logit) {
+        const float dz = p.g_logit[k] * live;
+        if (p.cls_hidden > 0) {
+            float db2 = dz;
+            wave_atomic_add(p.gbc2, db2);
+            for (int q = 0; q < p.cls_hidden; ++q) {
+                float z1 = p.bc1[q];
+#pragma unroll
+                for (int f = 0; f < kEF; ++f) z1 = fmaf(p.Wc1[q * kEF + f], es[f], z1);
+                const float r = fmaxf(z1, 0.f);
+                wave_atomic_add(p.gWc2 + q, dz * r);
+                const float gz1 = z1 > 0.f ? p.Wc2[q] * dz : 0.f;
+                wave_atomic_add(p.gbc1 + q, gz1);
+#pragma unroll
+                for (int f = 0; f < kEF; ++f) {
+                    wave_atomic_add(p.gWc1 + q * kEF + f, gz1 * es[f]);
+                    ge[f] = fmaf(p.Wc1[q * kEF + f], gz1, ge[f]);
+                }
+            }
+        } else {
+            wave_atomic_add(p.gbc1, dz);
+#pragma unroll
+            for (int f = 0; f < kEF; ++f) {
+                wave_atomic_add(p.gWc1 + f, dz * es[f]);
+                ge[f] = fmaf(p.Wc1[f], dz, ge[f]);
+            }
+        }
+    }
+    // ---- node update -------------------------------------------------------------------------------------------
+    if (p.g_h) {
+        const float inv = p.deg ? 1.f / (float)max(p.deg[i], 1) : 1.f;
+        for (int c = 0; c < kH; ++c) {
+            float b = p.Q[(size_t)i * kH + c];
+#pragma unroll
+            for (int f = 0; f < kEF; ++f) b = fmaf(p.Wn[c * (kH + kEF) + kH + f], es[f], b);
+            const float gb = b > 0.f ? p.g_h[(size_t)i * kH + c] * inv * live : 0.f;
+            wave_atomic_add(p.gbn + c, gb);
+#pragma unroll
+            for (int f = 0; f < kEF; ++f) {
+                wave_atomic_add(p.gWn + c * (kH + kEF) + kH + f, gb * es[f]);
+                ge[f] = fmaf(p.Wn[c * (kH + kEF) + kH + f], gb, ge[f]);
+            }
+            if (gb != 0.f) atomicAdd(&p.dP[(size_t)i * 44 + 12 + c], gb);
+        }
+    }
+    // ---- edge update ---------------------------------------------------------------------------------------------
+    float ga[kEF];
+#pragma unroll
+    for (int f = 0; f < kEF; ++f) {
+        ga[f] = es[f] > 0.f ? ge[f] : 0.f;
+        wave_atomic_add(p.gbe + f, ga[f]);
+        if (ga[f] != 0.f) {
+            atomicAdd(&p.dP[(size_t)i * 44 + f], ga[f]);
+            atomicAdd(&p.dP[(size_t)j * 44 + 6 + f], ga[f]);
+        }
+#pragma unroll
+        for (int g = 0; g < kEF; ++g) wave_atomic_add(p.gWe + f * 70 + 64 + g, ga[f] * ep[g]);
+    }
+    if (valid) {
+#pragma unroll
+        for (int g = 0; g < kEF; ++g) {
+            float s = 0.f;
+#pragma unroll
+            for (int f = 0; f < kEF; ++f) s = fmaf(p.We[f * 70 + 64 + g], ga[f], s);
+            p.ge_out[k * kEF + g] = s;
+        }
+    }
+}
+
+// d h_{s-1}[i][c] = sum_f W_src[f][c] dP_src[i][f] + W_dst[f][c] dP_dst[i][f] + sum_o W_nx[o][c] dQ[i][o]
+__global__ __launch_bounds__(256) void bwd_node_kernel(const float* __restrict__ dP, const float* __restrict__ We,
+                                                       const float* __restrict__ Wn, float* __restrict__ g_h_prev, int N) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= N * kH) return;
+    const int i = t / kH, c = t - i * kH;
+    const float* __restrict__ d = dP + (size_t)i * 44;
+    float acc = 0.f;
+#pragma unroll
+    for (int f = 0; f < kEF; ++f) {
+        acc = fmaf(We[f * 70 + c], d[f], acc);
+        acc = fmaf(We[f * 70 + kH + c], d[6 + f], acc);
+    }
+#pragma unroll
+    for (int o = 0; o < kH; ++o) acc = fmaf(Wn[o * (kH + kEF) + c], d[12 + o], acc);
+    g_h_prev[t] = acc;
+}
+
+// out[o][k] += sum over a chunk of 256 rows n of A[n][o] * B[n][k]   (one atomic per output per chunk)
+__global__ __launch_bounds__(256) void bwd_outer_sum_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B,
+                                                            int ldb, float* __restrict__ out, int ldo, int N, int O, int K) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long long)O * K) return;
+    const int o = (int)(t / K), k = (int)(t - (long long)o * K);
+    const int n0 = blockIdx.y * 256, n1 = min(n0 + 256, N);
+    float acc = 0.f;
+    for (int n = n0; n < n1; ++n) acc = fmaf(A[(size_t)n * lda + o], B[(size_t)n * ldb + k], acc);
+    if (acc != 0.f) atomicAdd(&out[(size_t)o * ldo + k], acc);
+}
+
+__global__ __launch_bounds__(256) void bwd_colsum_kernel(const float* __restrict__ A, int lda, float* __restrict__ out, int N, int O) {
+    const int o = blockIdx.x * 256 + threadIdx.x;
+    if (o >= O) return;
+    const int n0 = blockIdx.y * 256, n1 = min(n0 + 256, N);
+    float acc = 0.f;
+    for (int n = n0; n < n1; ++n) acc += A[(size_t)n * lda + o];
+    if (acc != 0.f) atomicAdd(&out[o], acc);
+}
+
+// g[t] = y[t] > 0 ? g[t] : 0     (ReLU backward from the saved output)
+__global__ __launch_bounds__(256) void bwd_relu_mask_kernel(float* __restrict__ g, const float* __restrict__ y, long long n) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t < n && !(y[t] > 0.f)) g[t] = 0.f;
+}
+
+// out[n][k] = (y[n][k] > 0) * sum_o G[n][o] W[o][k]      (d activation of the previous layer)
+__global__ __launch_bounds__(256) void bwd_matmul_mask_kernel(const float* __restrict__ G, const float* __restrict__ W,
+                                                              const float* __restrict__ y, float* __restrict__ out, int N, int O,
+                                                              int K) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long long)N * K) return;
+    const int n = (int)(t / K), k = (int)(t - (long long)n * K);
+    float acc = 0.f;
+    for (int o = 0; o < O; ++o) acc = fmaf(G[(size_t)n * O + o], W[(size_t)o * K + k], acc);
+    out[t] = y[t] > 0.f ? acc : 0.f;
+}
+
+// edge encoder backward: g_e0 -> ReLU' -> d W_e0 [6][A], d b_e0
+__global__ __launch_bounds__(256) void bwd_edge_enc_kernel(const float* __restrict__ ge0, const float* __restrict__ e0,
+                                                           const float* __restrict__ attr, int A, long long E,
+                                                           float* __restrict__ gW, float* __restrict__ gb) {
+    const long long k0 = (long long)blockIdx.x * 256 + threadIdx.x;
+    const bool valid = k0 < E;
+    const long long k = valid ? k0 : E - 1;
+    for (int f = 0; f < kEF; ++f) {
+        const float g = (valid && e0[k * kEF + f] > 0.f) ? ge0[k * kEF + f] : 0.f;
+        wave_atomic_add(gb + f, g);
+        for (int a = 0; a < A; ++a) wave_atomic_add(gW + f * A + a, g * attr[k * A + a]);
+    }
+}
+
+}  // namespace gnncca

@@ -23,6 +23,7 @@
 #include "step_fast.cuh"
 #include "generic.cuh"
 #include "postprocess.cuh"
+#include "backward.cuh"
 
 using namespace gnncca;
 
@@ -384,6 +385,167 @@ int gnncca_post_prune_cluster(const int64_t* edge_index, const int64_t* predicti
     }
     hipLaunchKernelGGL(post_cc_kernel, dim3(1), dim3(1024), 0, st, ei, (const long long*)pruned, (long long)E, N, labels_out,
                        n_clusters_out);
+    HIP_TRY(hipGetLastError());
+    return GNNCCA_OK;
+}
+
+
+// ---- backward ---------------------------------------------------------------------------
+static bool backward_ok(const gnncca_mpn_dims* d) {
+    if (classify(d) != kFamilyMfma32x6) return false;
+    if (d->reattach_nodes || d->reattach_edges || d->agg == GNNCCA_AGG_MAX || d->num_enc_steps < 1) return false;
+    if (d->enc_node.n_layers != 2) return false;
+    const gnncca_mlp* all[5] = {&d->enc_node, &d->enc_edge, &d->edge_mlp, &d->node_mlp, &d->cls_edge};
+    for (const gnncca_mlp* m : all)
+        for (int l = 0; l < m->n_layers; ++l)
+            if (m->layers[l].has_bn) return false;
+    return true;
+}
+
+int gnncca_backward_supported(const gnncca_mpn_dims* d) {
+    if (!dims_valid(d)) return GNNCCA_ERR_INVALID_ARG;
+    return backward_ok(d) ? GNNCCA_OK : GNNCCA_ERR_UNSUPPORTED;
+}
+
+size_t gnncca_backward_workspace_bytes(const gnncca_mpn_dims* d, int64_t n_nodes, int64_t n_edges) {
+    if (!dims_valid(d) || !backward_ok(d) || n_nodes < 0 || n_edges < 0) return 0;
+    const size_t N = (size_t)n_nodes, E = (size_t)n_edges, F1 = (size_t)d->enc_node.layers[0].out_dim;
+    auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+    return up(N * 4) + up(N * kH * 4) + up(N * 44 * 4) + 2 * up(N * kH * 4) + 2 * up(E * kEF * 4) + 2 * up(N * F1 * 4);
+}
+
+int gnncca_mpn_backward(const gnncca_mpn_dims* d, const float* const* params_dev, int n_params, const float* x,
+                        const int64_t* edge_index, const float* edge_attr, int64_t n_nodes, int64_t n_edges,
+                        const gnncca_trace* saved, const float* grad_logits, float* const* grads_dev, void* workspace,
+                        size_t workspace_bytes, gnncca_stream_t stream) {
+    if (!dims_valid(d) || n_nodes < 0 || n_edges < 0) return GNNCCA_ERR_INVALID_ARG;
+    if (!backward_ok(d)) return GNNCCA_ERR_UNSUPPORTED;
+    if (n_params != gnncca_param_count(d) || !params_dev || !grads_dev) return GNNCCA_ERR_INVALID_ARG;
+    for (int i = 0; i < n_params; ++i)
+        if (!params_dev[i] || !grads_dev[i]) return GNNCCA_ERR_INVALID_ARG;
+    if (n_nodes >= (1ll << 31) - 64 || n_edges >= (1ll << 31) - 64) return GNNCCA_ERR_UNSUPPORTED;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int N = (int)n_nodes, E = (int)n_edges;
+    const int D = d->node_in, F1 = d->enc_node.layers[0].out_dim, A = d->edge_in;
+    const int L = d->num_enc_steps, first_cls = L - d->num_class_steps + 1;
+    const int c1 = d->cls_edge.n_layers == 2 ? d->cls_edge.layers[0].out_dim : 0;
+    // zero every gradient
+    {
+        const gnncca_mlp* all[5] = {&d->enc_node, &d->enc_edge, &d->edge_mlp, &d->node_mlp, &d->cls_edge};
+        int pi = 0;
+        for (const gnncca_mlp* m : all)
+            for (int l = 0; l < m->n_layers; ++l) {
+                HIP_TRY(hipMemsetAsync(grads_dev[pi++], 0, (size_t)m->layers[l].in_dim * m->layers[l].out_dim * 4, st));
+                HIP_TRY(hipMemsetAsync(grads_dev[pi++], 0, (size_t)m->layers[l].out_dim * 4, st));
+            }
+    }
+    if (N == 0 || E == 0) return GNNCCA_OK;
+    if (!x || !edge_index || !edge_attr || !saved || !saved->h_enc || !saved->e_enc || !saved->h_steps || !saved->e_steps ||
+        !grad_logits || !workspace)
+        return GNNCCA_ERR_INVALID_ARG;
+    if (workspace_bytes < gnncca_backward_workspace_bytes(d, n_nodes, n_edges)) return GNNCCA_ERR_WORKSPACE;
+    auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+    char* base = static_cast<char*>(workspace);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char* q = base + off; off += up(bytes); return q; };
+    int* deg = reinterpret_cast<int*>(take((size_t)N * 4));
+    float* Q = reinterpret_cast<float*>(take((size_t)N * kH * 4));
+    float* dP = reinterpret_cast<float*>(take((size_t)N * 44 * 4));
+    float* Hb[2] = {reinterpret_cast<float*>(take((size_t)N * kH * 4)), reinterpret_cast<float*>(take((size_t)N * kH * 4))};
+    float* Gb[2] = {reinterpret_cast<float*>(take((size_t)E * kEF * 4)), reinterpret_cast<float*>(take((size_t)E * kEF * 4))};
+    float* a1 = reinterpret_cast<float*>(take((size_t)N * F1 * 4));
+    float* gz1 = reinterpret_cast<float*>(take((size_t)N * F1 * 4));
+    const float *W1 = params_dev[0], *b1 = params_dev[1], *W2 = params_dev[2];
+    const float *We = params_dev[6], *Wn = params_dev[8], *bn = params_dev[9];
+    const float *Wc1 = params_dev[10], *bc1 = params_dev[11], *Wc2 = c1 ? params_dev[12] : nullptr;
+    float *gW1 = grads_dev[0], *gb1 = grads_dev[1], *gW2 = grads_dev[2], *gb2 = grads_dev[3];
+    float *gWe0 = grads_dev[4], *gbe0 = grads_dev[5], *gWe = grads_dev[6], *gbe = grads_dev[7];
+    float *gWn = grads_dev[8], *gbn = grads_dev[9], *gWc1 = grads_dev[10], *gbc1 = grads_dev[11];
+    float *gWc2 = c1 ? grads_dev[12] : nullptr, *gbc2 = c1 ? grads_dev[13] : nullptr;
+    const long long* ei = reinterpret_cast<const long long*>(edge_index);
+    const int chunksN = (N + 255) / 256;
+    if (d->agg == GNNCCA_AGG_MEAN) {
+        HIP_TRY(hipMemsetAsync(deg, 0, (size_t)N * 4, st));
+        hipLaunchKernelGGL(bwd_degree_kernel, grid1((size_t)E, 256), dim3(256), 0, st, ei, (long long)E, N, deg);
+        HIP_TRY(hipGetLastError());
+    }
+    const float* g_h = nullptr;   // d loss / d h_s of the step being processed (null for s = L: its node update is dead)
+    const float* ge_in = nullptr; // d loss / d e_s arriving from step s+1
+    int out_idx = gnncca_num_outputs(d) - 1;
+    for (int s = L; s >= 1; --s) {
+        const float* h_prev = s == 1 ? saved->h_enc : saved->h_steps + (size_t)(s - 2) * N * kH;
+        const float* e_cur = saved->e_steps + (size_t)(s - 1) * E * kEF;
+        const float* e_prev = s == 1 ? saved->e_enc : saved->e_steps + (size_t)(s - 2) * E * kEF;
+        if (g_h) {
+            hipLaunchKernelGGL(bwd_q_kernel, grid1((size_t)N * kH, 256), dim3(256), 0, st, h_prev, Wn, bn, Q, N);
+            HIP_TRY(hipGetLastError());
+        }
+        HIP_TRY(hipMemsetAsync(dP, 0, (size_t)N * 44 * 4, st));
+        BwdEdgeParams bp;
+        std::memset(&bp, 0, sizeof(bp));
+        bp.ei = ei;
+        bp.e_cur = e_cur;
+        bp.e_prev = e_prev;
+        bp.Q = Q;
+        bp.g_h = g_h;
+        bp.deg = d->agg == GNNCCA_AGG_MEAN ? deg : nullptr;
+        bp.g_logit = s >= first_cls ? grad_logits + (size_t)(out_idx--) * E : nullptr;
+        bp.ge_in = ge_in;
+        bp.ge_out = Gb[s & 1];
+        bp.dP = dP;
+        bp.We = We;
+        bp.Wn = Wn;
+        bp.Wc1 = Wc1;
+        bp.bc1 = bc1;
+        bp.Wc2 = Wc2;
+        bp.gWe = gWe;
+        bp.gbe = gbe;
+        bp.gWn = gWn;
+        bp.gbn = gbn;
+        bp.gWc1 = gWc1;
+        bp.gbc1 = gbc1;
+        bp.gWc2 = gWc2;
+        bp.gbc2 = gbc2;
+        bp.E = E;
+        bp.N = N;
+        bp.cls_hidden = c1;
+        hipLaunchKernelGGL(bwd_edge_kernel, grid1((size_t)E, 256), dim3(256), 0, st, bp);
+        HIP_TRY(hipGetLastError());
+        float* g_h_prev = Hb[s & 1];
+        hipLaunchKernelGGL(bwd_node_kernel, grid1((size_t)N * kH, 256), dim3(256), 0, st, (const float*)dP, We, Wn, g_h_prev, N);
+        HIP_TRY(hipGetLastError());
+        // d W_src, d W_dst (columns 0..31, 32..63 of the edge-MLP weight), d W_nx (columns 0..31 of the node-MLP weight)
+        hipLaunchKernelGGL(bwd_outer_sum_kernel, dim3((6 * kH + 255) / 256, chunksN), dim3(256), 0, st, (const float*)dP, 44, h_prev,
+                           kH, gWe, 70, N, 6, kH);
+        hipLaunchKernelGGL(bwd_outer_sum_kernel, dim3((6 * kH + 255) / 256, chunksN), dim3(256), 0, st, (const float*)(dP + 6), 44,
+                           h_prev, kH, gWe + kH, 70, N, 6, kH);
+        if (g_h)
+            hipLaunchKernelGGL(bwd_outer_sum_kernel, dim3((kH * kH + 255) / 256, chunksN), dim3(256), 0, st,
+                               (const float*)(dP + 12), 44, h_prev, kH, gWn, kH + kEF, N, kH, kH);
+        HIP_TRY(hipGetLastError());
+        g_h = g_h_prev;
+        ge_in = Gb[s & 1];
+    }
+    // ---- encoders ---------------------------------------------------------------------------------------------------
+    hipLaunchKernelGGL(bwd_edge_enc_kernel, grid1((size_t)E, 256), dim3(256), 0, st, ge_in, saved->e_enc, edge_attr, A, (long long)E,
+                       gWe0, gbe0);
+    HIP_TRY(hipGetLastError());
+    {   // a1 = ReLU(x W1^T + b1) is recomputed instead of stored
+        GenSeg none = {nullptr, nullptr, 0, 0};
+        hipLaunchKernelGGL(gen_dense_kernel, grid1((size_t)N * F1, 256), dim3(256), 0, st, GenSeg{x, nullptr, D, D}, none, none, W1, b1,
+                           a1, (long long)N, D, F1, F1, 1);
+        HIP_TRY(hipGetLastError());
+    }
+    float* gz2 = const_cast<float*>(g_h);  // [N][32] d loss / d h_enc, masked in place
+    hipLaunchKernelGGL(bwd_relu_mask_kernel, grid1((size_t)N * kH, 256), dim3(256), 0, st, gz2, saved->h_enc, (long long)N * kH);
+    hipLaunchKernelGGL(bwd_outer_sum_kernel, dim3((kH * F1 + 255) / 256, chunksN), dim3(256), 0, st, (const float*)gz2, kH,
+                       (const float*)a1, F1, gW2, F1, N, kH, F1);
+    hipLaunchKernelGGL(bwd_colsum_kernel, dim3(1, chunksN), dim3(256), 0, st, (const float*)gz2, kH, gb2, N, kH);
+    hipLaunchKernelGGL(bwd_matmul_mask_kernel, grid1((size_t)N * F1, 256), dim3(256), 0, st, (const float*)gz2, W2, (const float*)a1,
+                       gz1, N, kH, F1);
+    hipLaunchKernelGGL(bwd_outer_sum_kernel, dim3((unsigned)(((size_t)F1 * D + 255) / 256), chunksN), dim3(256), 0, st,
+                       (const float*)gz1, F1, x, D, gW1, D, N, F1, D);
+    hipLaunchKernelGGL(bwd_colsum_kernel, dim3((F1 + 255) / 256, chunksN), dim3(256), 0, st, (const float*)gz1, F1, gb1, N, F1);
     HIP_TRY(hipGetLastError());
     return GNNCCA_OK;
 }

@@ -62,6 +62,44 @@ class MLPGraphIndependent(nn.Module):
             self.edge_mlp = MLP(edge_in_dim, list(edge_fc_dims) + [edge_out_dim], dropout_p, use_batchnorm)
 
 
+class _MPNTrainFunction(torch.autograd.Function):
+    """Autograd bridge for train mode: forward = the traced HIP forward (it saves the latents the
+    backward needs), backward = gnncca_mpn_backward.  Gradients flow to the module's parameters only (the reference
+    computes the node features under torch.no_grad(), train.py:248-253, so d/dx is never asked for)."""
+
+    @staticmethod
+    def forward(ctx, module, x, edge_index, edge_attr, *params):
+        trace = {}
+        with torch.no_grad():
+            out = module._forward_native(x, edge_index, edge_attr, trace)
+        ctx.module = module
+        ctx.n_params = len(params)
+        ctx.save_for_backward(x, edge_index, edge_attr, trace['h_enc'], trace['e_enc'], trace['h_steps'], trace['e_steps'],
+                              *params)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x, edge_index, edge_attr, h_enc, e_enc, h_steps, e_steps = ctx.saved_tensors[:7]
+        params = ctx.saved_tensors[7:]
+        module = ctx.module
+        lib, d = nat.lib(), module.native_dims()
+        dev = x.device
+        n, e = x.shape[0], edge_index.shape[1]
+        g = grad_out.reshape(grad_out.shape[0], -1).float().contiguous()
+        grads = [torch.empty_like(p, dtype=torch.float32) for p in params]
+        pp = (C.c_void_p * len(params))(*[p.data_ptr() for p in params])
+        gp = (C.c_void_p * len(params))(*[t.data_ptr() for t in grads])
+        ws = torch.empty(lib.gnncca_backward_workspace_bytes(C.byref(d), n, e) + 256, dtype=torch.uint8, device=dev)
+        saved = nat.Trace(h_enc.data_ptr(), e_enc.data_ptr(), h_steps.data_ptr(), e_steps.data_ptr())
+        with torch.cuda.device(dev):
+            st = lib.gnncca_mpn_backward(C.byref(d), pp, len(params), x.data_ptr(), edge_index.data_ptr(), edge_attr.data_ptr(),
+                                         n, e, C.byref(saved), g.data_ptr(), gp, ws.data_ptr(), ws.numel(),
+                                         torch.cuda.current_stream(dev).cuda_stream)
+        nat.check(st, "gnncca_mpn_backward")
+        return (None, None, None, None, *grads)
+
+
 def _fill_mlp(dst, mlp):
     dst.n_layers = 0 if mlp is None else len(mlp.plan)
     if dst.n_layers > nat.MAX_LAYERS:
@@ -199,10 +237,6 @@ class MOTMPNet(nn.Module):
     # -- forward -----------------------------------------------------------------------------------------------
     def _prepare(self, data):
         x, edge_index, edge_attr = data.x, data.edge_index, data.edge_attr
-        if self.training:
-            raise NotImplementedError(
-                "train-mode forward (batch-statistics BatchNorm + autograd through the fused kernels) is not part "
-                "of the HIP path yet (SURVEY.md 8f row N3); call .eval()")
         if not (x.is_cuda and edge_index.is_cuda and edge_attr.is_cuda):
             raise RuntimeError("gnn_cca_amd.MOTMPNet runs on MI355X only: move the module and `data` to the GPU "
                                "(there is no CPU fallback)")
@@ -232,10 +266,51 @@ class MOTMPNet(nn.Module):
         return lib, d, dev, x, edge_index, edge_attr, n, e, blob, logits, ws
 
     def forward(self, data, trace=None):
-        """See class docstring.  ``trace`` (optional dict) receives the intermediate latents for debugging."""
-        lib, d, dev, x, edge_index, edge_attr, n, e, blob, logits, ws = self._prepare(data)
+        """See class docstring.  ``trace`` (optional dict) receives the intermediate latents for debugging.
+        In train mode the outputs carry an autograd graph to the parameters (row N3)."""
+        if self.training:
+            return self._forward_train(data)
+        logits = self._forward_native(data.x, data.edge_index, data.edge_attr, trace)
+        return {'classified_edges': list(logits.unbind(0))}
+
+    def _check_trainable(self):
+        lib, d = nat.lib(), self.native_dims()
+        if lib.gnncca_backward_supported(C.byref(d)) != nat.OK:
+            raise NotImplementedError(
+                "train-mode forward/backward on the HIP path covers the shipped training shape (no BatchNorm, no reattach "
+                "flags, 'sum'/'mean', two-layer node encoder); this configuration is outside it (SURVEY.md 8f row N3)")
+        for mod in self.modules():
+            if isinstance(mod, nn.Dropout) and mod.p > 0:
+                raise NotImplementedError("Dropout with p > 0 in train mode is not implemented on the HIP path")
+
+    def _forward_train(self, data):
+        self._check_trainable()
+        params = self.native_param_tensors()
+        x, edge_index, edge_attr = data.x, data.edge_index, data.edge_attr
+        if x.dtype != torch.float32 or not x.is_contiguous():
+            x = x.float().contiguous()
+        if edge_attr.dtype != torch.float32 or not edge_attr.is_contiguous():
+            edge_attr = edge_attr.float().contiguous()
+        if edge_index.dtype != torch.int64 or not edge_index.is_contiguous():
+            edge_index = edge_index.long().contiguous()
+        logits = _MPNTrainFunction.apply(self, x.detach(), edge_index, edge_attr.detach(), *params)
+        return {'classified_edges': list(logits.unbind(0))}
+
+    def _forward_native(self, x, edge_index, edge_attr, trace=None):
+        """Eval-semantics forward through gnncca_mpn_forward; returns logits [n_out, E, 1]."""
+        class _D:
+            pass
+        dd = _D()
+        dd.x, dd.edge_index, dd.edge_attr = x, edge_index, edge_attr
+        lib, d, dev, x, edge_index, edge_attr, n, e, blob, logits, ws = self._prepare(dd)
         if ws is None:
-            return {'classified_edges': list(logits.unbind(0))}
+            if trace is not None:
+                L = int(self.num_enc_steps)
+                trace['h_enc'] = torch.zeros((n, d.node_dim), dtype=torch.float32, device=dev)
+                trace['e_enc'] = torch.zeros((e, d.edge_dim), dtype=torch.float32, device=dev)
+                trace['h_steps'] = torch.zeros((L, n, d.node_dim), dtype=torch.float32, device=dev)
+                trace['e_steps'] = torch.zeros((L, e, d.edge_dim), dtype=torch.float32, device=dev)
+            return logits
         tr = None
         if trace is not None:
             L = int(self.num_enc_steps)
@@ -251,7 +326,7 @@ class MOTMPNet(nn.Module):
                                         edge_attr.data_ptr(), n, e, ws.data_ptr(), ws.numel(), logits.data_ptr(), tr,
                                         stream)
         nat.check(st, "gnncca_mpn_forward")
-        return {'classified_edges': list(logits.unbind(0))}
+        return logits
 
     def forward_profiled(self, data):
         """Diagnostic (bench.py): same forward with a hipEvent after every kernel launch; synchronises.

@@ -196,6 +196,21 @@ GNNCCA_API int gnncca_post_prune_cluster(const int64_t* edge_index, const int64_
                                          int64_t* pruned_out, int32_t* flow_out, int32_t* flow_in,
                                          int32_t* labels_out, int32_t* n_clusters_out, gnncca_stream_t stream);
 
+/* ---- backward pass (training through the HIP kernels, train.py:454-494) -----------------
+ * Supported (GNNCCA_OK from gnncca_backward_supported): the MFMA family without reattach flags and without BatchNorm,
+ * 'sum' / 'mean' aggregation, two-layer node encoder, L >= 1 -- i.e. the shipped TRAINING config
+ * (config_training.yaml:94-181).  `saved` holds the latents written by gnncca_mpn_forward's trace taps for the same
+ * inputs and weights; `params_dev` / `grads_dev` are DEVICE pointers to the raw parameters / their gradients in the
+ * canonical order of gnncca_param_count (row-major, un-split, exactly the nn.Parameter layouts).  grads are
+ * overwritten.  grad_logits: [n_out][E]. */
+GNNCCA_API int gnncca_backward_supported(const gnncca_mpn_dims* dims);
+GNNCCA_API size_t gnncca_backward_workspace_bytes(const gnncca_mpn_dims* dims, int64_t n_nodes, int64_t n_edges);
+GNNCCA_API int gnncca_mpn_backward(const gnncca_mpn_dims* dims, const float* const* params_dev, int n_params,
+                                   const float* x, const int64_t* edge_index, const float* edge_attr, int64_t n_nodes,
+                                   int64_t n_edges, const gnncca_trace* saved, const float* grad_logits,
+                                   float* const* grads_dev, void* workspace, size_t workspace_bytes,
+                                   gnncca_stream_t stream);
+
 /* Synchronises `stream` and returns the flag word of the last forward that used `workspace`. */
 GNNCCA_API int gnncca_read_graph_flags(const void* workspace, uint32_t* flags_out, gnncca_stream_t stream);
 

@@ -68,17 +68,21 @@ def test_constructor_contract():
         MOTMPNet(copy.deepcopy(params), None, "no_such_arch")
 
 
-def test_no_cpu_fallback_and_train_mode_refused():
+def test_no_cpu_fallback_and_unsupported_train_mode_refused():
     m, _, _, _, a = _model("n8_sum")
 
     class D:
         x, edge_index, edge_attr = (torch.from_numpy(a[k]) for k in ("x", "edge_index", "edge_attr"))
 
-    with pytest.raises(RuntimeError):
+    with pytest.raises(RuntimeError):          # CPU tensors: no fallback
         m(D())
     m.train()
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(NotImplementedError):   # classifier BatchNorm in train mode is outside the HIP backward
         m(D())
+    m2, _, _, _, _ = _model("bn_off")          # the training config's shape: supported, but still GPU only
+    m2.train()
+    with pytest.raises(RuntimeError):
+        m2(D())
 
 
 def test_supported_family_and_counts():
