@@ -411,7 +411,8 @@ size_t gnncca_backward_workspace_bytes(const gnncca_mpn_dims* d, int64_t n_nodes
     if (!dims_valid(d) || !backward_ok(d) || n_nodes < 0 || n_edges < 0) return 0;
     const size_t N = (size_t)n_nodes, E = (size_t)n_edges, F1 = (size_t)d->enc_node.layers[0].out_dim;
     auto up = [](size_t v) { return (v + 255) / 256 * 256; };
-    return up(N * 4) + up(N * kH * 4) + up(N * 44 * 4) + 2 * up(N * kH * 4) + 2 * up(E * kEF * 4) + 2 * up(N * F1 * 4);
+    return up(N * 4) + up(N * kH * 4) + up(N * 44 * 4) + 2 * up(N * kH * 4) + 2 * up(E * kEF * 4) + 2 * up(N * F1 * 4) +
+           up(32 * N * F1 * 4);
 }
 
 int gnncca_mpn_backward(const gnncca_mpn_dims* d, const float* const* params_dev, int n_params, const float* x,
@@ -455,6 +456,7 @@ int gnncca_mpn_backward(const gnncca_mpn_dims* d, const float* const* params_dev
     float* Gb[2] = {reinterpret_cast<float*>(take((size_t)E * kEF * 4)), reinterpret_cast<float*>(take((size_t)E * kEF * 4))};
     float* a1 = reinterpret_cast<float*>(take((size_t)N * F1 * 4));
     float* gz1 = reinterpret_cast<float*>(take((size_t)N * F1 * 4));
+    float* part = reinterpret_cast<float*>(take((size_t)32 * N * F1 * 4));  // split-K partials of the a1 recompute
     const float *W1 = params_dev[0], *b1 = params_dev[1], *W2 = params_dev[2];
     const float *We = params_dev[6], *Wn = params_dev[8], *bn = params_dev[9];
     const float *Wc1 = params_dev[10], *bc1 = params_dev[11], *Wc2 = c1 ? params_dev[12] : nullptr;
@@ -530,10 +532,28 @@ int gnncca_mpn_backward(const gnncca_mpn_dims* d, const float* const* params_dev
     hipLaunchKernelGGL(bwd_edge_enc_kernel, grid1((size_t)E, 256), dim3(256), 0, st, ge_in, saved->e_enc, edge_attr, A, (long long)E,
                        gWe0, gbe0);
     HIP_TRY(hipGetLastError());
-    {   // a1 = ReLU(x W1^T + b1) is recomputed instead of stored
-        GenSeg none = {nullptr, nullptr, 0, 0};
-        hipLaunchKernelGGL(gen_dense_kernel, grid1((size_t)N * F1, 256), dim3(256), 0, st, GenSeg{x, nullptr, D, D}, none, none, W1, b1,
-                           a1, (long long)N, D, F1, F1, 1);
+    {   // a1 = ReLU(x W1^T + b1) is recomputed instead of stored: the forward's split-K MFMA GEMM + its reduce kernel
+        int ks = 1;
+        while (ks < 32 && (size_t)((N + 31) / 32) * ks < 512 && D / (ks * 2) >= 64) ks *= 2;
+        int kslice = (D + ks - 1) / ks;
+        kslice = (kslice + 63) / 64 * 64;
+        EncPlanParams ep;
+        std::memset(&ep, 0, sizeof(ep));
+        ep.in = x;
+        ep.W = W1;
+        ep.part = part;
+        ep.M = N;
+        ep.K = D;
+        ep.O = F1;
+        ep.kslice = kslice;
+        ep.vec_ok = (D % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+        ep.nrt = (N + 31) / 32;
+        ep.nks = ks;
+        ep.gemm_blocks = ep.nrt * ks * ((F1 + 127) / 128);
+        hipLaunchKernelGGL(enc_gemm_plan_kernel, dim3(ep.gemm_blocks), dim3(256), 0, st, ep);
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(reduce_bias_act_kernel, grid1((size_t)N * F1, 256), dim3(256), 0, st, (const float*)part, b1, a1, N, F1, ks,
+                           1);
         HIP_TRY(hipGetLastError());
     }
     float* gz2 = const_cast<float*>(g_h);  // [N][32] d loss / d h_enc, masked in place

@@ -210,7 +210,7 @@ class MOTMPNet(nn.Module):
         host = [t.detach().to("cpu", torch.float32).contiguous() for t in self.native_param_tensors()]
         ptrs = (C.c_void_p * len(host))(*[t.data_ptr() for t in host])
         nbytes = lib.gnncca_packed_weights_bytes(C.byref(d))
-        blob = torch.zeros(nbytes, dtype=torch.uint8)
+        blob = torch.empty(nbytes, dtype=torch.uint8)  # gnncca_pack_weights clears and fills every byte
         nat.check(lib.gnncca_pack_weights(C.byref(d), ptrs, len(host), blob.data_ptr(), nbytes), "gnncca_pack_weights")
         return blob
 
