@@ -93,13 +93,13 @@ def make_data(n_nodes, n_graphs, seed, device):
     return d
 
 
-def step_algorithmic_bytes(E, L, n_cls, msg_only=True):
+def step_algorithmic_bytes(E, L, n_cls, msg_only=True, e_bytes=24):
     """Algorithmic HBM bytes of the mpn_step_kernel launches of one forward (fp32):
     read e (24 B; step 1 reads edge_attr, 16 B) + col32 (4 B) + write e' (24 B, not on the last step) + logit (4 B)."""
     first_cls = L - n_cls + 1
     per_launch = []
     for s in range(1, L + 1):
-        b = (16 if s == 1 else 24) + 4 + (24 if s < L else 0) + (4 if s >= first_cls else 0)
+        b = (16 if s == 1 else e_bytes) + 4 + (e_bytes if s < L else 0) + (4 if s >= first_cls else 0)
         if msg_only and s == L:
             continue
         per_launch.append(b * E)
@@ -152,6 +152,8 @@ def main():
     ap.add_argument("--L", type=int, default=4)
     ap.add_argument("--mode", choices=["eager", "graph"], default="graph",
                     help="eager: one C-ABI call per step; graph: the same call captured once in a HIP graph")
+    ap.add_argument("--edge-state", choices=["fp32", "bf16"], default="fp32",
+                    help="storage of the edge latents between steps (bf16: GNNCCA_OPT_EDGE_STATE_BF16; arithmetic stays fp32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--single-device", action="store_true",
@@ -179,6 +181,7 @@ def main():
 
     params = graph_net_params(L=args.L)
     model = build_model(params, args.nodes, seed=0).to(device)
+    model.edge_state_dtype = args.edge_state
     # shared weights: rank 0 packs, everyone receives the blob over RCCL/xGMI (no other collective on the path)
     if world > 1:
         from gnn_cca_amd.sharding import broadcast_packed_weights
@@ -248,7 +251,7 @@ def main():
                 kernel_ms.setdefault(kind, []).append(ms)
 
     if rank == 0:
-        per_launch = step_algorithmic_bytes(E, args.L, 3)
+        per_launch = step_algorithmic_bytes(E, args.L, 3, e_bytes=12 if args.edge_state == "bf16" else 24)
         step_ms = float(np.mean(kernel_ms["step"])) if "step" in kernel_ms else float("nan")
         alg = float(np.mean(per_launch)) if per_launch else 0.0
         achieved = alg / (step_ms * 1e-3) / 1e9 if step_ms == step_ms and step_ms > 0 else 0.0
@@ -257,7 +260,7 @@ def main():
         traffic, rocprof_us = None, None
         try:
             with open(os.path.join(ROOT, "profiles", "pmc_index.json")) as f:
-                ent = json.load(f).get(f"{args.graphs}x{args.nodes}_L{args.L}")
+                ent = json.load(f).get(f"{args.graphs}x{args.nodes}_L{args.L}" + ("_bf16" if args.edge_state == "bf16" else ""))
             if ent:
                 traffic, rocprof_us = ent["hbm_bytes_per_launch"], ent["rocprof_avg_us"]
         except OSError:
@@ -277,7 +280,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{args.graphs} x dense{args.nodes} graph(s) per GPU per step "
                                    f"(N={N}, E={E}), feat 2048, L={args.L}, 3 classified steps, fp32, eval",
-                       "mode": mode_used, "outputs_finite": bool(ok),
+                       "mode": mode_used, "edge_state": args.edge_state, "outputs_finite": bool(ok),
                        "edge_steps_per_s": world * E * args.L * args.steps / t},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,

@@ -43,7 +43,10 @@ KERNEL_KINDS = ["plan", "plan_sort_unused", "enc_gemm", "enc_reduce", "enc_tail"
 
 
 class Profile(C.Structure):
-    _fields_ = [("count", C.c_int32), ("kind", C.c_int32 * PROFILE_MAX), ("ms", C.c_float * PROFILE_MAX)]
+    _fields_ = [("options", C.c_uint32), ("count", C.c_int32), ("kind", C.c_int32 * PROFILE_MAX), ("ms", C.c_float * PROFILE_MAX)]
+
+
+OPT_EDGE_STATE_BF16 = 1
 
 
 _SIGNATURES = {
@@ -58,6 +61,8 @@ _SIGNATURES = {
     "gnncca_num_outputs": (C.c_int, [C.POINTER(MpnDims)]),
     "gnncca_mpn_forward": (C.c_int, [C.POINTER(MpnDims), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                      C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(Trace), C.c_void_p]),
+    "gnncca_mpn_forward_ex": (C.c_int, [C.POINTER(MpnDims), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                        C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(Trace), C.c_uint32, C.c_void_p]),
     "gnncca_mpn_forward_profiled": (C.c_int, [C.POINTER(MpnDims), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                               C.c_int64, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
                                               C.POINTER(Profile)]),

@@ -51,7 +51,8 @@ int gnncca_read_graph_flags(const void* workspace, uint32_t* flags_out, gnncca_s
 
 static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const float* x, const int64_t* edge_index,
                         const float* edge_attr, int64_t n_nodes, int64_t n_edges, void* workspace, size_t workspace_bytes,
-                        float* logits_out, const gnncca_trace* trace, gnncca_stream_t stream, Profiler* prof) {
+                        float* logits_out, const gnncca_trace* trace, gnncca_stream_t stream, Profiler* prof,
+                        uint32_t options) {
     if (!dims_valid(d) || n_nodes < 0 || n_edges < 0) return GNNCCA_ERR_INVALID_ARG;
     const Family fam = classify(d);
     if (fam == kFamilyNone) return GNNCCA_ERR_UNSUPPORTED;
@@ -242,6 +243,7 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
     }
     sp.hin = hin;
     sp.pd_lds = (N <= 1024) && d->num_enc_steps > 0;
+    sp.e_bf16 = (options & GNNCCA_OPT_EDGE_STATE_BF16) != 0;  // honoured by the specialised kernels only
     const bool re = d->reattach_edges != 0;
     int out_idx = 0;
     if (L == 0) {  // models/mpn.py:295-297: classify the encoded edge features once
@@ -290,7 +292,14 @@ int gnncca_mpn_forward(const gnncca_mpn_dims* d, const void* packed_dev, const f
                        const float* edge_attr, int64_t n_nodes, int64_t n_edges, void* workspace, size_t workspace_bytes,
                        float* logits_out, const gnncca_trace* trace, gnncca_stream_t stream) {
     return forward_impl(d, packed_dev, x, edge_index, edge_attr, n_nodes, n_edges, workspace, workspace_bytes, logits_out,
-                        trace, stream, nullptr);
+                        trace, stream, nullptr, 0u);
+}
+
+int gnncca_mpn_forward_ex(const gnncca_mpn_dims* d, const void* packed_dev, const float* x, const int64_t* edge_index,
+                          const float* edge_attr, int64_t n_nodes, int64_t n_edges, void* workspace, size_t workspace_bytes,
+                          float* logits_out, const gnncca_trace* trace, uint32_t options, gnncca_stream_t stream) {
+    return forward_impl(d, packed_dev, x, edge_index, edge_attr, n_nodes, n_edges, workspace, workspace_bytes, logits_out,
+                        trace, stream, nullptr, options);
 }
 
 int gnncca_mpn_forward_profiled(const gnncca_mpn_dims* d, const void* packed_dev, const float* x,
@@ -305,7 +314,7 @@ int gnncca_mpn_forward_profiled(const gnncca_mpn_dims* d, const void* packed_dev
     int s = prof_begin(&p, st);
     if (s != GNNCCA_OK) return s;
     s = forward_impl(d, packed_dev, x, edge_index, edge_attr, n_nodes, n_edges, workspace, workspace_bytes, logits_out,
-                     nullptr, stream, &p);
+                     nullptr, stream, &p, profile->options);
     const int s2 = prof_end(&p, st);
     return s != GNNCCA_OK ? s : s2;
 }

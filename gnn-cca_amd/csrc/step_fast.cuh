@@ -9,7 +9,7 @@ namespace gnncca {
 // time, so the body is straight-line code whose loads issue back to back.  mpn_step_kernel stays as the
 // general / traced variant.
 // ------------------------------------------------------------------------------------------------------------
-template <bool FIRST, bool CLS, bool MSG, bool PD_LDS>
+template <bool FIRST, bool CLS, bool MSG, bool PD_LDS, bool EBF16>
 __global__ __launch_bounds__(256) void mpn_step_fast_kernel(const StepParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_proj = smem;                                   // [32][48]   (MSG)
@@ -98,6 +98,15 @@ __global__ __launch_bounds__(256) void mpn_step_fast_kernel(const StepParams p) 
         if (FIRST) {
             const f32x4 a = *reinterpret_cast<const f32x4*>(p.edge_attr + (size_t)c.ko * 4);
             c.raw[0] = a[0], c.raw[1] = a[1], c.raw[2] = a[2], c.raw[3] = a[3], c.raw[4] = 0.f, c.raw[5] = 0.f;
+        } else if (EBF16) {
+            // edge state stored as three planes of packed bf16 pairs: one dword load = two features
+            const unsigned* __restrict__ e2 = reinterpret_cast<const unsigned*>(p.e);
+#pragma unroll
+            for (int f = 0; f < kEF / 2; ++f) {
+                const unsigned w = e2[(size_t)f * p.e_stride + kk];
+                c.raw[2 * f] = __uint_as_float(w << 16);
+                c.raw[2 * f + 1] = __uint_as_float(w & 0xFFFF0000u);
+            }
         } else {
 #pragma unroll
             for (int f = 0; f < kEF; ++f) c.raw[f] = p.e[(size_t)f * p.e_stride + kk];
@@ -139,8 +148,20 @@ __global__ __launch_bounds__(256) void mpn_step_fast_kernel(const StepParams p) 
             en[f] = fmaxf(s, 0.f);
         }
         if (p.store_e && valid) {
+            if (EBF16) {
+                unsigned* __restrict__ e2 = reinterpret_cast<unsigned*>(p.e);
 #pragma unroll
-            for (int f = 0; f < kEF; ++f) p.e[(size_t)f * p.e_stride + k] = en[f];
+                for (int f = 0; f < kEF / 2; ++f) {
+                    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+                    bf16x2_t pk;  // round to nearest even (v_cvt_pk_bf16_f32)
+                    pk[0] = (__bf16)en[2 * f];
+                    pk[1] = (__bf16)en[2 * f + 1];
+                    e2[(size_t)f * p.e_stride + k] = __builtin_bit_cast(unsigned, pk);
+                }
+            } else {
+#pragma unroll
+                for (int f = 0; f < kEF; ++f) p.e[(size_t)f * p.e_stride + k] = en[f];
+            }
         }
         if (CLS) {
             float logit = cw[kFcCb2];
@@ -228,13 +249,18 @@ __global__ __launch_bounds__(256) void mpn_step_fast_kernel(const StepParams p) 
     GNNCCA_STAMP(p.stamp_slot, 7);
 }
 
-template <bool FIRST, bool CLS, bool MSG, bool PDL>
-static hipError_t launch_fast(const StepParams& sp, hipStream_t st) {
+template <bool FIRST, bool CLS, bool MSG, bool PDL, bool EB>
+static hipError_t launch_fast_t(const StepParams& sp, hipStream_t st) {
     const int npg = 4 / sp.wps;
     const unsigned blocks = (unsigned)((sp.N + npg - 1) / npg);
     const size_t lds = ((MSG ? (size_t)kH * kProjOut : 0) + 4 * kH + (PDL ? (size_t)sp.N * kPdStride : 0)) * sizeof(float);
-    hipLaunchKernelGGL((mpn_step_fast_kernel<FIRST, CLS, MSG, PDL>), dim3(blocks), dim3(256), lds, st, sp);
+    hipLaunchKernelGGL((mpn_step_fast_kernel<FIRST, CLS, MSG, PDL, EB>), dim3(blocks), dim3(256), lds, st, sp);
     return hipGetLastError();
+}
+
+template <bool FIRST, bool CLS, bool MSG, bool PDL>
+static hipError_t launch_fast(const StepParams& sp, hipStream_t st) {
+    return sp.e_bf16 ? launch_fast_t<FIRST, CLS, MSG, PDL, true>(sp, st) : launch_fast_t<FIRST, CLS, MSG, PDL, false>(sp, st);
 }
 
 static hipError_t launch_fast_dispatch(const StepParams& sp, bool msg, hipStream_t st) {

@@ -40,7 +40,7 @@ struct StepParams {
     int off_wee, off_wneb, off_projwT, off_projb, off_encw, off_encb, off_cw1, off_cb1, off_cw2, off_cb2;
     int off_fast;
     int cls_layers, cls_hidden;  // cls_layers == 0: this step does not classify
-    int N, E, edge_in, attr_vec, first, update, agg, reatt_n, wps, store_e, hin, pd_lds, stamp_slot;
+    int N, E, edge_in, attr_vec, first, update, agg, reatt_n, wps, store_e, hin, pd_lds, stamp_slot, e_bf16;
 };
 
 template <bool REATT_E, bool MSG, bool AGG_MAX>

@@ -141,6 +141,14 @@ class MOTMPNet(nn.Module):
         self._workspace = None     # grow-only device scratch
         self._weights_dirty = True
         self.last_workspace_bytes = 0
+        # 'fp32' (default: bit-faithful to the reference within summation order) or 'bf16': the edge latents are kept
+        # as bf16 in HBM between steps (GNNCCA_OPT_EDGE_STATE_BF16); arithmetic stays fp32
+        self.edge_state_dtype = 'fp32'
+
+    def _options(self):
+        if self.edge_state_dtype not in ('fp32', 'bf16'):
+            raise ValueError("edge_state_dtype must be 'fp32' or 'bf16'")
+        return nat.OPT_EDGE_STATE_BF16 if self.edge_state_dtype == 'bf16' else 0
 
     # -- construction --------------------------------------------------------------------------------------
     def _build_core_MPNet(self, model_params, encoder_feats_dict):
@@ -322,9 +330,9 @@ class MOTMPNet(nn.Module):
                                    trace['h_steps'].data_ptr(), trace['e_steps'].data_ptr()))
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
-            st = lib.gnncca_mpn_forward(C.byref(d), blob.data_ptr(), x.data_ptr(), edge_index.data_ptr(),
-                                        edge_attr.data_ptr(), n, e, ws.data_ptr(), ws.numel(), logits.data_ptr(), tr,
-                                        stream)
+            st = lib.gnncca_mpn_forward_ex(C.byref(d), blob.data_ptr(), x.data_ptr(), edge_index.data_ptr(),
+                                           edge_attr.data_ptr(), n, e, ws.data_ptr(), ws.numel(), logits.data_ptr(), tr,
+                                           self._options(), stream)
         nat.check(st, "gnncca_mpn_forward")
         return logits
 
@@ -335,6 +343,7 @@ class MOTMPNet(nn.Module):
         if ws is None:
             return {'classified_edges': list(logits.unbind(0))}, []
         prof = nat.Profile()
+        prof.options = self._options()
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
             st = lib.gnncca_mpn_forward_profiled(C.byref(d), blob.data_ptr(), x.data_ptr(), edge_index.data_ptr(),

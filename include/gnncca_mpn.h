@@ -139,6 +139,7 @@ GNNCCA_API int gnncca_mpn_forward(const gnncca_mpn_dims* dims, const void* packe
 enum { GNNCCA_K_PLAN_ROWS = 0, GNNCCA_K_PLAN_SORT = 1, GNNCCA_K_ENC_GEMM = 2, GNNCCA_K_ENC_REDUCE = 3,
        GNNCCA_K_ENC_TAIL = 4, GNNCCA_K_STEP = 5, GNNCCA_K_STEP_LAST = 6 };
 typedef struct gnncca_profile {
+    uint32_t options;                   /* in: GNNCCA_OPT_* for the profiled forward */
     int32_t count;                      /* launches recorded */
     int32_t kind[GNNCCA_PROFILE_MAX];   /* GNNCCA_K_* */
     float ms[GNNCCA_PROFILE_MAX];       /* hipEventElapsedTime between the events before / after the launch */
@@ -147,6 +148,16 @@ GNNCCA_API int gnncca_mpn_forward_profiled(const gnncca_mpn_dims* dims, const vo
                                 const int64_t* edge_index, const float* edge_attr, int64_t n_nodes,
                                 int64_t n_edges, void* workspace, size_t workspace_bytes, float* logits_out,
                                 gnncca_stream_t stream, gnncca_profile* profile);
+
+/* gnncca_mpn_forward with options.  GNNCCA_OPT_EDGE_STATE_BF16: keep the edge latents BETWEEN steps as bf16 in HBM
+ * (round to nearest even; all arithmetic, the classifier input and every other buffer stay fp32) -- halves the
+ * dominant traffic of the step kernels; honoured by the specialised kernels (shipped config shape), ignored elsewhere.
+ * Measured effect on the logits: DESIGN.md section 5. */
+#define GNNCCA_OPT_EDGE_STATE_BF16 1u
+GNNCCA_API int gnncca_mpn_forward_ex(const gnncca_mpn_dims* dims, const void* packed_dev, const float* x,
+                                     const int64_t* edge_index, const float* edge_attr, int64_t n_nodes,
+                                     int64_t n_edges, void* workspace, size_t workspace_bytes, float* logits_out,
+                                     const gnncca_trace* trace, uint32_t options, gnncca_stream_t stream);
 
 /* len(outputs['classified_edges']) for these dims (mpn.py:277-297). */
 GNNCCA_API int gnncca_num_outputs(const gnncca_mpn_dims* dims);
