@@ -1,0 +1,120 @@
+"""Randomised differential test on the GPU: many small random graphs (empty segments, isolated nodes, self loops,
+duplicate edges, degrees straddling the 64-edge chunk size, unsorted rows) x random options of the shipped config family,
+each compared against the CPU oracle.  One process, one model per option set."""
+import copy
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN_DIR
+from oracle.mpn_oracle import NumpyOracle, load_case
+
+pytestmark = pytest.mark.gpu
+
+
+class Data:
+    def __init__(self, x, ei, ea):
+        self.x, self.edge_index, self.edge_attr = x, ei, ea
+
+
+def random_graph(rng, kind):
+    if kind == "chunks":  # one hub whose out-degree sits right at a chunk boundary, plus noise
+        deg = int(rng.choice([1, 63, 64, 65, 127, 128, 129, 191, 192, 193, 255, 256, 257]))
+        n = deg + int(rng.integers(2, 6))
+        rows = [np.zeros(deg, np.int64)]
+        cols = [rng.permutation(n - 1)[:deg] + 1]
+        extra = int(rng.integers(0, 40))
+        rows.append(rng.integers(0, n, extra))
+        cols.append(rng.integers(0, n, extra))
+        ei = np.stack([np.concatenate(rows), np.concatenate(cols)])
+        ei = ei[:, np.argsort(ei[0], kind="stable")]
+    elif kind == "sparse":  # most nodes have no out-edges
+        n = int(rng.integers(2, 70))
+        e = int(rng.integers(1, 50))
+        ei = np.stack([rng.integers(0, max(1, n // 3), e), rng.integers(0, n, e)])
+        ei = ei[:, np.argsort(ei[0], kind="stable")]
+    elif kind == "unsorted":
+        n = int(rng.integers(2, 50))
+        e = int(rng.integers(1, 400))
+        ei = np.stack([rng.integers(0, n, e), rng.integers(0, n, e)])
+    else:  # cross-camera union of frames of random shape
+        frames = int(rng.integers(1, 5))
+        rows, cols, off = [], [], 0
+        for _ in range(frames):
+            cams = rng.integers(1, 5, size=int(rng.integers(2, 5)))
+            cam_of = np.repeat(np.arange(len(cams)), cams)
+            idx = np.arange(len(cam_of)) + off
+            i, j = np.meshgrid(idx, idx, indexing="ij")
+            m = cam_of[i - off] != cam_of[j - off]
+            rows.append(i[m])
+            cols.append(j[m])
+            off += len(cam_of)
+        n = off
+        ei = np.stack([np.concatenate(rows), np.concatenate(cols)])
+    return n, ei.astype(np.int64)
+
+
+@pytest.mark.parametrize("agg,L,n_cls,bf16", [("sum", 4, 3, False), ("mean", 3, 3, False), ("max", 2, 1, False),
+                                               ("sum", 5, 2, True), ("sum", 1, 3, False)])
+def test_random_graphs_vs_oracle(agg, L, n_cls, bf16):
+    from gnn_cca_amd import MOTMPNet
+    params, arch, sd, _ = load_case(os.path.join(GOLDEN_DIR, "n8_sum.npz"))  # node_in 64
+    params = copy.deepcopy(params)
+    params.update(node_agg_fn=agg, num_enc_steps=L, num_class_steps=n_cls)
+    sd = dict(sd)
+    if agg != "sum":  # golden n8_sum scales the node MLP for 'sum'; undo for mean / max
+        for k in list(sd):
+            if k.startswith("MPNet.node_model"):
+                sd[k] = (sd[k] * np.float32(4.0)).astype(np.float32)
+    m = MOTMPNet(copy.deepcopy(params), None, arch)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    m = m.cuda().eval()
+    m.edge_state_dtype = "bf16" if bf16 else "fp32"
+    orc = NumpyOracle(params, arch, sd, np.float32)
+    import zlib
+    rng = np.random.default_rng(zlib.crc32(repr((agg, L, n_cls, bf16)).encode()))
+    worst = 0.0
+    for it in range(60):
+        n, ei = random_graph(rng, ["chunks", "sparse", "unsorted", "frames"][it % 4])
+        x = (rng.standard_normal((n, 64)) * 0.3).astype(np.float32)
+        ea = rng.random((ei.shape[1], 4)).astype(np.float32)
+        ref = orc.forward(x, ei, ea)
+        with torch.no_grad():
+            out = m(Data(torch.from_numpy(x).cuda(), torch.from_numpy(ei).cuda(), torch.from_numpy(ea).cuda()))
+        scale = max(1.0, max(float(np.abs(r).max()) for r in ref))
+        for o, r in zip(out["classified_edges"], ref):
+            assert o.shape == r.shape
+            err = float(np.abs(o.cpu().numpy() - r).max()) / scale
+            worst = max(worst, err)
+            assert err <= (1e-4 if bf16 else 2e-5), (it, n, ei.shape, err)
+    print(f"fuzz agg={agg} L={L} bf16={bf16}: worst relative deviation {worst:.2e}")
+
+
+def test_config5_size_vs_oracle():
+    """BASELINE config 5: dense 1024-node graph (1 047 552 edges), L = 8, against the CPU oracle at full size."""
+    from gnn_cca_amd import MOTMPNet
+    params, arch, sd, _ = load_case(os.path.join(GOLDEN_DIR, "dense64.npz"))
+    params = copy.deepcopy(params)
+    params.update(num_enc_steps=8)
+    sd = dict(sd)
+    for k in list(sd):
+        if k.startswith("MPNet.node_model"):
+            sd[k] = (sd[k] * np.float32(63.0 / 1023.0)).astype(np.float32)
+    n = 1024
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((n, 2048)).astype(np.float32)
+    x /= np.linalg.norm(x, axis=0, keepdims=True)
+    i, j = np.meshgrid(np.arange(n), np.arange(n), indexing="ij")
+    keep = i != j
+    ei = np.stack([i[keep], j[keep]]).astype(np.int64)
+    ea = rng.random((ei.shape[1], 4)).astype(np.float32)
+    ref = NumpyOracle(params, arch, sd, np.float32).forward(x, ei, ea)
+    m = MOTMPNet(copy.deepcopy(params), None, arch)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    m = m.cuda().eval()
+    with torch.no_grad():
+        out = m(Data(torch.from_numpy(x).cuda(), torch.from_numpy(ei).cuda(), torch.from_numpy(ea).cuda()))
+    for o, r in zip(out["classified_edges"], ref):
+        assert np.abs(o.cpu().numpy() - r).max() <= 2e-5
