@@ -71,6 +71,11 @@ struct BwdEdgeParams {
     float* gbc1;
     float* gWc2;
     float* gbc2;
+    // train-mode BatchNorm between the classifier's two layers (null when it has none): per hidden unit q
+    const float* bn_gamma;
+    const float* bn_stat;  // [C1][2] batch mean, 1/sqrt(batch var + eps) of this step's pre-activation
+    const float* bn_red;   // [C1][2] mean over edges of g_y and of g_y * z_hat (from bwd_cls_bn_reduce_kernel)
+    const float* bn_beta;
     long long E;
     int N, cls_hidden;     // cls_hidden == 0: single Linear(6,1)
 };
@@ -91,7 +96,25 @@ __global__ __launch_bounds__(256) void bwd_edge_kernel(const BwdEdgeParams p) {
     // ---- classifier ------------------------------------------------------------------------------------------
     if (p.g_logit) {
         const float dz = p.g_logit[k] * live;
-        if (p.cls_hidden > 0) {
+        if (p.cls_hidden > 0 && p.bn_stat) {
+            // Linear -> BatchNorm(batch statistics) -> ReLU -> Linear.  d W2, d b2, d gamma, d beta were formed by
+            // bwd_cls_bn_reduce_kernel; here: g_z = gamma * invstd * (g_y - mean(g_y) - z_hat * mean(g_y z_hat))
+            for (int q = 0; q < p.cls_hidden; ++q) {
+                float z1 = p.bc1[q];
+#pragma unroll
+                for (int f = 0; f < kEF; ++f) z1 = fmaf(p.Wc1[q * kEF + f], es[f], z1);
+                const float zh = (z1 - p.bn_stat[2 * q]) * p.bn_stat[2 * q + 1];
+                const float y = fmaf(p.bn_gamma[q], zh, p.bn_beta[q]);
+                const float gy = y > 0.f ? p.Wc2[q] * dz : 0.f;
+                const float gz1 = live * p.bn_gamma[q] * p.bn_stat[2 * q + 1] * (gy - p.bn_red[2 * q] - zh * p.bn_red[2 * q + 1]);
+                wave_atomic_add(p.gbc1 + q, gz1);
+#pragma unroll
+                for (int f = 0; f < kEF; ++f) {
+                    wave_atomic_add(p.gWc1 + q * kEF + f, gz1 * es[f]);
+                    ge[f] = fmaf(p.Wc1[q * kEF + f], gz1, ge[f]);
+                }
+            }
+        } else if (p.cls_hidden > 0) {
             float db2 = dz;
             wave_atomic_add(p.gbc2, db2);
             for (int q = 0; q < p.cls_hidden; ++q) {
@@ -156,6 +179,115 @@ __global__ __launch_bounds__(256) void bwd_edge_kernel(const BwdEdgeParams p) {
             p.ge_out[k * kEF + g] = s;
         }
     }
+}
+
+// ---- classifier with train-mode BatchNorm1d (models/mlp.py:15, batch statistics over all E edges) ------------------
+__device__ __forceinline__ double wave_reduce_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// sums[q] += sum_k z, sums[C1 + q] += sum_k z^2   with z = W1 e + b1   (double accumulation)
+__global__ __launch_bounds__(256) void cls_bn_stats_kernel(const float* __restrict__ e, long long E, const float* __restrict__ W1,
+                                                           const float* __restrict__ b1, int C1, double* __restrict__ sums) {
+    const long long k0 = (long long)blockIdx.x * 256 + threadIdx.x;
+    const bool valid = k0 < E;
+    const long long k = valid ? k0 : E - 1;
+    float es[kEF];
+#pragma unroll
+    for (int f = 0; f < kEF; ++f) es[f] = e[k * kEF + f];
+    for (int q = 0; q < C1; ++q) {
+        float z = b1[q];
+#pragma unroll
+        for (int f = 0; f < kEF; ++f) z = fmaf(W1[q * kEF + f], es[f], z);
+        const double zd = valid ? (double)z : 0.0;
+        const double s1 = wave_reduce_sum_d(zd), s2 = wave_reduce_sum_d(zd * zd);
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(&sums[q], s1);
+            atomicAdd(&sums[C1 + q], s2);
+        }
+    }
+}
+
+// stat[q] = (mean, 1/sqrt(biased var + eps)); running buffers updated like torch.nn.BatchNorm1d (momentum 0.1, unbiased var)
+__global__ void cls_bn_finalize_kernel(const double* __restrict__ sums, long long E, int C1, float* __restrict__ stat,
+                                       float* __restrict__ running_mean, float* __restrict__ running_var) {
+    const int q = threadIdx.x;
+    if (q >= C1) return;
+    const double mean = sums[q] / (double)E;
+    double var = sums[C1 + q] / (double)E - mean * mean;
+    if (var < 0.0) var = 0.0;
+    stat[2 * q] = (float)mean;
+    stat[2 * q + 1] = (float)(1.0 / sqrt(var + 1e-5));
+    if (running_mean) {
+        const double unbiased = E > 1 ? var * (double)E / (double)(E - 1) : var;
+        running_mean[q] = (float)(0.9 * (double)running_mean[q] + 0.1 * mean);
+        running_var[q] = (float)(0.9 * (double)running_var[q] + 0.1 * unbiased);
+    }
+}
+
+__global__ __launch_bounds__(256) void cls_bn_apply_kernel(const float* __restrict__ e, long long E, const float* __restrict__ W1,
+                                                           const float* __restrict__ b1, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, const float* __restrict__ stat,
+                                                           const float* __restrict__ W2, const float* __restrict__ b2, int C1,
+                                                           float* __restrict__ logits) {
+    const long long k = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (k >= E) return;
+    float es[kEF];
+#pragma unroll
+    for (int f = 0; f < kEF; ++f) es[f] = e[k * kEF + f];
+    float logit = b2[0];
+    for (int q = 0; q < C1; ++q) {
+        float z = b1[q];
+#pragma unroll
+        for (int f = 0; f < kEF; ++f) z = fmaf(W1[q * kEF + f], es[f], z);
+        const float y = fmaf(gamma[q], (z - stat[2 * q]) * stat[2 * q + 1], beta[q]);
+        logit = fmaf(W2[q], fmaxf(y, 0.f), logit);
+    }
+    logits[k] = logit;
+}
+
+// backward reductions of the BN classifier: sums[q] += sum g_y, sums[C1+q] += sum g_y z_hat; d W2, d b2 directly
+__global__ __launch_bounds__(256) void bwd_cls_bn_reduce_kernel(const float* __restrict__ e, const float* __restrict__ g_logit,
+                                                                long long E, const float* __restrict__ W1, const float* __restrict__ b1,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                const float* __restrict__ stat, const float* __restrict__ W2, int C1,
+                                                                double* __restrict__ sums, float* __restrict__ gW2,
+                                                                float* __restrict__ gb2) {
+    const long long k0 = (long long)blockIdx.x * 256 + threadIdx.x;
+    const bool valid = k0 < E;
+    const long long k = valid ? k0 : E - 1;
+    float es[kEF];
+#pragma unroll
+    for (int f = 0; f < kEF; ++f) es[f] = e[k * kEF + f];
+    const float dz = valid ? g_logit[k] : 0.f;
+    wave_atomic_add(gb2, dz);
+    for (int q = 0; q < C1; ++q) {
+        float z = b1[q];
+#pragma unroll
+        for (int f = 0; f < kEF; ++f) z = fmaf(W1[q * kEF + f], es[f], z);
+        const float zh = (z - stat[2 * q]) * stat[2 * q + 1];
+        const float y = fmaf(gamma[q], zh, beta[q]);
+        wave_atomic_add(gW2 + q, dz * fmaxf(y, 0.f));
+        const double gy = y > 0.f ? (double)(W2[q] * dz) : 0.0;
+        const double s1 = wave_reduce_sum_d(gy), s2 = wave_reduce_sum_d(gy * (double)zh);
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(&sums[q], s1);
+            atomicAdd(&sums[C1 + q], s2);
+        }
+    }
+}
+
+// red[q] = (mean g_y, mean g_y z_hat);  d beta = sum g_y, d gamma = sum g_y z_hat (accumulated over the classified steps)
+__global__ void bwd_cls_bn_finalize_kernel(const double* __restrict__ sums, long long E, int C1, float* __restrict__ red,
+                                           float* __restrict__ g_gamma, float* __restrict__ g_beta) {
+    const int q = threadIdx.x;
+    if (q >= C1) return;
+    red[2 * q] = (float)(sums[q] / (double)E);
+    red[2 * q + 1] = (float)(sums[C1 + q] / (double)E);
+    g_beta[q] += (float)sums[q];
+    g_gamma[q] += (float)sums[C1 + q];
 }
 
 // d h_{s-1}[i][c] = sum_f W_src[f][c] dP_src[i][f] + W_dst[f][c] dP_dst[i][f] + sum_o W_nx[o][c] dQ[i][o]

@@ -405,10 +405,56 @@ static bool backward_ok(const gnncca_mpn_dims* d) {
     if (d->reattach_nodes || d->reattach_edges || d->agg == GNNCCA_AGG_MAX || d->num_enc_steps < 1) return false;
     if (d->enc_node.n_layers != 2) return false;
     const gnncca_mlp* all[5] = {&d->enc_node, &d->enc_edge, &d->edge_mlp, &d->node_mlp, &d->cls_edge};
-    for (const gnncca_mlp* m : all)
-        for (int l = 0; l < m->n_layers; ++l)
-            if (m->layers[l].has_bn) return false;
-    return true;
+    for (int mi = 0; mi < 5; ++mi)
+        for (int l = 0; l < all[mi]->n_layers; ++l)
+            if (all[mi]->layers[l].has_bn && !(mi == 4 && l == 0 && d->cls_edge.n_layers == 2)) return false;
+    return true;  // BatchNorm is allowed only between the classifier's two layers (the shipped inference config)
+}
+
+// index of the first tensor of layer `l` of MLP `mi` in the canonical parameter order
+static int param_index(const gnncca_mpn_dims* d, int mi, int l) {
+    int idx = 0;
+    for (int m = 0; m < 5; ++m) {
+        const gnncca_mlp& mlp = mlp_by_index(d, m);
+        for (int k = 0; k < mlp.n_layers; ++k) {
+            if (m == mi && k == l) return idx;
+            idx += 2 + (mlp.layers[k].has_bn ? 4 : 0);
+        }
+    }
+    return idx;
+}
+
+// Train-mode classifier with BatchNorm1d between its two layers: batch statistics over the E edges for every
+// classified step (models/mpn.py:290-293 with models/mlp.py:15 in train mode); running buffers updated in place.
+int gnncca_classifier_train(const gnncca_mpn_dims* d, const float* const* params_dev, int n_params, const float* e_steps,
+                            int64_t n_edges, void* scratch /* 2*C1 doubles */, float* bn_stat_out /* [n_out][C1][2] */,
+                            float* logits_out, gnncca_stream_t stream) {
+    if (!dims_valid(d) || !params_dev || n_params != gnncca_param_count(d) || n_edges < 0) return GNNCCA_ERR_INVALID_ARG;
+    if (!backward_ok(d) || d->cls_edge.n_layers != 2 || !d->cls_edge.layers[0].has_bn) return GNNCCA_ERR_UNSUPPORTED;
+    if (n_edges == 0) return GNNCCA_OK;
+    if (!e_steps || !scratch || !bn_stat_out || !logits_out) return GNNCCA_ERR_INVALID_ARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int C1 = d->cls_edge.layers[0].out_dim, L = d->num_enc_steps, first_cls = L - d->num_class_steps + 1;
+    const int pc = param_index(d, 4, 0);
+    const float *W1 = params_dev[pc], *b1 = params_dev[pc + 1], *gamma = params_dev[pc + 2], *beta = params_dev[pc + 3];
+    float *rm = const_cast<float*>(params_dev[pc + 4]), *rv = const_cast<float*>(params_dev[pc + 5]);
+    const float *W2 = params_dev[pc + 6], *b2 = params_dev[pc + 7];
+    const long long E = n_edges;
+    double* sums = static_cast<double*>(scratch);
+    int li = 0;
+    for (int s = 1; s <= L; ++s) {
+        if (s < first_cls) continue;
+        const float* e = e_steps + (size_t)(s - 1) * E * kEF;
+        float* stat = bn_stat_out + (size_t)li * C1 * 2;
+        HIP_TRY(hipMemsetAsync(sums, 0, sizeof(double) * 2 * C1, st));
+        hipLaunchKernelGGL(cls_bn_stats_kernel, grid1((size_t)E, 256), dim3(256), 0, st, e, E, W1, b1, C1, sums);
+        hipLaunchKernelGGL(cls_bn_finalize_kernel, dim3(1), dim3(64), 0, st, (const double*)sums, E, C1, stat, rm, rv);
+        hipLaunchKernelGGL(cls_bn_apply_kernel, grid1((size_t)E, 256), dim3(256), 0, st, e, E, W1, b1, gamma, beta, (const float*)stat,
+                           W2, b2, C1, logits_out + (size_t)li * E);
+        HIP_TRY(hipGetLastError());
+        ++li;
+    }
+    return GNNCCA_OK;
 }
 
 int gnncca_backward_supported(const gnncca_mpn_dims* d) {
@@ -421,13 +467,13 @@ size_t gnncca_backward_workspace_bytes(const gnncca_mpn_dims* d, int64_t n_nodes
     const size_t N = (size_t)n_nodes, E = (size_t)n_edges, F1 = (size_t)d->enc_node.layers[0].out_dim;
     auto up = [](size_t v) { return (v + 255) / 256 * 256; };
     return up(N * 4) + up(N * kH * 4) + up(N * 44 * 4) + 2 * up(N * kH * 4) + 2 * up(E * kEF * 4) + 2 * up(N * F1 * 4) +
-           up(32 * N * F1 * 4);
+           up(32 * N * F1 * 4) + up(sizeof(double) * 128) + up(sizeof(float) * 128);
 }
 
 int gnncca_mpn_backward(const gnncca_mpn_dims* d, const float* const* params_dev, int n_params, const float* x,
                         const int64_t* edge_index, const float* edge_attr, int64_t n_nodes, int64_t n_edges,
-                        const gnncca_trace* saved, const float* grad_logits, float* const* grads_dev, void* workspace,
-                        size_t workspace_bytes, gnncca_stream_t stream) {
+                        const gnncca_trace* saved, const float* cls_bn_stat, const float* grad_logits,
+                        float* const* grads_dev, void* workspace, size_t workspace_bytes, gnncca_stream_t stream) {
     if (!dims_valid(d) || n_nodes < 0 || n_edges < 0) return GNNCCA_ERR_INVALID_ARG;
     if (!backward_ok(d)) return GNNCCA_ERR_UNSUPPORTED;
     if (n_params != gnncca_param_count(d) || !params_dev || !grads_dev) return GNNCCA_ERR_INVALID_ARG;
@@ -447,6 +493,8 @@ int gnncca_mpn_backward(const gnncca_mpn_dims* d, const float* const* params_dev
             for (int l = 0; l < m->n_layers; ++l) {
                 HIP_TRY(hipMemsetAsync(grads_dev[pi++], 0, (size_t)m->layers[l].in_dim * m->layers[l].out_dim * 4, st));
                 HIP_TRY(hipMemsetAsync(grads_dev[pi++], 0, (size_t)m->layers[l].out_dim * 4, st));
+                if (m->layers[l].has_bn)  // gamma, beta, and the two buffers (no gradient: left at zero)
+                    for (int k = 0; k < 4; ++k) HIP_TRY(hipMemsetAsync(grads_dev[pi++], 0, (size_t)m->layers[l].out_dim * 4, st));
             }
     }
     if (N == 0 || E == 0) return GNNCCA_OK;
@@ -468,11 +516,16 @@ int gnncca_mpn_backward(const gnncca_mpn_dims* d, const float* const* params_dev
     float* part = reinterpret_cast<float*>(take((size_t)32 * N * F1 * 4));  // split-K partials of the a1 recompute
     const float *W1 = params_dev[0], *b1 = params_dev[1], *W2 = params_dev[2];
     const float *We = params_dev[6], *Wn = params_dev[8], *bn = params_dev[9];
-    const float *Wc1 = params_dev[10], *bc1 = params_dev[11], *Wc2 = c1 ? params_dev[12] : nullptr;
+    const bool cls_bn = d->cls_edge.layers[0].has_bn != 0;
+    if (cls_bn && !cls_bn_stat) return GNNCCA_ERR_INVALID_ARG;
+    const int pw2 = cls_bn ? 16 : 12;  // second classifier layer follows the four BatchNorm tensors
+    const float *Wc1 = params_dev[10], *bc1 = params_dev[11], *Wc2 = c1 ? params_dev[pw2] : nullptr;
     float *gW1 = grads_dev[0], *gb1 = grads_dev[1], *gW2 = grads_dev[2], *gb2 = grads_dev[3];
     float *gWe0 = grads_dev[4], *gbe0 = grads_dev[5], *gWe = grads_dev[6], *gbe = grads_dev[7];
     float *gWn = grads_dev[8], *gbn = grads_dev[9], *gWc1 = grads_dev[10], *gbc1 = grads_dev[11];
-    float *gWc2 = c1 ? grads_dev[12] : nullptr, *gbc2 = c1 ? grads_dev[13] : nullptr;
+    float *gWc2 = c1 ? grads_dev[pw2] : nullptr, *gbc2 = c1 ? grads_dev[pw2 + 1] : nullptr;
+    double* bn_sums = reinterpret_cast<double*>(take(sizeof(double) * 2 * 64));
+    float* bn_red = reinterpret_cast<float*>(take(sizeof(float) * 2 * 64));
     const long long* ei = reinterpret_cast<const long long*>(edge_index);
     const int chunksN = (N + 255) / 256;
     if (d->agg == GNNCCA_AGG_MEAN) {
@@ -500,7 +553,21 @@ int gnncca_mpn_backward(const gnncca_mpn_dims* d, const float* const* params_dev
         bp.Q = Q;
         bp.g_h = g_h;
         bp.deg = d->agg == GNNCCA_AGG_MEAN ? deg : nullptr;
-        bp.g_logit = s >= first_cls ? grad_logits + (size_t)(out_idx--) * E : nullptr;
+        bp.g_logit = s >= first_cls ? grad_logits + (size_t)out_idx * E : nullptr;
+        if (bp.g_logit && cls_bn) {  // reductions the BatchNorm backward needs before any per-edge gradient
+            const float* stat = cls_bn_stat + (size_t)out_idx * c1 * 2;
+            HIP_TRY(hipMemsetAsync(bn_sums, 0, sizeof(double) * 2 * c1, st));
+            hipLaunchKernelGGL(bwd_cls_bn_reduce_kernel, grid1((size_t)E, 256), dim3(256), 0, st, e_cur, bp.g_logit, (long long)E, Wc1,
+                               bc1, params_dev[12], params_dev[13], stat, Wc2, c1, bn_sums, gWc2, gbc2);
+            hipLaunchKernelGGL(bwd_cls_bn_finalize_kernel, dim3(1), dim3(64), 0, st, (const double*)bn_sums, (long long)E, c1, bn_red,
+                               grads_dev[12], grads_dev[13]);
+            HIP_TRY(hipGetLastError());
+            bp.bn_gamma = params_dev[12];
+            bp.bn_beta = params_dev[13];
+            bp.bn_stat = stat;
+            bp.bn_red = bn_red;
+        }
+        if (bp.g_logit) --out_idx;
         bp.ge_in = ge_in;
         bp.ge_out = Gb[s & 1];
         bp.dP = dP;

@@ -72,16 +72,32 @@ class _MPNTrainFunction(torch.autograd.Function):
         trace = {}
         with torch.no_grad():
             out = module._forward_native(x, edge_index, edge_attr, trace)
+            bn_stat = torch.zeros(1, dtype=torch.float32, device=x.device)
+            bn = module._classifier_batchnorm()
+            if bn is not None and edge_index.shape[1] > 0:
+                # BatchNorm1d in train mode: the logits are recomputed from the saved edge latents with batch statistics
+                lib, d = nat.lib(), module.native_dims()
+                n_out, c1, e = out.shape[0], bn.num_features, edge_index.shape[1]
+                bn_stat = torch.empty((n_out, c1, 2), dtype=torch.float32, device=x.device)
+                scratch = torch.empty(2 * c1, dtype=torch.float64, device=x.device)
+                pp = (C.c_void_p * len(params))(*[p.data_ptr() for p in params])
+                with torch.cuda.device(x.device):
+                    st = lib.gnncca_classifier_train(C.byref(d), pp, len(params), trace['e_steps'].data_ptr(), e,
+                                                     scratch.data_ptr(), bn_stat.data_ptr(), out.data_ptr(),
+                                                     torch.cuda.current_stream(x.device).cuda_stream)
+                nat.check(st, "gnncca_classifier_train")
+                bn.num_batches_tracked += n_out  # one BatchNorm call per classified step (models/mpn.py:292)
         ctx.module = module
         ctx.n_params = len(params)
+        ctx.has_bn = bn is not None
         ctx.save_for_backward(x, edge_index, edge_attr, trace['h_enc'], trace['e_enc'], trace['h_steps'], trace['e_steps'],
-                              *params)
+                              bn_stat, *params)
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
-        x, edge_index, edge_attr, h_enc, e_enc, h_steps, e_steps = ctx.saved_tensors[:7]
-        params = ctx.saved_tensors[7:]
+        x, edge_index, edge_attr, h_enc, e_enc, h_steps, e_steps, bn_stat = ctx.saved_tensors[:8]
+        params = ctx.saved_tensors[8:]
         module = ctx.module
         lib, d = nat.lib(), module.native_dims()
         dev = x.device
@@ -94,10 +110,10 @@ class _MPNTrainFunction(torch.autograd.Function):
         saved = nat.Trace(h_enc.data_ptr(), e_enc.data_ptr(), h_steps.data_ptr(), e_steps.data_ptr())
         with torch.cuda.device(dev):
             st = lib.gnncca_mpn_backward(C.byref(d), pp, len(params), x.data_ptr(), edge_index.data_ptr(), edge_attr.data_ptr(),
-                                         n, e, C.byref(saved), g.data_ptr(), gp, ws.data_ptr(), ws.numel(),
-                                         torch.cuda.current_stream(dev).cuda_stream)
+                                         n, e, C.byref(saved), bn_stat.data_ptr() if ctx.has_bn else None, g.data_ptr(), gp,
+                                         ws.data_ptr(), ws.numel(), torch.cuda.current_stream(dev).cuda_stream)
         nat.check(st, "gnncca_mpn_backward")
-        return (None, None, None, None, *grads)
+        return (None, None, None, None, *[gr if p.requires_grad else None for gr, p in zip(grads, params)])
 
 
 def _fill_mlp(dst, mlp):
@@ -281,12 +297,20 @@ class MOTMPNet(nn.Module):
         logits = self._forward_native(data.x, data.edge_index, data.edge_attr, trace)
         return {'classified_edges': list(logits.unbind(0))}
 
+    def _classifier_batchnorm(self):
+        mlp = self.classifier.edge_mlp
+        for bi in (mlp.bn_index if mlp is not None else []):
+            if bi is not None:
+                return mlp.fc_layers[bi]
+        return None
+
     def _check_trainable(self):
         lib, d = nat.lib(), self.native_dims()
         if lib.gnncca_backward_supported(C.byref(d)) != nat.OK:
             raise NotImplementedError(
-                "train-mode forward/backward on the HIP path covers the shipped training shape (no BatchNorm, no reattach "
-                "flags, 'sum'/'mean', two-layer node encoder); this configuration is outside it (SURVEY.md 8f row N3)")
+                "train-mode forward/backward on the HIP path covers the shipped config shapes (BatchNorm nowhere or only "
+                "inside the classifier, no reattach flags, 'sum'/'mean', two-layer node encoder); this configuration is "
+                "outside it (SURVEY.md 8f row N3)")
         for mod in self.modules():
             if isinstance(mod, nn.Dropout) and mod.p > 0:
                 raise NotImplementedError("Dropout with p > 0 in train mode is not implemented on the HIP path")

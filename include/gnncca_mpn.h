@@ -208,9 +208,9 @@ GNNCCA_API int gnncca_post_prune_cluster(const int64_t* edge_index, const int64_
                                          int32_t* labels_out, int32_t* n_clusters_out, gnncca_stream_t stream);
 
 /* ---- backward pass (training through the HIP kernels, train.py:454-494) -----------------
- * Supported (GNNCCA_OK from gnncca_backward_supported): the MFMA family without reattach flags and without BatchNorm,
- * 'sum' / 'mean' aggregation, two-layer node encoder, L >= 1 -- i.e. the shipped TRAINING config
- * (config_training.yaml:94-181).  `saved` holds the latents written by gnncca_mpn_forward's trace taps for the same
+ * Supported (GNNCCA_OK from gnncca_backward_supported): the MFMA family without reattach flags, 'sum' / 'mean'
+ * aggregation, two-layer node encoder, L >= 1, BatchNorm nowhere or only between the classifier's two layers -- i.e.
+ * both shipped config shapes (config_training.yaml:94-181, config_inference.yaml:76-163).  `saved` holds the latents written by gnncca_mpn_forward's trace taps for the same
  * inputs and weights; `params_dev` / `grads_dev` are DEVICE pointers to the raw parameters / their gradients in the
  * canonical order of gnncca_param_count (row-major, un-split, exactly the nn.Parameter layouts).  grads are
  * overwritten.  grad_logits: [n_out][E]. */
@@ -218,9 +218,17 @@ GNNCCA_API int gnncca_backward_supported(const gnncca_mpn_dims* dims);
 GNNCCA_API size_t gnncca_backward_workspace_bytes(const gnncca_mpn_dims* dims, int64_t n_nodes, int64_t n_edges);
 GNNCCA_API int gnncca_mpn_backward(const gnncca_mpn_dims* dims, const float* const* params_dev, int n_params,
                                    const float* x, const int64_t* edge_index, const float* edge_attr, int64_t n_nodes,
-                                   int64_t n_edges, const gnncca_trace* saved, const float* grad_logits,
-                                   float* const* grads_dev, void* workspace, size_t workspace_bytes,
-                                   gnncca_stream_t stream);
+                                   int64_t n_edges, const gnncca_trace* saved, const float* cls_bn_stat,
+                                   const float* grad_logits, float* const* grads_dev, void* workspace,
+                                   size_t workspace_bytes, gnncca_stream_t stream);
+/* Train-mode classifier when a BatchNorm1d sits between its two layers (the shipped inference config): recomputes the
+ * logits of every classified step from the saved edge latents with BATCH statistics over the E edges, updates
+ * running_mean / running_var in place (momentum 0.1, unbiased variance, as torch.nn.BatchNorm1d), and returns per
+ * step and hidden unit (mean, 1/sqrt(var + eps)) in bn_stat_out [n_out][C1][2] for gnncca_mpn_backward (cls_bn_stat).
+ * scratch: 2 * C1 doubles. */
+GNNCCA_API int gnncca_classifier_train(const gnncca_mpn_dims* dims, const float* const* params_dev, int n_params,
+                                       const float* e_steps, int64_t n_edges, void* scratch, float* bn_stat_out,
+                                       float* logits_out, gnncca_stream_t stream);
 
 /* Synchronises `stream` and returns the flag word of the last forward that used `workspace`. */
 GNNCCA_API int gnncca_read_graph_flags(const void* workspace, uint32_t* flags_out, gnncca_stream_t stream);

@@ -77,11 +77,11 @@ def test_no_cpu_fallback_and_unsupported_train_mode_refused():
     with pytest.raises(RuntimeError):          # CPU tensors: no fallback
         m(D())
     m.train()
-    with pytest.raises(NotImplementedError):   # classifier BatchNorm in train mode is outside the HIP backward
+    with pytest.raises(RuntimeError):          # train mode of a shipped shape: supported, but GPU only
         m(D())
-    m2, _, _, _, _ = _model("bn_off")          # the training config's shape: supported, but still GPU only
+    m2, _, _, _, _ = _model("reattach_n1e1")   # reattach flags are outside the HIP backward: loud refusal
     m2.train()
-    with pytest.raises(RuntimeError):
+    with pytest.raises(NotImplementedError):
         m2(D())
 
 

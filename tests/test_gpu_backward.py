@@ -38,10 +38,6 @@ def test_gradients_match_reference(name):
     params, arch, sd, grads, _, a = load_bwd(name)
     m = build(params, arch, sd)
     d = Data(torch.from_numpy(a["x"]).cuda(), torch.from_numpy(a["edge_index"]).cuda(), torch.from_numpy(a["edge_attr"]).cuda())
-    if name == "cls_bn_train":
-        with pytest.raises(NotImplementedError):  # train-mode BatchNorm is outside the HIP backward: loud, no fallback
-            m(d)
-        return
     out = m(d)
     loss = loss_of(out, torch.from_numpy(a["labels"]).cuda())
     loss.backward()
@@ -55,6 +51,10 @@ def test_gradients_match_reference(name):
         assert g is not None, k
         scale = max(1.0, float(np.abs(ref).max()))
         assert np.abs(g.cpu().numpy() - ref).max() <= 2e-5 * scale, (k, float(np.abs(g.cpu().numpy() - ref).max()))
+    _, _, _, _, after, _ = load_bwd(name)
+    state = m.state_dict()
+    for k, v in after.items():  # BatchNorm buffers after the train-mode forward (cls_bn_train)
+        assert np.abs(state[k].cpu().numpy().astype(np.float64) - v).max() <= 1e-6, k
 
 
 def test_gradients_dense64_default_width_vs_oracle():
