@@ -90,37 +90,35 @@ __global__ __launch_bounds__(256) void enc_gemm_plan_kernel(const EncPlanParams 
 // ------------------------------------------------------------------------------------------------------------
 // Large-N encoder GEMM on the bf16 MFMA pipe with fp32-level accuracy ("split-bf16"):  x = x0 + x1 + x2 and
 // w = w0 + w1 + w2 with bf16 pieces (3 x 8 = 24 mantissa bits, the pieces of w prepared at pack time, those of x
-// on the fly while staging), and  x.w ~= x2w0 + x1w1 + x0w2 + x1w0 + x0w1 + x0w0  -- the dropped terms are
-// <= 2^-24 relative.  Every product of two bf16 values is exact in fp32 and the MFMA accumulates in fp32, so the
-// result differs from an fp32 FMA chain only by rounding of the same order as fp32 itself, while the six
-// v_mfma_f32_32x32x16_bf16 cost 6/16 of the v_mfma_f32_32x32x2_f32 time: the GEMM becomes HBM-bound on the
-// x read (8 KB per node) instead of MFMA-bound.
-// Workgroup = 64 rows x 128 columns, 4 waves as 2 x 2 (32 rows x 64 columns each), K in chunks of 32 through LDS
-// (rows padded to 80 B: conflict-free ds_read_b128); the next chunk's global loads are in flight during the MFMAs.
+// on the fly), and  x.w ~= x2w0 + x1w1 + x0w2 + x1w0 + x0w1 + x0w0  -- the dropped terms are <= 2^-24 relative.
+// Every product of two bf16 values is exact in fp32 and the MFMA accumulates in fp32: measured against fp64 the
+// result is MORE accurate than an fp32 GEMM (1.9e-9 vs 1.4e-7 on the N=64 golden case), while the six
+// v_mfma_f32_32x32x16_bf16 cost 6/16 of the v_mfma_f32_32x32x2_f32 time.  (Keeping only x0w0 + x0w1 + x1w0 would
+// halve the MFMA work again at 1.2e-6 absolute error on the pre-activations -- not taken: accuracy first.)
 // ------------------------------------------------------------------------------------------------------------
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
-template <int WM>  // rows per wave: 32 (workgroup 64 x 128) or 64 (workgroup 128 x 128)
-__global__ __launch_bounds__(256) void enc_gemm_split_kernel(const float* __restrict__ x, const unsigned short* __restrict__ w3,
-                                                             float* __restrict__ out, int M, int K, int O, int kslice) {
-    constexpr int BM = 2 * WM, BN = 128, BK = 32, LDK = 40;  // LDK: padded row length in bf16 elements (80 B)
-    constexpr int RT = WM / 32;                              // 32-row MFMA tiles per wave
-    constexpr int XU = BM * BK / 4 / 256;                    // float4 loads of x per thread per chunk
-    __shared__ __attribute__((aligned(16))) __bf16 xs[3][BM][LDK];
-    __shared__ __attribute__((aligned(16))) __bf16 wsm[3][BN][LDK];
+// ------------------------------------------------------------------------------------------------------------
+// Structure ("direct A"): a wave owns 32 rows x all 128 columns, so its A operand
+// never needs sharing -- x goes global -> registers -> three bf16 fragments (converted once per element) and
+// never touches LDS.  Only the weight tile goes through LDS, double-buffered, ONE barrier per 32-deep chunk:
+//   top of iteration : global loads of the next chunk's W pieces (6 x 16 B per lane) and x (4 x 16 B per lane)
+//   middle           : 2 k-steps x 4 column tiles x 6 MFMAs from the current LDS stage + the A fragments in registers
+//   bottom           : next W -> the other LDS stage, next x -> A fragments (loads had the whole middle to land)
+// Workgroup = 4 waves = 128 rows.  Split-K over blockIdx.y for mid-size batches.
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void enc_gemm_split_direct_kernel(const float* __restrict__ x,
+                                                                    const unsigned short* __restrict__ w3,
+                                                                    float* __restrict__ out, int M, int K, int O, int kslice) {
+    constexpr int BN = 128, BK = 32, LDK = 40;
+    __shared__ __attribute__((aligned(16))) __bf16 wsm[2][3][BN][LDK];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
-    const int row0 = blockIdx.x * BM;
+    const int row0 = blockIdx.x * 128 + wave * 32;
     const int kbeg = blockIdx.y * kslice;
     const size_t plane = (size_t)O * K;
-    int xr[XU], xc[XU];
-#pragma unroll
-    for (int u = 0; u < XU; ++u) {
-        const int idx = tid + 256 * u;
-        xr[u] = idx >> 3;
-        xc[u] = (idx & 7) * 4;
-    }
+    const int h = lane >> 5;
+    const float* __restrict__ xrow = x + (size_t)min(row0 + (lane & 31), M - 1) * K + kbeg + 8 * h;
     int wp[6], wcol[6], wk[6];
 #pragma unroll
     for (int u = 0; u < 6; ++u) {
@@ -129,96 +127,85 @@ __global__ __launch_bounds__(256) void enc_gemm_split_kernel(const float* __rest
         wcol[u] = (idx & 511) >> 2;
         wk[u] = (idx & 3) * 8;
     }
-    f32x4 xreg[XU];
+    f32x4 xreg[4];   // chunk's x: k-step 0 -> [0],[1]; k-step 1 -> [2],[3]   (8 consecutive k each)
     bf16x8 wreg[6];
-    auto load_tile = [&](int kt) {
+    bf16x8 afrag[2][3];
+    auto load_next = [&](int kt) {
 #pragma unroll
-        for (int u = 0; u < XU; ++u) {
-            const int r = min(row0 + xr[u], M - 1);
-            xreg[u] = *reinterpret_cast<const f32x4*>(x + (size_t)r * K + kbeg + kt * BK + xc[u]);
+        for (int ks = 0; ks < 2; ++ks) {
+            xreg[2 * ks] = *reinterpret_cast<const f32x4*>(xrow + kt * BK + ks * 16);
+            xreg[2 * ks + 1] = *reinterpret_cast<const f32x4*>(xrow + kt * BK + ks * 16 + 4);
         }
 #pragma unroll
         for (int u = 0; u < 6; ++u)
             wreg[u] = *reinterpret_cast<const bf16x8*>(w3 + wp[u] * plane + (size_t)wcol[u] * K + kbeg + kt * BK + wk[u]);
     };
-    auto store_tile = [&]() {
+    auto convert_x = [&]() {
 #pragma unroll
-        for (int u = 0; u < XU; ++u) {
-            bf16x4 p0, p1, p2;
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float v = xreg[u][q];
+            for (int q = 0; q < 8; ++q) {
+                const float v = xreg[2 * ks + (q >> 2)][q & 3];
                 const __bf16 h0 = (__bf16)v;
                 const float r1 = v - (float)h0;
                 const __bf16 h1 = (__bf16)r1;
                 const float r2 = r1 - (float)h1;
-                p0[q] = h0;
-                p1[q] = h1;
-                p2[q] = (__bf16)r2;
+                afrag[ks][0][q] = h0;
+                afrag[ks][1][q] = h1;
+                afrag[ks][2][q] = (__bf16)r2;
             }
-            *reinterpret_cast<bf16x4*>(&xs[0][xr[u]][xc[u]]) = p0;
-            *reinterpret_cast<bf16x4*>(&xs[1][xr[u]][xc[u]]) = p1;
-            *reinterpret_cast<bf16x4*>(&xs[2][xr[u]][xc[u]]) = p2;
-        }
-#pragma unroll
-        for (int u = 0; u < 6; ++u) *reinterpret_cast<bf16x8*>(&wsm[wp[u]][wcol[u]][wk[u]]) = wreg[u];
     };
-    f32x16 acc[RT][2];
+    auto store_w = [&](int stage) {
 #pragma unroll
-    for (int r = 0; r < RT; ++r)
+        for (int u = 0; u < 6; ++u) *reinterpret_cast<bf16x8*>(&wsm[stage][wp[u]][wcol[u]][wk[u]]) = wreg[u];
+    };
+    f32x16 acc[4];
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
+    for (int c = 0; c < 4; ++c)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[r][c][i] = 0.f;
+        for (int i = 0; i < 16; ++i) acc[c][i] = 0.f;
     const int nk = min(kslice, K - kbeg) / BK;
-    load_tile(0);
-    store_tile();
+    load_next(0);
+    store_w(0);
+    convert_x();
     __syncthreads();
-    const int k8 = 8 * (lane >> 5);
+    const int k8 = 8 * h;
     for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) load_tile(kt + 1);
+        const int stage = kt & 1;
+        if (kt + 1 < nk) load_next(kt + 1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 a[RT][3], b[2][3];
 #pragma unroll
-            for (int r = 0; r < RT; ++r)
-#pragma unroll
-                for (int p = 0; p < 3; ++p)
-                    a[r][p] = *reinterpret_cast<const bf16x8*>(&xs[p][wr * WM + r * 32 + (lane & 31)][ks * 16 + k8]);
-#pragma unroll
-            for (int c = 0; c < 2; ++c)
+            for (int c = 0; c < 4; ++c) {
+                bf16x8 b[3];
 #pragma unroll
                 for (int p = 0; p < 3; ++p)
-                    b[c][p] = *reinterpret_cast<const bf16x8*>(&wsm[p][wc * 64 + c * 32 + (lane & 31)][ks * 16 + k8]);
-#pragma unroll
-            for (int r = 0; r < RT; ++r)
-#pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    // smallest terms first
-                    acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[r][2], b[c][0], acc[r][c], 0, 0, 0);
-                    acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[r][1], b[c][1], acc[r][c], 0, 0, 0);
-                    acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[r][0], b[c][2], acc[r][c], 0, 0, 0);
-                    acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[r][1], b[c][0], acc[r][c], 0, 0, 0);
-                    acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[r][0], b[c][1], acc[r][c], 0, 0, 0);
-                    acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[r][0], b[c][0], acc[r][c], 0, 0, 0);
-                }
-        }
-        __syncthreads();
-        if (kt + 1 < nk) store_tile();
-        __syncthreads();
-    }
-    float* __restrict__ dst = out + (size_t)blockIdx.y * M * O;  // split-K partial slab
-#pragma unroll
-    for (int r = 0; r < RT; ++r)
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const int col = wc * 64 + c * 32 + (lane & 31);
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int row = row0 + wr * WM + r * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
-                if (row < M) dst[(size_t)row * O + col] = acc[r][c][i];
+                    b[p] = *reinterpret_cast<const bf16x8*>(&wsm[stage][p][c * 32 + (lane & 31)][ks * 16 + k8]);
+                // smallest terms first
+                acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[ks][2], b[0], acc[c], 0, 0, 0);
+                acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[ks][1], b[1], acc[c], 0, 0, 0);
+                acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[ks][0], b[2], acc[c], 0, 0, 0);
+                acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[ks][1], b[0], acc[c], 0, 0, 0);
+                acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[ks][0], b[1], acc[c], 0, 0, 0);
+                acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[ks][0], b[0], acc[c], 0, 0, 0);
             }
         }
+        if (kt + 1 < nk) {
+            store_w(stage ^ 1);
+            convert_x();
+        }
+        __syncthreads();
+    }
+    float* __restrict__ dst = out + (size_t)blockIdx.y * M * O;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int col = c * 32 + (lane & 31);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = row0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+            if (row < M) dst[(size_t)row * O + col] = acc[c][i];
+        }
+    }
 }
 
 // act[M][O] = [ReLU](bias + sum_ks part[ks][M][O]) -- only for encoders deeper than two layers.
@@ -403,6 +390,7 @@ __global__ __launch_bounds__(256) void enc_tail_kernel(const TailParams p) {
     }
     GNNCCA_STAMP(0, 8);
 }
+
 
 
 }  // namespace gnncca

@@ -16,6 +16,8 @@
 //   topology     seg_ptr: [N+1] int32 CSR offsets by source node;  col32 [E] int32 (sorted order)
 // One wave owns (a share of) one source node's contiguous edge segment, so the per-destination reduction needs
 // no atomics and is bitwise reproducible.
+#include <cstdlib>
+
 #include "common.cuh"
 #include "plan.cuh"
 #include "encoder.cuh"
@@ -116,14 +118,10 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
         int ks_split = 1;
         if (split) {  // big batches: split-bf16 MFMA GEMM; the plan gets its own launch
             const unsigned short* w3 = reinterpret_cast<const unsigned short*>(blob + hdr.enc_w3);
-            if (N >= 32768) {  // 128-row workgroups: the weight tile is amortised over twice the rows
-                hipLaunchKernelGGL((enc_gemm_split_kernel<64>), dim3((N + 127) / 128, 1), dim3(256), 0, st, cur_in, w3, part, N,
-                                   K, O, K);
-            } else {           // 64-row workgroups + split-K so that >= 512 workgroups are in flight
-                while (ks_split < ws.ksplit && ((N + 63) / 64) * ks_split < 512 && (K / (ks_split * 2)) % 32 == 0) ks_split *= 2;
-                hipLaunchKernelGGL((enc_gemm_split_kernel<32>), dim3((N + 63) / 64, ks_split), dim3(256), 0, st, cur_in, w3,
-                                   part, N, K, O, K / ks_split);
-            }
+            // 128-row workgroups (a wave = 32 rows x 128 columns); split-K until >= 512 workgroups are in flight
+            while (ks_split < ws.ksplit && ((N + 127) / 128) * ks_split < 512 && (K / (ks_split * 2)) % 32 == 0) ks_split *= 2;
+            hipLaunchKernelGGL(enc_gemm_split_direct_kernel, dim3((N + 127) / 128, ks_split), dim3(256), 0, st, cur_in, w3, part, N,
+                               K, O, K / ks_split);
             HIP_TRY(hipGetLastError());
             PROF_MARK(GNNCCA_K_ENC_GEMM);
         }

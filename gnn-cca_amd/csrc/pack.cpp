@@ -436,9 +436,9 @@ Workspace carve(const gnncca_mpn_dims* d, int64_t n, int64_t e) {
     const size_t row_tiles = (N + 31) / 32;
     int ks = 1;
     while (ks < 32 && row_tiles * (size_t)ks < 512 && k0 / (ks * 2) >= 64) ks *= 2;
-    // mid-size batches run the split-bf16 GEMM with 64-row workgroups: room for its split-K factor too
-    if (N >= 4096 && N < 32768)
-        while (ks < 8 && ((N + 63) / 64) * (size_t)ks < 512 && k0 / (ks * 2) >= 64) ks *= 2;
+    // batches run the split-bf16 GEMM with 128-row workgroups: room for its split-K factor too
+    if (N >= 4096)
+        while (ks < 8 && ((N + 127) / 128) * (size_t)ks < 512 && k0 / (ks * 2) >= 64) ks *= 2;
     w.ksplit = ks;
     size_t fmax = 0;
     for (int i = 0; i < d->enc_node.n_layers; ++i)
