@@ -150,8 +150,9 @@ def main():
     ap.add_argument("--nodes", type=int, default=256)
     ap.add_argument("--graphs", type=int, default=1, help="independent graphs per GPU per step")
     ap.add_argument("--L", type=int, default=4)
-    ap.add_argument("--mode", choices=["eager", "graph"], default="graph",
-                    help="eager: one C-ABI call per step; graph: the same call captured once in a HIP graph")
+    ap.add_argument("--mode", choices=["auto", "eager", "graph"], default="auto",
+                    help="eager: one C-ABI call per step; graph: the same call captured once in a HIP graph and replayed; "
+                         "auto: time 50 steps of each after warm-up and keep the faster (reported in config.mode)")
     ap.add_argument("--edge-state", choices=["fp32", "bf16"], default="fp32",
                     help="storage of the edge latents between steps (bf16: GNNCCA_OPT_EDGE_STATE_BF16; arithmetic stays fp32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -191,12 +192,11 @@ def main():
     N = data.x.shape[0]
 
     with torch.no_grad():
-        mode_used = args.mode
-        static_out = None
-        run = lambda: model(data)
-        if args.mode == "graph":
-            # The whole forward (7 launches, no sync / malloc / memset inside the C ABI call) is captured once and
-            # replayed; if capture is refused on this box the bench falls back to plain launches and says so.
+        def eager_run():
+            return model(data)
+
+        def try_capture():
+            """The whole forward (no sync / malloc / memset inside the C ABI call) captured once in a HIP graph."""
             try:
                 side = torch.cuda.Stream()
                 side.wait_stream(torch.cuda.current_stream())
@@ -206,13 +206,32 @@ def main():
                 torch.cuda.current_stream().wait_stream(side)
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph):
-                    static_out = model(data)
-                run = graph.replay
+                    out_static = model(data)
+                return graph.replay, out_static
             except Exception as exc:  # noqa: BLE001
                 print(f"[bench] HIP graph capture failed ({type(exc).__name__}: {exc}); using eager launches", file=sys.stderr)
                 torch.cuda.synchronize()
-                mode_used, static_out = "eager (graph capture failed)", None
-                run = lambda: model(data)
+                return None, None
+
+        def quick_time(fn, n=50):
+            for _ in range(5):
+                fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / n
+
+        mode_used, static_out, run = "eager", None, eager_run
+        if args.mode in ("graph", "auto"):
+            replay, out_static = try_capture()
+            if replay is None:
+                mode_used = "eager (graph capture failed)"
+            elif args.mode == "graph" or quick_time(replay) < quick_time(eager_run):
+                mode_used, static_out, run = "graph", out_static, replay
+            if args.mode == "auto":
+                mode_used += " (auto)"
 
         for _ in range(args.warmup):
             run()

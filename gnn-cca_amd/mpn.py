@@ -156,6 +156,7 @@ class MOTMPNet(nn.Module):
         self._packed = None        # (key, device blob)
         self._workspace = None     # grow-only device scratch
         self._weights_dirty = True
+        self._param_cache = None
         self.last_workspace_bytes = 0
         # 'fp32' (default: bit-faithful to the reference within summation order) or 'bf16': the edge latents are kept
         # as bf16 in HBM between steps (GNNCCA_OPT_EDGE_STATE_BF16); arithmetic stays fp32
@@ -204,6 +205,13 @@ class MOTMPNet(nn.Module):
         return self._dims
 
     def native_param_tensors(self):
+        """Parameters and BatchNorm buffers in gnncca_pack_weights order (cached: walking the module tree costs more
+        than the whole GPU forward of a small graph; `_apply` drops the cache because it replaces buffer objects)."""
+        if self._param_cache is None:
+            self._param_cache = self._collect_param_tensors()
+        return self._param_cache
+
+    def _collect_param_tensors(self):
         out = []
         for mlp in (self.encoder.node_mlp, self.encoder.edge_mlp, self.MPNet.edge_model.edge_mlp,
                     self.MPNet.node_model.node_mlp, self.classifier.edge_mlp):
@@ -217,6 +225,7 @@ class MOTMPNet(nn.Module):
 
     def _apply(self, fn, *a, **k):  # .cuda() / .to() / .float()
         self._weights_dirty = True
+        self._param_cache = None
         return super()._apply(fn, *a, **k)
 
     def load_state_dict(self, *a, **k):
@@ -259,8 +268,7 @@ class MOTMPNet(nn.Module):
         return ws
 
     # -- forward -----------------------------------------------------------------------------------------------
-    def _prepare(self, data):
-        x, edge_index, edge_attr = data.x, data.edge_index, data.edge_attr
+    def _prepare(self, x, edge_index, edge_attr):
         if not (x.is_cuda and edge_index.is_cuda and edge_attr.is_cuda):
             raise RuntimeError("gnn_cca_amd.MOTMPNet runs on MI355X only: move the module and `data` to the GPU "
                                "(there is no CPU fallback)")
@@ -330,11 +338,7 @@ class MOTMPNet(nn.Module):
 
     def _forward_native(self, x, edge_index, edge_attr, trace=None):
         """Eval-semantics forward through gnncca_mpn_forward; returns logits [n_out, E, 1]."""
-        class _D:
-            pass
-        dd = _D()
-        dd.x, dd.edge_index, dd.edge_attr = x, edge_index, edge_attr
-        lib, d, dev, x, edge_index, edge_attr, n, e, blob, logits, ws = self._prepare(dd)
+        lib, d, dev, x, edge_index, edge_attr, n, e, blob, logits, ws = self._prepare(x, edge_index, edge_attr)
         if ws is None:
             if trace is not None:
                 L = int(self.num_enc_steps)
@@ -363,7 +367,7 @@ class MOTMPNet(nn.Module):
     def forward_profiled(self, data):
         """Diagnostic (bench.py): same forward with a hipEvent after every kernel launch; synchronises.
         Returns (outputs, [(kernel_kind, milliseconds), ...])."""
-        lib, d, dev, x, edge_index, edge_attr, n, e, blob, logits, ws = self._prepare(data)
+        lib, d, dev, x, edge_index, edge_attr, n, e, blob, logits, ws = self._prepare(data.x, data.edge_index, data.edge_attr)
         if ws is None:
             return {'classified_edges': list(logits.unbind(0))}, []
         prof = nat.Profile()
