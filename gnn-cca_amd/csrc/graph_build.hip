@@ -1,15 +1,19 @@
 // graph_build.hip -- SURVEY.md 8f row N1 on gfx950: cross-camera graph construction + edge attributes for a batch of
 // frames (replaces the per-frame Python / sklearn / GPU<->CPU round trips of inference.py:189-279).
 //
-// One wave per SOURCE detection, in the order the reference emits sources (camera-major inside a frame).  The wave
-// walks the frame's detections in ascending id, skips its own camera, and for every target computes
+// One wave per (SOURCE detection, slice of its frame's 64-candidate chunks), sources in the order the reference emits
+// them (camera-major inside a frame).  A chunk is 64 consecutive detections of the frame, ONE PER LANE: the lane
+// decides whether its candidate is on another camera (an edge, inference.py:210-211), and computes for it
 //   ground-plane L2 and L1 distance in float64, divided by the frame's max_dist, cast to fp32   (inference.py:229-242)
-//   F.pairwise_distance(p=2, eps=1e-6) and F.cosine_similarity(eps=1e-8) of the reid rows        (inference.py:222-226)
 //   the same-identity label                                                                     (inference.py:262-266)
-// with the reid row of the target read as one coalesced 1 KB wave load and reduced across the wave by DPP shuffles.
-// Results are parked one per lane and flushed 64 at a time, so every store of edge_index / edge_attr / labels is a
-// contiguous wave store.  Traffic: the reid table (N x R x 4 B) is re-read once per source from L2 -- it is 256 KB for
-// a 256-detection frame -- and 8+8+16+4 B are written per edge; the kernel is L2/latency bound, not HBM bound.
+// while the reid terms -- F.pairwise_distance(p=2, eps=1e-6), F.cosine_similarity(eps=1e-8)     (inference.py:222-226)
+// -- are computed by the whole wave, four targets at a time: each target's reid row is one coalesced wave load, the
+// 4 x 4 partial sums are reduced across the wave by a transposing butterfly (v_permlane32_swap, v_permlane16_swap,
+// then 5 shuffles: 17 cross-lane ops for 16 sums instead of 96) and parked in the candidate's lane; sqrt / divide run
+// once per chunk, lane-parallel.  The edge slot of a candidate is edge_ptr[source] + (other-camera candidates before
+// it), a ballot prefix, so every store of edge_index / edge_attr / labels is a contiguous wave store in the
+// reference's edge order.  Traffic: the reid table (N x R x 4 B) is re-read once per source from L2 -- it is 256 KB
+// for a 256-detection frame -- and 8+8+16+4 B are written per edge; the kernel is L2/latency bound, not HBM bound.
 #include <hip/hip_runtime.h>
 
 #include "internal.h"
@@ -31,6 +35,32 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// 16 per-lane partial sums v[idx] -> the full wave sum of v[lane >> 2] in every lane
+__device__ __forceinline__ float transpose_reduce16(float (&v)[16]) {
+    float w[8], x[4];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {  // lanes 0-31 keep idx k, lanes 32-63 keep idx k + 8
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[k]), __float_as_uint(v[k + 8]), false, false);
+        w[k] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {  // odd rows of 16 lanes keep idx + 4
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(w[k]), __float_as_uint(w[k + 4]), false, false);
+        x[k] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+    const int lane = threadIdx.x & 63;
+    const bool b3 = lane & 8, b2 = lane & 4;
+    const float y0 = (b3 ? x[2] : x[0]) + __shfl_xor(b3 ? x[0] : x[2], 8);
+    const float y1 = (b3 ? x[3] : x[1]) + __shfl_xor(b3 ? x[1] : x[3], 8);
+    float z = (b2 ? y1 : y0) + __shfl_xor(b2 ? y0 : y1, 4);
+    z += __shfl_xor(z, 2);
+    z += __shfl_xor(z, 1);
+    return z;
+}
+
+// after transpose_reduce16 the full sum of idx sits in lanes 4 * idx .. 4 * idx + 3
+__host__ __device__ constexpr int lane_of_sum(int idx) { return 4 * idx; }
+
 template <int MODE>
 __global__ __launch_bounds__(256) void build_edges_kernel(const gnncca_frames fr, const float* __restrict__ reid, int R, int N,
                                                           long long E, long long* __restrict__ ei_out,
@@ -45,72 +75,112 @@ __global__ __launch_bounds__(256) void build_edges_kernel(const gnncca_frames fr
     const int ci = fr.cam[i], pi = fr.person_id[i];
     const double xi = fr.xw[i], yi = fr.yw[i], md = fr.max_dist[g];
     const float* __restrict__ ri = reid + (size_t)i * R;
+    const bool vec4 = (R & 3) == 0;
     long long pos = fr.edge_ptr[p];
-    // parked results of up to 64 targets (lane q holds target number q of the current batch)
-    int pj = 0;
-    float pa[4] = {0.f, 0.f, 0.f, 0.f};
-    float pl = 0.f;
-    int parked = 0;
-    auto flush = [&]() {
-        if (lane < parked) {
-            const long long k = pos + lane;
-            ei_out[k] = i;
-            ei_out[E + k] = pj;
-            if (NA == 4) {
-                *reinterpret_cast<float4*>(attr_out + k * 4) = make_float4(pa[0], pa[1], pa[2], pa[3]);
-            } else {
-                *reinterpret_cast<float2*>(attr_out + k * 2) = make_float2(pa[0], pa[1]);
+    for (int c = 0, j0 = gs; j0 < ge; ++c, j0 += 64) {
+        const int j = j0 + lane;
+        const bool inb = j < ge;
+        const bool valid = inb && fr.cam[j] != ci;  // same camera: no edge (inference.py:210-211)
+        const unsigned long long mask = __ballot(valid);
+        const int n_valid = __popcll(mask);
+        if (c % (int)gridDim.y == (int)blockIdx.y && mask != 0ull) {
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, lab = 0.f;
+            if (valid) {
+                lab = fr.person_id[j] == pi ? 1.f : 0.f;
+                if (MODE != GNNCCA_EDGE_ATTR_ONLY_APPEARANCE) {
+                    // sklearn paired_distances on float64 rows, / max_dist, .type(float32); no FMA contraction
+                    const double dx = __dsub_rn(xi, fr.xw[j]), dy = __dsub_rn(yi, fr.yw[j]);
+                    const double l2 = __dsqrt_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)));
+                    const double l1 = __dadd_rn(fabs(dx), fabs(dy));
+                    a0 = (float)__ddiv_rn(l2, md);
+                    a1 = (float)__ddiv_rn(l1, md);
+                }
             }
-            lab_out[k] = pl;
-        }
-        pos += parked;
-        parked = 0;
-    };
-    for (int j = gs; j < ge; ++j) {
-        if (fr.cam[j] == ci) continue;  // wave-uniform: same camera, no edge (inference.py:210-211)
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-        if (MODE != GNNCCA_EDGE_ATTR_ONLY_APPEARANCE) {
-            // sklearn paired_distances on float64 rows, / max_dist, .type(float32); no FMA contraction
-            const double dx = __dsub_rn(xi, fr.xw[j]), dy = __dsub_rn(yi, fr.yw[j]);
-            const double l2 = __dsqrt_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)));
-            const double l1 = __dadd_rn(fabs(dx), fabs(dy));
-            a0 = (float)__ddiv_rn(l2, md);
-            a1 = (float)__ddiv_rn(l1, md);
-        }
-        if (MODE != GNNCCA_EDGE_ATTR_ONLY_DIST) {
-            const float* __restrict__ rj = reid + (size_t)j * R;
-            float sd = 0.f, sab = 0.f, saa = 0.f, sbb = 0.f;
-            for (int d = lane; d < R; d += 64) {
-                const float a = ri[d], b = rj[d];
-                const float df = (a - b) + 1e-6f;  // F.pairwise_distance adds eps to the difference
-                sd = fmaf(df, df, sd);
-                sab = fmaf(a, b, sab);
-                saa = fmaf(a, a, saa);
-                sbb = fmaf(b, b, sbb);
+            if (MODE != GNNCCA_EDGE_ATTR_ONLY_DIST) {
+                float sd = 0.f, sab = 0.f, saa = 1.f, sbb = 1.f;  // this lane's candidate: raw sums over the reid row
+                unsigned long long m = mask;
+                while (m != 0ull) {  // wave-uniform: four targets per round (the last round repeats its last target)
+                    int t[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        if (m != 0ull) {
+                            t[k] = __ffsll((long long)m) - 1;
+                            m &= m - 1;
+                        } else {
+                            t[k] = t[k - 1 < 0 ? 0 : k - 1];
+                        }
+                    }
+                    const float* __restrict__ rj[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) rj[k] = reid + (size_t)(j0 + t[k]) * R;
+                    float v[16];
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) v[q] = 0.f;
+                    auto acc = [&](int k, float a, float b) {
+                        const float df = (a - b) + 1e-6f;  // F.pairwise_distance adds eps to the difference
+                        v[4 * k + 0] = fmaf(df, df, v[4 * k + 0]);
+                        v[4 * k + 1] = fmaf(a, b, v[4 * k + 1]);
+                        v[4 * k + 2] = fmaf(a, a, v[4 * k + 2]);
+                        v[4 * k + 3] = fmaf(b, b, v[4 * k + 3]);
+                    };
+                    if (vec4) {
+                        for (int d = lane * 4; d < R; d += 256) {
+                            const float4 a = *reinterpret_cast<const float4*>(ri + d);
+                            float4 b[4];
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) b[k] = *reinterpret_cast<const float4*>(rj[k] + d);
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                acc(k, a.x, b[k].x);
+                                acc(k, a.y, b[k].y);
+                                acc(k, a.z, b[k].z);
+                                acc(k, a.w, b[k].w);
+                            }
+                        }
+                    } else {
+                        for (int d = lane; d < R; d += 64) {
+                            const float a = ri[d];
+                            float b[4];
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) b[k] = rj[k][d];
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) acc(k, a, b[k]);
+                        }
+                    }
+                    const int toti = __float_as_int(transpose_reduce16(v));
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float s0 = __int_as_float(__builtin_amdgcn_readlane(toti, lane_of_sum(4 * k + 0)));
+                        const float s1 = __int_as_float(__builtin_amdgcn_readlane(toti, lane_of_sum(4 * k + 1)));
+                        const float s2 = __int_as_float(__builtin_amdgcn_readlane(toti, lane_of_sum(4 * k + 2)));
+                        const float s3 = __int_as_float(__builtin_amdgcn_readlane(toti, lane_of_sum(4 * k + 3)));
+                        if (lane == t[k]) sd = s0, sab = s1, saa = s2, sbb = s3;
+                    }
+                }
+                const float emb = sqrtf(sd);
+                const float cosv = sab / (fmaxf(sqrtf(saa), 1e-8f) * fmaxf(sqrtf(sbb), 1e-8f));
+                if (MODE == GNNCCA_EDGE_ATTR_FULL) {
+                    a2 = emb;
+                    a3 = cosv;
+                } else {
+                    a0 = emb;
+                    a1 = cosv;
+                }
             }
-            sd = wave_sum(sd);
-            sab = wave_sum(sab);
-            saa = wave_sum(saa);
-            sbb = wave_sum(sbb);
-            const float emb = sqrtf(sd);
-            const float cosv = sab / (fmaxf(sqrtf(saa), 1e-8f) * fmaxf(sqrtf(sbb), 1e-8f));
-            if (MODE == GNNCCA_EDGE_ATTR_FULL) {
-                a2 = emb;
-                a3 = cosv;
-            } else {
-                a0 = emb;
-                a1 = cosv;
+            if (valid) {
+                const long long k = pos + __popcll(mask & ((1ull << lane) - 1ull));
+                ei_out[k] = i;
+                ei_out[E + k] = j;
+                if (NA == 4) {
+                    *reinterpret_cast<float4*>(attr_out + k * 4) = make_float4(a0, a1, a2, a3);
+                } else {
+                    *reinterpret_cast<float2*>(attr_out + k * 2) = make_float2(a0, a1);
+                }
+                lab_out[k] = lab;
             }
         }
-        const float lab = fr.person_id[j] == pi ? 1.f : 0.f;
-        if (lane == parked) {
-            pj = j;
-            pa[0] = a0, pa[1] = a1, pa[2] = a2, pa[3] = a3;
-            pl = lab;
-        }
-        if (++parked == 64) flush();
+        pos += n_valid;
     }
-    flush();
 }
 
 // partial[chunk][c] = sum over the chunk's 256 rows of x[r][c]^2, rows in ascending order
@@ -179,7 +249,10 @@ int gnncca_build_edges(const gnncca_frames* fr, const float* reid, int32_t reid_
         return GNNCCA_ERR_INVALID_ARG;
     if (mode != GNNCCA_EDGE_ATTR_ONLY_DIST && (!reid || reid_dim == 0)) return GNNCCA_ERR_INVALID_ARG;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const dim3 grid((unsigned)((n_nodes + 3) / 4)), block(256);
+    // few sources: split each source's candidate chunks over up to 16 waves so that the launch still fills the chip
+    unsigned slices = 1;
+    while (slices < 16 && (long long)n_nodes * slices < 4096) slices *= 2;
+    const dim3 grid((unsigned)((n_nodes + 3) / 4), slices), block(256);
     long long* ei = reinterpret_cast<long long*>(edge_index_out);
     switch (mode) {
         case GNNCCA_EDGE_ATTR_FULL:

@@ -37,15 +37,14 @@ def plan_frames(id_cam, graph_sizes):
     if len(id_cam) != n:
         raise ValueError("id_cam length does not match graph_sizes")
     graph_of = np.repeat(np.arange(len(sizes), dtype=np.int32), sizes)
-    src_order = np.empty(n, dtype=np.int32)
-    deg = np.empty(n, dtype=np.int64)
-    for g in range(len(sizes)):
-        lo, hi = graph_ptr[g], graph_ptr[g + 1]
-        cams = id_cam[lo:hi]
-        order = np.argsort(cams, kind="stable")  # camera-major, node id ascending inside a camera
-        src_order[lo:hi] = lo + order
-        _, inv, cnt = np.unique(cams, return_inverse=True, return_counts=True)
-        deg[lo:hi] = (hi - lo) - cnt[inv][order]
+    # one stable sort of (graph, camera) keys for the whole batch: graph-major, np.unique's camera order inside a graph,
+    # node id ascending inside a camera
+    _, cam_rank = np.unique(id_cam, return_inverse=True)
+    n_cam = int(cam_rank.max()) + 1 if n else 1
+    key = graph_of.astype(np.int64) * n_cam + cam_rank
+    src_order = np.argsort(key, kind="stable").astype(np.int32)
+    same_cam = np.bincount(key, minlength=len(sizes) * n_cam)
+    deg = (sizes[graph_of] - same_cam[key])[src_order]
     edge_ptr = np.concatenate([[0], np.cumsum(deg)])
     if edge_ptr[-1] >= 2 ** 31 - 64:
         raise NotImplementedError("more than 2^31 edges in one batch")
@@ -87,16 +86,19 @@ def build_graph_batch(xw, yw, ids, id_cam, graph_sizes, max_dist, node_embeds, r
     mode = MODE_ONLY_APPEARANCE if only_appearance else (MODE_ONLY_DIST if only_dist else MODE_FULL)
     n_attr = 4 if mode == MODE_FULL else 2
     _, dense_ids = np.unique(np.asarray(ids), return_inverse=True)
-    # one small host->device transfer with every per-node / per-graph array
+    # ONE host->device transfer with every per-node / per-graph array: 8-byte fields first, then the int32 ones
+    g = len(plan.graph_ptr) - 1
+    ids64 = np.ascontiguousarray(ids, dtype=np.int64)
     f64 = np.concatenate([np.asarray(xw, np.float64), np.asarray(yw, np.float64), np.asarray(max_dist, np.float64)])
     i32 = np.concatenate([dense_ids.astype(np.int32), np.asarray(id_cam).astype(np.int32), plan.graph_of, plan.graph_ptr,
                           plan.src_order, plan.edge_ptr])
-    d64 = torch.from_numpy(f64).to(dev)
-    d32 = torch.from_numpy(i32).to(dev)
-    g = len(plan.graph_ptr) - 1
+    host = np.concatenate([f64.view(np.uint8), ids64.view(np.uint8), i32.view(np.uint8)])
+    staged = torch.from_numpy(host).to(dev)
     fr = nat.Frames()
-    fr.xw, fr.yw, fr.max_dist = d64.data_ptr(), d64.data_ptr() + 8 * n, d64.data_ptr() + 16 * n
-    base, o = d32.data_ptr(), 0
+    p0 = staged.data_ptr()
+    fr.xw, fr.yw, fr.max_dist = p0, p0 + 8 * n, p0 + 16 * n
+    y_off = 8 * (2 * n + g)
+    base, o = p0 + y_off + 8 * n, 0
     for name, cnt in (("person_id", n), ("cam", n), ("graph_of", n), ("graph_ptr", g + 1), ("src_order", n), ("edge_ptr", n + 1)):
         setattr(fr, name, base + 4 * o)
         o += cnt
@@ -110,10 +112,10 @@ def build_graph_batch(xw, yw, ids, id_cam, graph_sizes, max_dist, node_embeds, r
                                               torch.cuda.current_stream(dev).cuda_stream)
         nat.check(st, "gnncca_build_edges")
     # per-graph edge ranges: edges are emitted graph by graph, so graph g owns edge_ptr[graph_ptr[g]] .. edge_ptr[graph_ptr[g+1]]
-    edge_ptr_g = [int(plan.edge_ptr[p]) for p in plan.graph_ptr]
-    batch = GraphBatch(node_embeds, edge_index, edge_attr, edge_ptr_g, [int(p) for p in plan.graph_ptr])
+    edge_ptr_g = plan.edge_ptr[plan.graph_ptr].tolist()
+    batch = GraphBatch(node_embeds, edge_index, edge_attr, edge_ptr_g, plan.graph_ptr.tolist())
     batch.edge_labels = edge_labels
-    batch.y = torch.from_numpy(np.asarray(ids)).to(dev)
+    batch.y = staged[y_off:y_off + 8 * n].view(torch.int64)
     batch.reid_embeds = reid_embeds
-    batch._keepalive = (d64, d32)
+    batch._keepalive = staged
     return batch
