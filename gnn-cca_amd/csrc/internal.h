@@ -46,12 +46,14 @@ struct BlobHeader {
     int32_t pad[6];
 };
 
-// Layout of the `fast_consts` block (floats): what mpn_step_fast_kernel stages into LDS in one coalesced load.
+// Layout of the `fast_consts` block (floats): the per-step scalars mpn_step_fast_kernel reads into SGPRs.
 // Present when edge_in == 4, no reattach flags and the classifier is Linear(6,4)+ReLU+Linear(4,1).
-constexpr int kFcEncW = 0;     // [6][4]
+// The three matrices are stored TRANSPOSED ([in][out]) so that the weights of two adjacent outputs are one aligned
+// SGPR pair, the operand form of v_pk_fma_f32.
+constexpr int kFcEncW = 0;     // [4][6]  enc_edge_w^T
 constexpr int kFcEncB = 24;    // [6]
-constexpr int kFcWee = 32;     // [6][6]
-constexpr int kFcCw1 = 68;     // [4][6]
+constexpr int kFcWee = 32;     // [6][6]  wee^T
+constexpr int kFcCw1 = 68;     // [6][4]  cls_w1^T
 constexpr int kFcCb1 = 92;     // [4]
 constexpr int kFcCw2 = 96;     // [4]
 constexpr int kFcCb2 = 100;    // [1]

@@ -356,10 +356,14 @@ int gnncca_pack_weights(const gnncca_mpn_dims* d, const float* const* params, in
     }
     if (p.h.fast_consts) {  // contiguous copy of the per-step scalars for the specialised kernel
         float* fc = blob + p.h.fast_consts;
-        std::memcpy(fc + kFcEncW, blob + p.h.enc_edge_w, 24 * sizeof(float));
+        auto transpose = [&](int dst, int src, int rows, int cols) {  // [rows][cols] -> [cols][rows]
+            for (int r = 0; r < rows; ++r)
+                for (int c = 0; c < cols; ++c) fc[dst + c * rows + r] = blob[src + r * cols + c];
+        };
+        transpose(kFcEncW, p.h.enc_edge_w, 6, 4);
         std::memcpy(fc + kFcEncB, blob + p.h.enc_edge_b, 6 * sizeof(float));
-        std::memcpy(fc + kFcWee, blob + p.h.wee, 36 * sizeof(float));
-        std::memcpy(fc + kFcCw1, blob + p.h.cls_w1, 24 * sizeof(float));
+        transpose(kFcWee, p.h.wee, 6, 6);
+        transpose(kFcCw1, p.h.cls_w1, 4, 6);
         std::memcpy(fc + kFcCb1, blob + p.h.cls_b1, 4 * sizeof(float));
         std::memcpy(fc + kFcCw2, blob + p.h.cls_w2, 4 * sizeof(float));
         std::memcpy(fc + kFcCb2, blob + p.h.cls_b2, 1 * sizeof(float));

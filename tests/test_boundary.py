@@ -189,8 +189,11 @@ def blob_forward(blob_u8, params, arch, x, edge_index, edge_attr):
         out.append(classify(e))
     if h.fast_consts:
         fc = f[h.fast_consts:h.fast_consts + 152]
-        assert np.array_equal(fc[32:68], f[h.wee:h.wee + 36]) and np.array_equal(fc[104:152], projb)
-        assert np.array_equal(fc[0:24], f[h.enc_edge_w:h.enc_edge_w + 24]) and fc[100] == f[h.cls_b2]
+        # the three matrices are stored transposed ([in][out]): SGPR-pair operands of the packed-fp32 FMAs
+        assert np.array_equal(fc[32:68].reshape(6, 6).T.ravel(), f[h.wee:h.wee + 36]) and np.array_equal(fc[104:152], projb)
+        assert np.array_equal(fc[0:24].reshape(4, 6).T.ravel(), f[h.enc_edge_w:h.enc_edge_w + 24]) and fc[100] == f[h.cls_b2]
+        if h.cls_w1:
+            assert np.array_equal(fc[68:92].reshape(6, 4).T.ravel(), f[h.cls_w1:h.cls_w1 + 24])
     return out
 
 
