@@ -8,10 +8,10 @@
 //   node update     (models/mpn.py:97-99) d h_s[row] (/ deg for 'mean') -> ReLU' -> d W_ne, d b_n, d Q[row], d e_s
 //   edge update     (models/mpn.py:48,68-69) d e_s -> ReLU' -> d W_ee, d b_e, d P_src[row], d P_dst[col], d e_{s-1}
 //   projections     d (P_src | P_dst | Q) -> d h_{s-1}, d W_src, d W_dst, d W_nx
-// then the two encoders.  Parameter gradients are sums over edges / nodes: contributions are reduced across the wave
-// first (DPP shuffles) and then added with one float atomic per wave, so the result depends on arrival order in the
-// last bits exactly like the reference on CUDA (cuBLAS / torch_scatter atomics).  Correctness first; this path is
-// not tuned (the reference trains on batches of a few 10^4 edges).
+// then the two encoders.  Parameter gradients are sums over edges / nodes: per-edge contributions are reduced across
+// the wave sixteen at a time (transposing butterfly, wave_atomic_add16) and added with one float atomic per value
+// per wave; sums of outer products over nodes run on the fp32 MFMA pipe (bwd_outer_mfma_kernel).  The result depends
+// on arrival order in the last bits exactly like the reference on CUDA (cuBLAS / torch_scatter atomics).
 // Supported: the MFMA family without reattach flags, without BatchNorm, 'sum' / 'mean', two-layer node encoder.
 // Part of the single translation unit mpn_forward.hip.
 namespace gnncca {
@@ -26,6 +26,17 @@ __device__ __forceinline__ float wave_reduce_sum(float v) {
 __device__ __forceinline__ void wave_atomic_add(float* dst, float v) {
     v = wave_reduce_sum(v);
     if ((threadIdx.x & 63) == 0 && v != 0.f) atomicAdd(dst, v);
+}
+
+// Sixteen contributions every lane holds, each summed over the wave and added to its own address: one transposing
+// reduction (17 cross-lane operations instead of 96) and ONE atomic instruction, issued by the 16 lanes 4 idx that
+// end up holding the sums.  `dst_of(idx)` maps idx -> address (nullptr: slot unused); it is evaluated per lane.
+template <typename DstOf>
+__device__ __forceinline__ void wave_atomic_add16(const float (&v)[16], DstOf dst_of) {
+    const float z = transpose_reduce16(v);
+    const int lane = threadIdx.x & 63;
+    float* dst = dst_of(lane >> 2);
+    if ((lane & 3) == 0 && dst != nullptr && z != 0.f) atomicAdd(dst, z);
 }
 
 __global__ __launch_bounds__(256) void bwd_degree_kernel(const long long* __restrict__ ei, long long E, int N, int* __restrict__ deg) {
@@ -99,62 +110,101 @@ __global__ __launch_bounds__(256) void bwd_edge_kernel(const BwdEdgeParams p) {
         if (p.cls_hidden > 0 && p.bn_stat) {
             // Linear -> BatchNorm(batch statistics) -> ReLU -> Linear.  d W2, d b2, d gamma, d beta were formed by
             // bwd_cls_bn_reduce_kernel; here: g_z = gamma * invstd * (g_y - mean(g_y) - z_hat * mean(g_y z_hat))
-            for (int q = 0; q < p.cls_hidden; ++q) {
-                float z1 = p.bc1[q];
+            // two hidden units per reduction: slots [8u + 0] d b1[q0+u], [8u + 1 + f] d W1[q0+u][f]
+            for (int q0 = 0; q0 < p.cls_hidden; q0 += 2) {
+                float v[16];
 #pragma unroll
-                for (int f = 0; f < kEF; ++f) z1 = fmaf(p.Wc1[q * kEF + f], es[f], z1);
-                const float zh = (z1 - p.bn_stat[2 * q]) * p.bn_stat[2 * q + 1];
-                const float y = fmaf(p.bn_gamma[q], zh, p.bn_beta[q]);
-                const float gy = y > 0.f ? p.Wc2[q] * dz : 0.f;
-                const float gz1 = live * p.bn_gamma[q] * p.bn_stat[2 * q + 1] * (gy - p.bn_red[2 * q] - zh * p.bn_red[2 * q + 1]);
-                wave_atomic_add(p.gbc1 + q, gz1);
+                for (int u = 0; u < 2; ++u) {
+                    const int q = min(q0 + u, p.cls_hidden - 1);
+                    float z1 = p.bc1[q];
 #pragma unroll
-                for (int f = 0; f < kEF; ++f) {
-                    wave_atomic_add(p.gWc1 + q * kEF + f, gz1 * es[f]);
-                    ge[f] = fmaf(p.Wc1[q * kEF + f], gz1, ge[f]);
+                    for (int f = 0; f < kEF; ++f) z1 = fmaf(p.Wc1[q * kEF + f], es[f], z1);
+                    const float zh = (z1 - p.bn_stat[2 * q]) * p.bn_stat[2 * q + 1];
+                    const float y = fmaf(p.bn_gamma[q], zh, p.bn_beta[q]);
+                    const float gy = y > 0.f ? p.Wc2[q] * dz : 0.f;
+                    float gz1 = live * p.bn_gamma[q] * p.bn_stat[2 * q + 1] * (gy - p.bn_red[2 * q] - zh * p.bn_red[2 * q + 1]);
+                    if (q0 + u >= p.cls_hidden) gz1 = 0.f;
+                    v[8 * u] = gz1;
+                    v[8 * u + 7] = 0.f;
+#pragma unroll
+                    for (int f = 0; f < kEF; ++f) {
+                        v[8 * u + 1 + f] = gz1 * es[f];
+                        ge[f] = fmaf(p.Wc1[q * kEF + f], gz1, ge[f]);
+                    }
                 }
+                wave_atomic_add16(v, [&](int idx) -> float* {
+                    const int q = q0 + (idx >> 3), r = idx & 7;
+                    if (q >= p.cls_hidden || r == 7) return nullptr;
+                    return r == 0 ? p.gbc1 + q : p.gWc1 + q * kEF + r - 1;
+                });
             }
         } else if (p.cls_hidden > 0) {
-            float db2 = dz;
-            wave_atomic_add(p.gbc2, db2);
-            for (int q = 0; q < p.cls_hidden; ++q) {
-                float z1 = p.bc1[q];
+            wave_atomic_add(p.gbc2, dz);
+            // two hidden units per reduction: slots [8u + 0] d W2[q], [8u + 1] d b1[q], [8u + 2 + f] d W1[q][f]
+            for (int q0 = 0; q0 < p.cls_hidden; q0 += 2) {
+                float v[16];
 #pragma unroll
-                for (int f = 0; f < kEF; ++f) z1 = fmaf(p.Wc1[q * kEF + f], es[f], z1);
-                const float r = fmaxf(z1, 0.f);
-                wave_atomic_add(p.gWc2 + q, dz * r);
-                const float gz1 = z1 > 0.f ? p.Wc2[q] * dz : 0.f;
-                wave_atomic_add(p.gbc1 + q, gz1);
+                for (int u = 0; u < 2; ++u) {
+                    const int q = min(q0 + u, p.cls_hidden - 1);
+                    const bool on = q0 + u < p.cls_hidden;
+                    float z1 = p.bc1[q];
 #pragma unroll
-                for (int f = 0; f < kEF; ++f) {
-                    wave_atomic_add(p.gWc1 + q * kEF + f, gz1 * es[f]);
-                    ge[f] = fmaf(p.Wc1[q * kEF + f], gz1, ge[f]);
+                    for (int f = 0; f < kEF; ++f) z1 = fmaf(p.Wc1[q * kEF + f], es[f], z1);
+                    const float gz1 = (on && z1 > 0.f) ? p.Wc2[q] * dz : 0.f;
+                    v[8 * u] = on ? dz * fmaxf(z1, 0.f) : 0.f;
+                    v[8 * u + 1] = gz1;
+#pragma unroll
+                    for (int f = 0; f < kEF; ++f) {
+                        v[8 * u + 2 + f] = gz1 * es[f];
+                        ge[f] = fmaf(p.Wc1[q * kEF + f], gz1, ge[f]);
+                    }
                 }
+                wave_atomic_add16(v, [&](int idx) -> float* {
+                    const int q = q0 + (idx >> 3), r = idx & 7;
+                    if (q >= p.cls_hidden) return nullptr;
+                    return r == 0 ? p.gWc2 + q : (r == 1 ? p.gbc1 + q : p.gWc1 + q * kEF + r - 2);
+                });
             }
         } else {
-            wave_atomic_add(p.gbc1, dz);
+            float v[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) v[q] = 0.f;
+            v[0] = dz;
 #pragma unroll
             for (int f = 0; f < kEF; ++f) {
-                wave_atomic_add(p.gWc1 + f, dz * es[f]);
+                v[1 + f] = dz * es[f];
                 ge[f] = fmaf(p.Wc1[f], dz, ge[f]);
             }
+            wave_atomic_add16(v, [&](int idx) -> float* { return idx == 0 ? p.gbc1 : (idx <= kEF ? p.gWc1 + idx - 1 : nullptr); });
         }
     }
     // ---- node update -------------------------------------------------------------------------------------------
     if (p.g_h) {
         const float inv = p.deg ? 1.f / (float)max(p.deg[i], 1) : 1.f;
-        for (int c = 0; c < kH; ++c) {
-            float b = p.Q[(size_t)i * kH + c];
+        // two channels per reduction: slots [8u + 0] d b_n[c0+u], [8u + 1 + f] d W_ne[c0+u][f]
+        for (int c0 = 0; c0 < kH; c0 += 2) {
+            float v[16];
 #pragma unroll
-            for (int f = 0; f < kEF; ++f) b = fmaf(p.Wn[c * (kH + kEF) + kH + f], es[f], b);
-            const float gb = b > 0.f ? p.g_h[(size_t)i * kH + c] * inv * live : 0.f;
-            wave_atomic_add(p.gbn + c, gb);
+            for (int u = 0; u < 2; ++u) {
+                const int c = c0 + u;
+                float b = p.Q[(size_t)i * kH + c];
 #pragma unroll
-            for (int f = 0; f < kEF; ++f) {
-                wave_atomic_add(p.gWn + c * (kH + kEF) + kH + f, gb * es[f]);
-                ge[f] = fmaf(p.Wn[c * (kH + kEF) + kH + f], gb, ge[f]);
+                for (int f = 0; f < kEF; ++f) b = fmaf(p.Wn[c * (kH + kEF) + kH + f], es[f], b);
+                const float gb = b > 0.f ? p.g_h[(size_t)i * kH + c] * inv * live : 0.f;
+                v[8 * u] = gb;
+                v[8 * u + 7] = 0.f;
+#pragma unroll
+                for (int f = 0; f < kEF; ++f) {
+                    v[8 * u + 1 + f] = gb * es[f];
+                    ge[f] = fmaf(p.Wn[c * (kH + kEF) + kH + f], gb, ge[f]);
+                }
+                if (gb != 0.f) atomicAdd(&p.dP[(size_t)i * 44 + 12 + c], gb);
             }
-            if (gb != 0.f) atomicAdd(&p.dP[(size_t)i * 44 + 12 + c], gb);
+            wave_atomic_add16(v, [&](int idx) -> float* {
+                const int c = c0 + (idx >> 3), r = idx & 7;
+                if (r == 7) return nullptr;
+                return r == 0 ? p.gbn + c : p.gWn + c * (kH + kEF) + kH + r - 1;
+            });
         }
     }
     // ---- edge update ---------------------------------------------------------------------------------------------
@@ -162,13 +212,27 @@ __global__ __launch_bounds__(256) void bwd_edge_kernel(const BwdEdgeParams p) {
 #pragma unroll
     for (int f = 0; f < kEF; ++f) {
         ga[f] = es[f] > 0.f ? ge[f] : 0.f;
-        wave_atomic_add(p.gbe + f, ga[f]);
         if (ga[f] != 0.f) {
             atomicAdd(&p.dP[(size_t)i * 44 + f], ga[f]);
             atomicAdd(&p.dP[(size_t)j * 44 + 6 + f], ga[f]);
         }
+    }
+    // two output features per reduction: slots [8u + 0] d b_e[f0+u], [8u + 1 + g] d W_ee[f0+u][g]
 #pragma unroll
-        for (int g = 0; g < kEF; ++g) wave_atomic_add(p.gWe + f * 70 + 64 + g, ga[f] * ep[g]);
+    for (int f0 = 0; f0 < kEF; f0 += 2) {
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            v[8 * u] = ga[f0 + u];
+            v[8 * u + 7] = 0.f;
+#pragma unroll
+            for (int g = 0; g < kEF; ++g) v[8 * u + 1 + g] = ga[f0 + u] * ep[g];
+        }
+        wave_atomic_add16(v, [&](int idx) -> float* {
+            const int f = f0 + (idx >> 3), r = idx & 7;
+            if (r == 7) return nullptr;
+            return r == 0 ? p.gbe + f : p.gWe + f * 70 + 64 + r - 1;
+        });
     }
     if (valid) {
 #pragma unroll
@@ -308,25 +372,66 @@ __global__ __launch_bounds__(256) void bwd_node_kernel(const float* __restrict__
     g_h_prev[t] = acc;
 }
 
-// out[o][k] += sum over a chunk of 256 rows n of A[n][o] * B[n][k]   (one atomic per output per chunk)
-__global__ __launch_bounds__(256) void bwd_outer_sum_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B,
-                                                            int ldb, float* __restrict__ out, int ldo, int N, int O, int K) {
-    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (t >= (long long)O * K) return;
-    const int o = (int)(t / K), k = (int)(t - (long long)o * K);
-    const int n0 = blockIdx.y * 256, n1 = min(n0 + 256, N);
-    float acc = 0.f;
-    for (int n = n0; n < n1; ++n) acc = fmaf(A[(size_t)n * lda + o], B[(size_t)n * ldb + k], acc);
-    if (acc != 0.f) atomicAdd(&out[(size_t)o * ldo + k], acc);
+// Parameter gradients that are sums of outer products over rows (nodes or edges):
+//   out[o][k] += sum_n A[n][o] * B[n][k]          and optionally      colsum[o] += sum_n A[n][o]
+// on the fp32 MFMA pipe.  Both operands of v_mfma_f32_32x32x2_f32 are read straight from global memory in their
+// natural layout -- lane (l % 32, l / 32) holds A[n + l/32][o0 + l%32] and B[n + l/32][k0 + l%32] -- so there is no
+// LDS staging: the reduction index n (rows) is the MFMA's k, two rows per instruction.  One wave owns a 32 x 64
+// output tile over a chunk of `rows_per_chunk` rows; partial tiles are added to `out` with one atomic per element.
+// The column sum comes from a third MFMA against a B that is 1 in column 0 (k-tile 0 only).
+constexpr int kOuterRows = 256;
+__global__ __launch_bounds__(64) void bwd_outer_mfma_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B,
+                                                            int ldb, float* __restrict__ out, int ldo, float* __restrict__ colsum,
+                                                            int N, int O, int K) {
+    const int lane = threadIdx.x, half = lane >> 5, l32 = lane & 31;
+    const int k0 = blockIdx.x * 64, o0 = blockIdx.y * 32;
+    const int n0 = blockIdx.z * kOuterRows, n1 = min(n0 + kOuterRows, N);
+    const int o = o0 + l32;
+    const bool o_ok = o < O, k_ok0 = k0 + l32 < K, k_ok1 = k0 + 32 + l32 < K;
+    const bool want_cs = colsum != nullptr && blockIdx.x == 0;
+    const float* __restrict__ pa = A + (o_ok ? o : 0);
+    const float* __restrict__ pb0 = B + (k_ok0 ? k0 + l32 : 0);
+    const float* __restrict__ pb1 = B + (k_ok1 ? k0 + 32 + l32 : 0);
+    f32x16 acc0, acc1, acc2;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc0[i] = acc1[i] = acc2[i] = 0.f;
+    const float one = l32 == 0 ? 1.f : 0.f;
+    for (int n = n0; n < n1; n += 8) {  // four MFMA k-steps (8 rows) per round: 12 loads in flight
+        float a[4], b0[4], b1[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int r = n + 2 * u + half;
+            const bool ok = r < n1;
+            const size_t rr = (size_t)(ok ? r : n0);
+            const float av = pa[rr * lda], bv0 = pb0[rr * ldb], bv1 = pb1[rr * ldb];
+            a[u] = ok && o_ok ? av : 0.f;
+            b0[u] = k_ok0 ? bv0 : 0.f;
+            b1[u] = k_ok1 ? bv1 : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b0[u], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b1[u], acc1, 0, 0, 0);
+            if (want_cs) acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], one, acc2, 0, 0, 0);
+        }
+    }
+    // D layout: lane (j = l % 32), register r -> row i = (r % 4) + 8 * (r / 4) + 4 * (l / 32)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int oo = o0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (oo < O) {
+            if (k_ok0 && acc0[r] != 0.f) atomicAdd(&out[(size_t)oo * ldo + k0 + l32], acc0[r]);
+            if (k_ok1 && acc1[r] != 0.f) atomicAdd(&out[(size_t)oo * ldo + k0 + 32 + l32], acc1[r]);
+            if (want_cs && l32 == 0 && acc2[r] != 0.f) atomicAdd(&colsum[oo], acc2[r]);
+        }
+    }
 }
 
-__global__ __launch_bounds__(256) void bwd_colsum_kernel(const float* __restrict__ A, int lda, float* __restrict__ out, int N, int O) {
-    const int o = blockIdx.x * 256 + threadIdx.x;
-    if (o >= O) return;
-    const int n0 = blockIdx.y * 256, n1 = min(n0 + 256, N);
-    float acc = 0.f;
-    for (int n = n0; n < n1; ++n) acc += A[(size_t)n * lda + o];
-    if (acc != 0.f) atomicAdd(&out[o], acc);
+static hipError_t launch_outer(const float* A, int lda, const float* B, int ldb, float* out, int ldo, float* colsum, int N, int O,
+                               int K, hipStream_t st) {
+    const dim3 grid((unsigned)((K + 63) / 64), (unsigned)((O + 31) / 32), (unsigned)((N + kOuterRows - 1) / kOuterRows));
+    hipLaunchKernelGGL(bwd_outer_mfma_kernel, grid, dim3(64), 0, st, A, lda, B, ldb, out, ldo, colsum, N, O, K);
+    return hipGetLastError();
 }
 
 // g[t] = y[t] > 0 ? g[t] : 0     (ReLU backward from the saved output)
@@ -354,6 +459,29 @@ __global__ __launch_bounds__(256) void bwd_edge_enc_kernel(const float* __restri
     const long long k0 = (long long)blockIdx.x * 256 + threadIdx.x;
     const bool valid = k0 < E;
     const long long k = valid ? k0 : E - 1;
+    if (A <= 7) {  // two output features per reduction: slots [8u + 0] d b[f0+u], [8u + 1 + a] d W[f0+u][a]
+        float at[7];
+#pragma unroll
+        for (int a = 0; a < 7; ++a) at[a] = a < A ? attr[k * A + a] : 0.f;
+#pragma unroll
+        for (int f0 = 0; f0 < kEF; f0 += 2) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int f = f0 + u;
+                const float g = (valid && e0[k * kEF + f] > 0.f) ? ge0[k * kEF + f] : 0.f;
+                v[8 * u] = g;
+#pragma unroll
+                for (int a = 0; a < 7; ++a) v[8 * u + 1 + a] = g * at[a];
+            }
+            wave_atomic_add16(v, [&](int idx) -> float* {
+                const int f = f0 + (idx >> 3), r = idx & 7;
+                if (r > A) return nullptr;
+                return r == 0 ? gb + f : gW + f * A + r - 1;
+            });
+        }
+        return;
+    }
     for (int f = 0; f < kEF; ++f) {
         const float g = (valid && e0[k * kEF + f] > 0.f) ? ge0[k * kEF + f] : 0.f;
         wave_atomic_add(gb + f, g);

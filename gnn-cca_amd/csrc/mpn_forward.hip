@@ -19,6 +19,7 @@
 #include <cstdlib>
 
 #include "common.cuh"
+#include "wave_reduce.cuh"
 #include "plan.cuh"
 #include "encoder.cuh"
 #include "step_general.cuh"
@@ -525,7 +526,6 @@ int gnncca_mpn_backward(const gnncca_mpn_dims* d, const float* const* params_dev
     double* bn_sums = reinterpret_cast<double*>(take(sizeof(double) * 2 * 64));
     float* bn_red = reinterpret_cast<float*>(take(sizeof(float) * 2 * 64));
     const long long* ei = reinterpret_cast<const long long*>(edge_index);
-    const int chunksN = (N + 255) / 256;
     if (d->agg == GNNCCA_AGG_MEAN) {
         HIP_TRY(hipMemsetAsync(deg, 0, (size_t)N * 4, st));
         hipLaunchKernelGGL(bwd_degree_kernel, grid1((size_t)E, 256), dim3(256), 0, st, ei, (long long)E, N, deg);
@@ -591,14 +591,9 @@ int gnncca_mpn_backward(const gnncca_mpn_dims* d, const float* const* params_dev
         hipLaunchKernelGGL(bwd_node_kernel, grid1((size_t)N * kH, 256), dim3(256), 0, st, (const float*)dP, We, Wn, g_h_prev, N);
         HIP_TRY(hipGetLastError());
         // d W_src, d W_dst (columns 0..31, 32..63 of the edge-MLP weight), d W_nx (columns 0..31 of the node-MLP weight)
-        hipLaunchKernelGGL(bwd_outer_sum_kernel, dim3((6 * kH + 255) / 256, chunksN), dim3(256), 0, st, (const float*)dP, 44, h_prev,
-                           kH, gWe, 70, N, 6, kH);
-        hipLaunchKernelGGL(bwd_outer_sum_kernel, dim3((6 * kH + 255) / 256, chunksN), dim3(256), 0, st, (const float*)(dP + 6), 44,
-                           h_prev, kH, gWe + kH, 70, N, 6, kH);
-        if (g_h)
-            hipLaunchKernelGGL(bwd_outer_sum_kernel, dim3((kH * kH + 255) / 256, chunksN), dim3(256), 0, st,
-                               (const float*)(dP + 12), 44, h_prev, kH, gWn, kH + kEF, N, kH, kH);
-        HIP_TRY(hipGetLastError());
+        HIP_TRY(launch_outer(dP, 44, h_prev, kH, gWe, 70, nullptr, N, 6, kH, st));
+        HIP_TRY(launch_outer(dP + 6, 44, h_prev, kH, gWe + kH, 70, nullptr, N, 6, kH, st));
+        if (g_h) HIP_TRY(launch_outer(dP + 12, 44, h_prev, kH, gWn, kH + kEF, nullptr, N, kH, kH, st));
         g_h = g_h_prev;
         ge_in = Gb[s & 1];
     }
@@ -632,14 +627,10 @@ int gnncca_mpn_backward(const gnncca_mpn_dims* d, const float* const* params_dev
     }
     float* gz2 = const_cast<float*>(g_h);  // [N][32] d loss / d h_enc, masked in place
     hipLaunchKernelGGL(bwd_relu_mask_kernel, grid1((size_t)N * kH, 256), dim3(256), 0, st, gz2, saved->h_enc, (long long)N * kH);
-    hipLaunchKernelGGL(bwd_outer_sum_kernel, dim3((kH * F1 + 255) / 256, chunksN), dim3(256), 0, st, (const float*)gz2, kH,
-                       (const float*)a1, F1, gW2, F1, N, kH, F1);
-    hipLaunchKernelGGL(bwd_colsum_kernel, dim3(1, chunksN), dim3(256), 0, st, (const float*)gz2, kH, gb2, N, kH);
+    HIP_TRY(launch_outer(gz2, kH, a1, F1, gW2, F1, gb2, N, kH, F1, st));
     hipLaunchKernelGGL(bwd_matmul_mask_kernel, grid1((size_t)N * F1, 256), dim3(256), 0, st, (const float*)gz2, W2, (const float*)a1,
                        gz1, N, kH, F1);
-    hipLaunchKernelGGL(bwd_outer_sum_kernel, dim3((unsigned)(((size_t)F1 * D + 255) / 256), chunksN), dim3(256), 0, st,
-                       (const float*)gz1, F1, x, D, gW1, D, N, F1, D);
-    hipLaunchKernelGGL(bwd_colsum_kernel, dim3((F1 + 255) / 256, chunksN), dim3(256), 0, st, (const float*)gz1, F1, gb1, N, F1);
+    HIP_TRY(launch_outer(gz1, F1, x, D, gW1, D, gb1, N, F1, D, st));
     HIP_TRY(hipGetLastError());
     return GNNCCA_OK;
 }
