@@ -56,6 +56,10 @@ _SIGNATURES = {
     "gnncca_param_count": (C.c_int, [C.POINTER(MpnDims)]),
     "gnncca_packed_weights_bytes": (C.c_size_t, [C.POINTER(MpnDims)]),
     "gnncca_pack_weights": (C.c_int, [C.POINTER(MpnDims), C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_size_t]),
+    "gnncca_pack_program_bytes": (C.c_size_t, []),
+    "gnncca_pack_program": (C.c_int, [C.POINTER(MpnDims), C.c_void_p, C.c_size_t]),
+    "gnncca_pack_weights_device": (C.c_int, [C.POINTER(MpnDims), C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_void_p,
+                                             C.c_size_t, C.c_void_p]),
     "gnncca_workspace_bytes": (C.c_size_t, [C.POINTER(MpnDims), C.c_int64, C.c_int64]),
     "gnncca_supported": (C.c_int, [C.POINTER(MpnDims)]),
     "gnncca_num_outputs": (C.c_int, [C.POINTER(MpnDims)]),

@@ -60,6 +60,30 @@ constexpr int kFcCb2 = 100;    // [1]
 constexpr int kFcProjB = 104;  // [48]
 constexpr int kFastConsts = 152;
 bool fast_consts_ok(const gnncca_mpn_dims* d);
+
+// Device-side packing (gnncca_pack_weights_device): the blob as a list of strided copies out of the parameter
+// tensors, built once per GRAPH_NET_PARAMS by pack_program() and interpreted by pack_device_kernel -- the same
+// folding / splitting as gnncca_pack_weights, bit for bit, without the parameters ever visiting the host.
+struct PackSeg {
+    int32_t kind;               // 0: weight element, 1: bias element, 2: weight element split into 3 bf16 planes
+    int32_t dst;                // float offset in the blob (kind 2: offset of plane 0)
+    int32_t param;              // index of the Linear's weight (kind 0, 2) or bias (kind 1) in the parameter list
+    int32_t bn;                 // index of the BatchNorm weight (gamma; beta, mean, var follow), or -1
+    int32_t src_off;            // element offset inside the parameter
+    int32_t rows, cols;         // rows = output units (the BatchNorm channel of element (r, c) is unit0 + r)
+    int32_t unit0;
+    int32_t drs, dcs, srs, scs; // destination / source strides per row and per column
+    int32_t plane;              // kind 2: elements per bf16 plane
+    int32_t pad[3];
+};
+constexpr int kMaxPackSegs = 96;
+struct PackProgram {
+    BlobHeader header;
+    int32_t n_segs;
+    int32_t pad[3];
+    PackSeg segs[kMaxPackSegs];
+};
+bool pack_program(const gnncca_mpn_dims* d, PackProgram* out);
 bool enc_split_ok(const gnncca_mpn_dims* d);  // first encoder layer eligible for the split-bf16 MFMA GEMM
 
 // Blob of the generic family: every layer of every MLP as W[out][in] + b[out], BatchNorm folded.

@@ -27,6 +27,7 @@
 #include "generic.cuh"
 #include "postprocess.cuh"
 #include "backward.cuh"
+#include "pack_device.cuh"
 
 using namespace gnncca;
 
@@ -467,6 +468,36 @@ size_t gnncca_backward_workspace_bytes(const gnncca_mpn_dims* d, int64_t n_nodes
     auto up = [](size_t v) { return (v + 255) / 256 * 256; };
     return up(N * 4) + up(N * kH * 4) + up(N * 44 * 4) + 2 * up(N * kH * 4) + 2 * up(E * kEF * 4) + 2 * up(N * F1 * 4) +
            up(32 * N * F1 * 4) + up(sizeof(double) * 128) + up(sizeof(float) * 128);
+}
+
+size_t gnncca_pack_program_bytes(void) { return sizeof(PackProgram); }
+
+int gnncca_pack_program(const gnncca_mpn_dims* d, void* program_host, size_t program_bytes) {
+    if (!dims_valid(d) || !program_host) return GNNCCA_ERR_INVALID_ARG;
+    if (classify(d) != kFamilyMfma32x6) return GNNCCA_ERR_UNSUPPORTED;
+    if (program_bytes < sizeof(PackProgram)) return GNNCCA_ERR_INVALID_ARG;
+    return pack_program(d, static_cast<PackProgram*>(program_host)) ? GNNCCA_OK : GNNCCA_ERR_UNSUPPORTED;
+}
+
+int gnncca_pack_weights_device(const gnncca_mpn_dims* d, const float* const* params_dev, int n_params, const void* program_dev,
+                               void* packed_dev, size_t packed_bytes, gnncca_stream_t stream) {
+    if (!dims_valid(d) || !params_dev || !program_dev || !packed_dev) return GNNCCA_ERR_INVALID_ARG;
+    if (classify(d) != kFamilyMfma32x6) return GNNCCA_ERR_UNSUPPORTED;
+    if (n_params != gnncca_param_count(d) || n_params > kMaxPackParams) return GNNCCA_ERR_INVALID_ARG;
+    if (packed_bytes < gnncca_packed_weights_bytes(d)) return GNNCCA_ERR_INVALID_ARG;
+    PackProgram host;  // segment count only: the program itself is read on the device
+    if (!pack_program(d, &host)) return GNNCCA_ERR_UNSUPPORTED;
+    PackPtrs ptrs;
+    std::memset(&ptrs, 0, sizeof(ptrs));
+    for (int i = 0; i < n_params; ++i) {
+        if (!params_dev[i]) return GNNCCA_ERR_INVALID_ARG;
+        ptrs.p[i] = params_dev[i];
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(pack_device_kernel, dim3(64, (unsigned)host.n_segs + 1), dim3(256), 0, st,
+                       static_cast<const PackProgram*>(program_dev), ptrs, static_cast<float*>(packed_dev));
+    HIP_TRY(hipGetLastError());
+    return GNNCCA_OK;
 }
 
 int gnncca_mpn_backward(const gnncca_mpn_dims* d, const float* const* params_dev, int n_params, const float* x,

@@ -219,6 +219,100 @@ static Folded fold_layer(const gnncca_layer& l, const float* const*& cur) {
     return f;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// The blob of gnncca_pack_weights restated as data: every region is a strided copy out of one parameter tensor,
+// optionally through the BatchNorm fold.  Kept next to the host packer on purpose -- tests/test_boundary.py and
+// tests/test_gpu_parity.py check that interpreting this program reproduces the host blob byte for byte.
+bool pack_program(const gnncca_mpn_dims* d, PackProgram* out) {
+    if (!out || classify(d) != kFamilyMfma32x6) return false;
+    const BlobPlan p = plan_blob(d);
+    std::memset(out, 0, sizeof(*out));
+    out->header = p.h;
+    int n = 0;
+    bool overflow = false;
+    struct Lin {
+        int w, b, bn, in, out;
+    };
+    int cur = 0;
+    auto next = [&](const gnncca_layer& l) {
+        Lin r;
+        r.w = cur++;
+        r.b = cur++;
+        r.bn = l.has_bn ? cur : -1;
+        if (l.has_bn) cur += 4;
+        r.in = l.in_dim;
+        r.out = l.out_dim;
+        return r;
+    };
+    auto weight = [&](const Lin& L, int dst, int src_off, int rows, int cols, int unit0, int drs, int dcs, int srs, int scs) {
+        if (n >= kMaxPackSegs) { overflow = true; return; }
+        PackSeg& g = out->segs[n++];
+        g.kind = 0, g.dst = dst, g.param = L.w, g.bn = L.bn, g.src_off = src_off, g.rows = rows, g.cols = cols, g.unit0 = unit0;
+        g.drs = drs, g.dcs = dcs, g.srs = srs, g.scs = scs;
+    };
+    auto bias = [&](const Lin& L, int dst, int rows) {
+        if (n >= kMaxPackSegs) { overflow = true; return; }
+        PackSeg& g = out->segs[n++];
+        g.kind = 1, g.dst = dst, g.param = L.b, g.bn = L.bn, g.rows = rows, g.cols = 1, g.drs = 1, g.srs = 1;
+    };
+    const int nf = d->reattach_nodes ? 2 : 1, ef = d->reattach_edges ? 2 : 1;
+    const int hin = nf * kH, ein = ef * kEF;
+    // encoder.node_mlp
+    for (int i = 0; i < d->enc_node.n_layers; ++i) {
+        const Lin L = next(d->enc_node.layers[i]);
+        weight(L, p.h.enc_node_w[i], 0, L.out, L.in, 0, L.in, 1, L.in, 1);
+        bias(L, p.h.enc_node_b[i], L.out);
+        if (i == 0 && p.h.enc_w3) {
+            if (n >= kMaxPackSegs) return false;
+            PackSeg& g = out->segs[n++];
+            g.kind = 2, g.dst = p.h.enc_w3, g.param = L.w, g.bn = L.bn, g.rows = L.out, g.cols = L.in, g.drs = L.in, g.dcs = 1;
+            g.srs = L.in, g.scs = 1, g.plane = L.in * L.out;
+        }
+        if (i == d->enc_node.n_layers - 1) weight(L, p.h.enc_last_wT, 0, kH, L.in, 0, 1, kH, L.in, 1);
+    }
+    // encoder.edge_mlp
+    const Lin Le0 = next(d->enc_edge.layers[0]);
+    weight(Le0, p.h.enc_edge_w, 0, kEF, d->edge_in, 0, d->edge_in, 1, d->edge_in, 1);
+    bias(Le0, p.h.enc_edge_b, kEF);
+    // MPNet.edge_model.edge_mlp : columns [src | dst | edge]   (mpn.py:68)
+    const Lin Le = next(d->edge_mlp.layers[0]);
+    weight(Le, p.h.proj_wT + 8, 0, kEF, hin, 0, 1, kProjOut, Le.in, 1);        // P_src
+    weight(Le, p.h.proj_wT + 0, hin, kEF, hin, 0, 1, kProjOut, Le.in, 1);      // P_dst
+    weight(Le, p.h.wee, 2 * hin, kEF, ein, 0, ein, 1, Le.in, 1);
+    bias(Le, p.h.proj_b + 8, kEF);
+    // MPNet.node_model.node_mlp : columns [x[row] | edge]        (mpn.py:97)
+    const Lin Ln = next(d->node_mlp.layers[0]);
+    weight(Ln, p.h.proj_wT + 16, 0, kH, hin, 0, 1, kProjOut, Ln.in, 1);        // Q
+    bias(Ln, p.h.proj_b + 16, kH);
+    for (int s = 0; s < 3; ++s)
+        for (int h = 0; h < 2; ++h) weight(Ln, p.h.wne_b + s * 64 + h * 32, hin + 2 * s + h, kH, 1, 0, 1, 0, Ln.in, 0);
+    // classifier.edge_mlp
+    const Lin Lc1 = next(d->cls_edge.layers[0]);
+    weight(Lc1, p.h.cls_w1, 0, Lc1.out, kEF, 0, kEF, 1, kEF, 1);
+    bias(Lc1, p.h.cls_b1, Lc1.out);
+    Lin Lc2 = Lc1;
+    if (d->cls_edge.n_layers == 2) {
+        Lc2 = next(d->cls_edge.layers[1]);
+        weight(Lc2, p.h.cls_w2, 0, 1, Lc2.in, 0, Lc2.in, 1, Lc2.in, 1);
+        bias(Lc2, p.h.cls_b2, 1);
+    }
+    if (p.h.fast_consts) {  // the transposed copies mpn_step_fast_kernel reads into SGPR pairs
+        const int fc = p.h.fast_consts;
+        weight(Le0, fc + kFcEncW, 0, kEF, 4, 0, 1, kEF, 4, 1);
+        bias(Le0, fc + kFcEncB, kEF);
+        weight(Le, fc + kFcWee, 2 * hin, kEF, kEF, 0, 1, kEF, Le.in, 1);
+        weight(Lc1, fc + kFcCw1, 0, 4, kEF, 0, 1, 4, kEF, 1);
+        bias(Lc1, fc + kFcCb1, 4);
+        weight(Lc2, fc + kFcCw2, 0, 1, 4, 0, 4, 1, 4, 1);
+        bias(Lc2, fc + kFcCb2, 1);
+        bias(Le, fc + kFcProjB + 8, kEF);
+        bias(Ln, fc + kFcProjB + 16, kH);
+    }
+    out->n_segs = n;
+    return !overflow && cur == gnncca_param_count(d);
+}
+
 }  // namespace gnncca
 
 using namespace gnncca;

@@ -157,6 +157,7 @@ class MOTMPNet(nn.Module):
         self._workspace = None     # grow-only device scratch
         self._weights_dirty = True
         self._param_cache = None
+        self._pack_state = None    # (device copy of the pack program, persistent blob) for the on-GPU repack
         self.last_workspace_bytes = 0
         # 'fp32' (default: bit-faithful to the reference within summation order) or 'bf16': the edge latents are kept
         # as bf16 in HBM between steps (GNNCCA_OPT_EDGE_STATE_BF16); arithmetic stays fp32
@@ -226,6 +227,7 @@ class MOTMPNet(nn.Module):
     def _apply(self, fn, *a, **k):  # .cuda() / .to() / .float()
         self._weights_dirty = True
         self._param_cache = None
+        self._pack_state = None
         return super()._apply(fn, *a, **k)
 
     def load_state_dict(self, *a, **k):
@@ -255,10 +257,34 @@ class MOTMPNet(nn.Module):
     def _version_key(self):
         return sum(t._version for t in self.native_param_tensors())
 
+    def _pack_weights_device(self, device):
+        """Repack on the GPU (gnncca_pack_weights_device): no host round trip, enqueued on the current stream.
+        Returns None when this configuration / parameter placement needs the host packer."""
+        lib, d = nat.lib(), self.native_dims()
+        params = self.native_param_tensors()
+        if any(t.device != device or t.dtype != torch.float32 or not t.is_contiguous() for t in params):
+            return None
+        st = self._pack_state
+        if st is None or st[0].device != device:
+            nbytes = lib.gnncca_pack_program_bytes()
+            prog = torch.zeros(nbytes, dtype=torch.uint8)
+            if lib.gnncca_pack_program(C.byref(d), prog.data_ptr(), nbytes) != nat.OK:
+                return None  # generic family
+            blob = torch.zeros(lib.gnncca_packed_weights_bytes(C.byref(d)), dtype=torch.uint8, device=device)
+            st = self._pack_state = (prog.to(device), blob)
+        prog, blob = st
+        ptrs = (C.c_void_p * len(params))(*[t.data_ptr() for t in params])
+        with torch.cuda.device(device):
+            status = lib.gnncca_pack_weights_device(C.byref(d), ptrs, len(params), prog.data_ptr(), blob.data_ptr(), blob.numel(),
+                                                    torch.cuda.current_stream(device).cuda_stream)
+        nat.check(status, "gnncca_pack_weights_device")
+        return blob
+
     def _packed_weights(self, device):
         if self._weights_dirty or self._packed is None or self._packed[1].device != device \
                 or self._packed[0] != self._version_key():
-            self.set_packed_weights(self.pack_weights_host().to(device))
+            blob = self._pack_weights_device(device)
+            self.set_packed_weights(blob if blob is not None else self.pack_weights_host().to(device))
         return self._packed[1]
 
     def _scratch(self, nbytes, device):

@@ -114,6 +114,20 @@ GNNCCA_API size_t gnncca_packed_weights_bytes(const gnncca_mpn_dims* dims);
 GNNCCA_API int gnncca_pack_weights(const gnncca_mpn_dims* dims, const float* const* params, int n_params,
                         void* packed_host, size_t packed_bytes);
 
+/* DEVICE variant of gnncca_pack_weights for the tuned (H = 32, EF = 6) family: the same blob, byte for byte, built by
+ * one kernel straight from the parameter tensors in HBM -- a training step (train.py:492-494: the optimizer has just
+ * rewritten every parameter) or a load_state_dict() never moves the weights through the host.
+ *   gnncca_pack_program(dims, program_host, bytes)  HOST: the copy/fold program for `dims`
+ *                                                   (gnncca_pack_program_bytes() bytes); upload it once.
+ *   gnncca_pack_weights_device(...)                 enqueues the packing on `stream`.  `params_dev`: a HOST array of
+ *                                                   DEVICE pointers in the canonical order; `packed_dev` must have
+ *                                                   been zero-filled once (padding words are not rewritten).
+ * GNNCCA_ERR_UNSUPPORTED for the generic family (use the host packer). */
+GNNCCA_API size_t gnncca_pack_program_bytes(void);
+GNNCCA_API int gnncca_pack_program(const gnncca_mpn_dims* dims, void* program_host, size_t program_bytes);
+GNNCCA_API int gnncca_pack_weights_device(const gnncca_mpn_dims* dims, const float* const* params_dev, int n_params,
+                               const void* program_dev, void* packed_dev, size_t packed_bytes, gnncca_stream_t stream);
+
 /* Bytes of device scratch one forward over a graph of N nodes / E edges needs. */
 GNNCCA_API size_t gnncca_workspace_bytes(const gnncca_mpn_dims* dims, int64_t n_nodes, int64_t n_edges);
 

@@ -204,3 +204,75 @@ def test_packed_blob_reproduces_reference(name):
     assert len(out) == int(a["n_logits"])
     for i, o in enumerate(out):
         assert np.abs(o - a[f"logits_{i}"]).max() <= 5e-6, (name, i)
+
+
+# ---- the device-side pack program (gnncca_pack_program), interpreted in numpy ------------------------------------
+class PackSeg(C.Structure):  # mirror of csrc/internal.h: PackSeg
+    _fields_ = [(n, C.c_int32) for n in ("kind", "dst", "param", "bn", "src_off", "rows", "cols", "unit0", "drs", "dcs", "srs",
+                                         "scs", "plane")] + [("pad", C.c_int32 * 3)]
+
+
+class PackProgram(C.Structure):
+    _fields_ = [("header", BlobHeader), ("n_segs", C.c_int32), ("pad", C.c_int32 * 3), ("segs", PackSeg * 96)]
+
+
+def _bf16_rne(v):
+    u = v.astype(np.float32).view(np.uint32).astype(np.uint64)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) >> 16
+    return u.astype(np.uint16)
+
+
+def run_pack_program(prog, params, nbytes):
+    """What pack_device_kernel does, restated with numpy: strided copies through the BatchNorm fold (double, one rounding
+    per operation), plus the three bf16 planes of the first encoder weight."""
+    blob = np.zeros(nbytes // 4, dtype=np.float32)
+    hdr = np.frombuffer(bytes(prog.header), dtype=np.float32)
+    blob[:len(hdr)] = hdr
+    u16 = blob.view(np.uint16)
+    for g in list(prog.segs)[:prog.n_segs]:
+        src = params[g.param].ravel()
+        r, c = np.meshgrid(np.arange(g.rows), np.arange(g.cols), indexing="ij")
+        v = src[g.src_off + r * g.srs + c * g.scs].astype(np.float32)
+        if g.bn >= 0:
+            gamma, beta, mean, var = (params[g.bn + k].astype(np.float64) for k in range(4))
+            s = (gamma / np.sqrt(var + 1e-5))[g.unit0 + r]
+            if g.kind == 1:
+                v = ((v.astype(np.float64) - mean[g.unit0 + r]) * s + beta[g.unit0 + r]).astype(np.float32)
+            else:
+                v = (v.astype(np.float64) * s).astype(np.float32)
+        k = r * g.drs + c * g.dcs
+        if g.kind == 2:
+            h0 = _bf16_rne(v)
+            r1 = v - (h0.astype(np.uint32) << 16).view(np.float32)
+            h1 = _bf16_rne(r1)
+            r2 = r1 - (h1.astype(np.uint32) << 16).view(np.float32)
+            base = 2 * g.dst
+            u16[base + k], u16[base + g.plane + k], u16[base + 2 * g.plane + k] = h0, h1, _bf16_rne(r2)
+        else:
+            blob[g.dst + k] = v
+    return blob
+
+
+@pytest.mark.parametrize("name", [n for n in golden_cases() if not n.startswith("generic_")])
+def test_pack_program_reproduces_host_blob(name):
+    from gnn_cca_amd import _native as nat
+    m, params, arch, sd, a = _model(name)
+    lib, d = nat.lib(), m.native_dims()
+    assert lib.gnncca_pack_program_bytes() == C.sizeof(PackProgram)
+    prog = PackProgram()
+    nat.check(lib.gnncca_pack_program(C.byref(d), C.byref(prog), C.sizeof(prog)), "gnncca_pack_program")
+    host = m.pack_weights_host().numpy()
+    tensors = [t.detach().numpy() for t in m.native_param_tensors()]
+    emulated = run_pack_program(prog, tensors, host.size)
+    assert np.array_equal(emulated.view(np.uint8), host), name
+
+
+def test_pack_program_refuses_generic_family():
+    gen = [n for n in golden_cases() if n.startswith("generic_")]
+    if not gen:
+        pytest.skip("no generic golden case")
+    from gnn_cca_amd import _native as nat
+    m, *_ = _model(gen[0])
+    d = m.native_dims()
+    prog = PackProgram()
+    assert nat.lib().gnncca_pack_program(C.byref(d), C.byref(prog), C.sizeof(prog)) == nat.ERR_UNSUPPORTED

@@ -237,3 +237,30 @@ def test_bf16_edge_state_option(name):
         out32 = m(to_data(a))["classified_edges"]
     for i, o in enumerate(out32):
         assert np.abs(o.cpu().numpy() - a[f"logits_{i}"]).max() <= TOL_TIGHT
+
+
+@pytest.mark.parametrize("name", [n for n in golden_cases() if not n.startswith("generic_")])
+def test_device_pack_equals_host_pack(name):
+    """gnncca_pack_weights_device (what a training step / load_state_dict uses) builds the host packer's blob byte for
+    byte: BatchNorm fold in double, split-weight layouts, bf16 planes."""
+    params, arch, sd, a = load_case(os.path.join(GOLDEN_DIR, name + ".npz"))
+    m = build(params, arch, sd)
+    dev_blob = m._pack_weights_device(torch.device("cuda", torch.cuda.current_device()))
+    assert dev_blob is not None, "tuned family must pack on the GPU"
+    torch.cuda.synchronize()
+    assert torch.equal(dev_blob.cpu(), m.pack_weights_host()), name
+
+
+def test_device_repack_follows_parameter_updates():
+    params, arch, sd, a = load_case(os.path.join(GOLDEN_DIR, "dense64.npz"))
+    m = build(params, arch, sd)
+    data = to_data(a)
+    with torch.no_grad():
+        before = m(data)["classified_edges"][-1].clone()
+        for p in m.parameters():
+            p.mul_(1.01)            # in-place update, like an optimizer step: bumps the tensors' version counters
+        after = m(data)["classified_edges"][-1]
+        m2 = build(params, arch, {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()})
+        assert torch.equal(m._packed[1].cpu(), m2.pack_weights_host())
+        assert not torch.equal(before, after)
+        assert torch.allclose(after, m2(data)["classified_edges"][-1], atol=0, rtol=0)
