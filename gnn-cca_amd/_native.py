@@ -47,6 +47,7 @@ class Profile(C.Structure):
 
 
 OPT_EDGE_STATE_BF16 = 1
+BWD_GRADS_ZEROED = 1
 
 
 _SIGNATURES = {
@@ -82,6 +83,9 @@ _SIGNATURES = {
     "gnncca_mpn_backward": (C.c_int, [C.POINTER(MpnDims), C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_int64, C.c_int64, C.POINTER(Trace), C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p),
                                       C.c_void_p, C.c_size_t, C.c_void_p]),
+    "gnncca_mpn_backward_ex": (C.c_int, [C.POINTER(MpnDims), C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_int64, C.c_int64, C.POINTER(Trace), C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p),
+                                         C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p]),
     "gnncca_classifier_train": (C.c_int, [C.POINTER(MpnDims), C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_int64, C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.c_void_p]),
     "gnncca_read_graph_flags": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.c_void_p]),

@@ -9,8 +9,9 @@
 //   edge update     (models/mpn.py:48,68-69) d e_s -> ReLU' -> d W_ee, d b_e, d P_src[row], d P_dst[col], d e_{s-1}
 //   projections     d (P_src | P_dst | Q) -> d h_{s-1}, d W_src, d W_dst, d W_nx
 // then the two encoders.  Parameter gradients are sums over edges / nodes: per-edge contributions are reduced across
-// the wave sixteen at a time (transposing butterfly, wave_atomic_add16) and added with one float atomic per value
-// per wave; sums of outer products over nodes run on the fp32 MFMA pipe (bwd_outer_mfma_kernel).  The result depends
+// the wave sixteen at a time (transposing butterfly, wave_lds_add16) into workgroup-resident LDS sums that reach
+// global memory with one float atomic per value and (persistent) workgroup; sums of outer products over nodes run on
+// the fp32 MFMA pipe (bwd_outer_mfma_kernel).  The result depends
 // on arrival order in the last bits exactly like the reference on CUDA (cuBLAS / torch_scatter atomics).
 // Supported: the MFMA family without reattach flags, without BatchNorm, 'sum' / 'mean', two-layer node encoder.
 // Part of the single translation unit mpn_forward.hip.
@@ -26,17 +27,6 @@ __device__ __forceinline__ float wave_reduce_sum(float v) {
 __device__ __forceinline__ void wave_atomic_add(float* dst, float v) {
     v = wave_reduce_sum(v);
     if ((threadIdx.x & 63) == 0 && v != 0.f) atomicAdd(dst, v);
-}
-
-// Sixteen contributions every lane holds, each summed over the wave and added to its own address: one transposing
-// reduction (17 cross-lane operations instead of 96) and ONE atomic instruction, issued by the 16 lanes 4 idx that
-// end up holding the sums.  `dst_of(idx)` maps idx -> address (nullptr: slot unused); it is evaluated per lane.
-template <typename DstOf>
-__device__ __forceinline__ void wave_atomic_add16(const float (&v)[16], DstOf dst_of) {
-    const float z = transpose_reduce16(v);
-    const int lane = threadIdx.x & 63;
-    float* dst = dst_of(lane >> 2);
-    if ((lane & 3) == 0 && dst != nullptr && z != 0.f) atomicAdd(dst, z);
 }
 
 __global__ __launch_bounds__(256) void bwd_degree_kernel(const long long* __restrict__ ei, long long E, int N, int* __restrict__ deg) {
@@ -57,6 +47,8 @@ __global__ __launch_bounds__(256) void bwd_q_kernel(const float* __restrict__ h,
     for (int d = 0; d < kH; ++d) acc = fmaf(Wn[c * (kH + kEF) + d], h[(size_t)i * kH + d], acc);
     Q[t] = acc;
 }
+
+constexpr int kBwdLdsRows = 64;  // source rows a workgroup of bwd_edge_kernel accumulates in LDS
 
 struct BwdEdgeParams {
     const long long* ei;
@@ -91,157 +83,254 @@ struct BwdEdgeParams {
     int N, cls_hidden;     // cls_hidden == 0: single Linear(6,1)
 };
 
+// Workgroup-resident accumulators of the parameter gradients this kernel produces (LDS slots):
+constexpr int kSlotWe = 0;                    // [6][6]  d W_ee
+constexpr int kSlotBe = kSlotWe + 36;         // [6]     d b_e
+constexpr int kSlotWn = kSlotBe + 6;          // [32][6] d W_ne
+constexpr int kSlotBn = kSlotWn + 192;        // [32]    d b_n
+constexpr int kSlotWc1 = kSlotBn + 32;        // [C1][6] d W_cls1   (C1 <= kMaxCls; single Linear: [1][6])
+constexpr int kSlotBc1 = kSlotWc1 + 6 * kMaxCls;
+constexpr int kSlotWc2 = kSlotBc1 + kMaxCls;  // [C1]    d W_cls2
+constexpr int kSlotBc2 = kSlotWc2 + kMaxCls;  // [1]
+constexpr int kBwdSlots = kSlotBc2 + 1;
+
+// Sixteen contributions every lane holds, each summed over the wave and added to its own LDS slot: one transposing
+// reduction (17 cross-lane operations instead of 96) and ONE ds_add_f32, issued by the 16 lanes 4 idx that end up
+// holding the sums.  `slot_of(idx)` maps idx -> slot (-1: unused); it is evaluated per lane.
+template <typename SlotOf>
+__device__ __forceinline__ void wave_lds_add16(const float (&v)[16], float* s_acc, SlotOf slot_of) {
+    const float z = transpose_reduce16(v);
+    const int lane = threadIdx.x & 63;
+    const int slot = slot_of(lane >> 2);
+    if ((lane & 3) == 0 && slot >= 0 && z != 0.f) atomicAdd(&s_acc[slot], z);
+}
+
+// One thread per edge, a PERSISTENT grid: a workgroup walks 256-edge chunks and keeps its parameter-gradient sums in
+// LDS for its whole lifetime, so global memory sees one atomic per parameter and workgroup instead of one per wave
+// (every wave hammering the same 1.3 KB of gradient memory was what bounded the first version of this kernel).
 __global__ __launch_bounds__(256) void bwd_edge_kernel(const BwdEdgeParams p) {
-    const long long k0 = (long long)blockIdx.x * 256 + threadIdx.x;
-    const bool valid = k0 < p.E;
-    const long long k = valid ? k0 : p.E - 1;  // every lane takes part in the wave reductions; invalid lanes add zeros
-    const float live = valid ? 1.f : 0.f;
-    const int i = (int)p.ei[k], j = (int)p.ei[p.E + k];
-    float es[kEF], ep[kEF], ge[kEF];
+    __shared__ float s_acc[kBwdSlots];
+    // Gradients of the per-node tables indexed by the SOURCE row (d P_src, d Q) are first summed in LDS: with rows
+    // sorted (the usual edge order) a chunk's 256 edges touch a handful of rows, so the ~15-255 same-address global
+    // atomics per row become LDS atomics plus ONE global atomic per (row, column) and chunk.  Rows further than
+    // kBwdLdsRows from the chunk's first row (unsorted or very sparse input) go straight to global memory.
+    __shared__ float s_dp[kBwdLdsRows * 44];
+    for (int t = threadIdx.x; t < kBwdSlots; t += 256) s_acc[t] = 0.f;
+    // The small read-only tensors are read through the CONSTANT address space: wave-uniform reads become s_load
+    // into SGPRs and are not ordered against the atomics below.
+    typedef const float __attribute__((address_space(4))) cfloat;
+    cfloat* We = (cfloat*)(unsigned long long)p.We;
+    cfloat* Wn = (cfloat*)(unsigned long long)p.Wn;
+    cfloat* Wc1 = (cfloat*)(unsigned long long)p.Wc1;
+    cfloat* bc1 = (cfloat*)(unsigned long long)p.bc1;
+    cfloat* Wc2 = (cfloat*)(unsigned long long)p.Wc2;
+    cfloat* bn_gamma = (cfloat*)(unsigned long long)p.bn_gamma;
+    cfloat* bn_beta = (cfloat*)(unsigned long long)p.bn_beta;
+    cfloat* bn_stat = (cfloat*)(unsigned long long)p.bn_stat;
+    cfloat* bn_red = (cfloat*)(unsigned long long)p.bn_red;
+    const int lane = threadIdx.x & 63;
+
+    for (long long chunk = blockIdx.x; chunk * 256 < p.E; chunk += gridDim.x) {
+        const long long k0 = chunk * 256 + threadIdx.x;
+        const bool valid = k0 < p.E;
+        const long long k = valid ? k0 : p.E - 1;  // every lane takes part in the wave reductions; invalid lanes add zeros
+        const float live = valid ? 1.f : 0.f;
+        const int i = (int)p.ei[k], j = (int)p.ei[p.E + k];
+        const int i_first = (int)p.ei[chunk * 256];
+        for (int t = threadIdx.x; t < kBwdLdsRows * 44; t += 256) s_dp[t] = 0.f;
+        __syncthreads();
+        const unsigned li = (unsigned)(i - i_first);
+        auto add_row = [&](int col, float v) {
+            if (li < (unsigned)kBwdLdsRows)
+                atomicAdd(&s_dp[li * 44 + col], v);
+            else
+                atomicAdd(&p.dP[(size_t)i * 44 + col], v);
+        };
+        // the row's Q and d h rows, requested up front (16 x 16 B per lane) so that the channel loop has no loads
+        float q_row[kH], gh_row[kH];
+        if (p.g_h) {
+            const f32x4* __restrict__ q4 = reinterpret_cast<const f32x4*>(p.Q + (size_t)i * kH);
+            const f32x4* __restrict__ g4 = reinterpret_cast<const f32x4*>(p.g_h + (size_t)i * kH);
 #pragma unroll
-    for (int f = 0; f < kEF; ++f) {
-        es[f] = p.e_cur[k * kEF + f];
-        ep[f] = p.e_prev[k * kEF + f];
-        ge[f] = p.ge_in ? p.ge_in[k * kEF + f] * live : 0.f;
-    }
-    // ---- classifier ------------------------------------------------------------------------------------------
-    if (p.g_logit) {
-        const float dz = p.g_logit[k] * live;
-        if (p.cls_hidden > 0 && p.bn_stat) {
-            // Linear -> BatchNorm(batch statistics) -> ReLU -> Linear.  d W2, d b2, d gamma, d beta were formed by
-            // bwd_cls_bn_reduce_kernel; here: g_z = gamma * invstd * (g_y - mean(g_y) - z_hat * mean(g_y z_hat))
-            // two hidden units per reduction: slots [8u + 0] d b1[q0+u], [8u + 1 + f] d W1[q0+u][f]
-            for (int q0 = 0; q0 < p.cls_hidden; q0 += 2) {
+            for (int c = 0; c < kH / 4; ++c) {
+                const f32x4 a = q4[c], b = g4[c];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) q_row[4 * c + u] = a[u], gh_row[4 * c + u] = b[u];
+            }
+        }
+        float es[kEF], ep[kEF], ge[kEF];
+#pragma unroll
+        for (int f = 0; f < kEF; ++f) {
+            es[f] = p.e_cur[k * kEF + f];
+            ep[f] = p.e_prev[k * kEF + f];
+            ge[f] = p.ge_in ? p.ge_in[k * kEF + f] * live : 0.f;
+        }
+        // ---- classifier ----------------------------------------------------------------------------------------
+        if (p.g_logit) {
+            const float dz = p.g_logit[k] * live;
+            if (p.cls_hidden > 0 && p.bn_stat) {
+                // Linear -> BatchNorm(batch statistics) -> ReLU -> Linear.  d W2, d b2, d gamma, d beta were formed by
+                // bwd_cls_bn_reduce_kernel; here: g_z = gamma * invstd * (g_y - mean(g_y) - z_hat * mean(g_y z_hat))
+                // two hidden units per reduction: slots [8u + 0] d b1[q0+u], [8u + 1 + f] d W1[q0+u][f]
+                for (int q0 = 0; q0 < p.cls_hidden; q0 += 2) {
+                    float v[16];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int q = min(q0 + u, p.cls_hidden - 1);
+                        float z1 = bc1[q];
+#pragma unroll
+                        for (int f = 0; f < kEF; ++f) z1 = fmaf(Wc1[q * kEF + f], es[f], z1);
+                        const float zh = (z1 - bn_stat[2 * q]) * bn_stat[2 * q + 1];
+                        const float y = fmaf(bn_gamma[q], zh, bn_beta[q]);
+                        const float gy = y > 0.f ? Wc2[q] * dz : 0.f;
+                        float gz1 = live * bn_gamma[q] * bn_stat[2 * q + 1] * (gy - bn_red[2 * q] - zh * bn_red[2 * q + 1]);
+                        if (q0 + u >= p.cls_hidden) gz1 = 0.f;
+                        v[8 * u] = gz1;
+                        v[8 * u + 7] = 0.f;
+#pragma unroll
+                        for (int f = 0; f < kEF; ++f) {
+                            v[8 * u + 1 + f] = gz1 * es[f];
+                            ge[f] = fmaf(Wc1[q * kEF + f], gz1, ge[f]);
+                        }
+                    }
+                    wave_lds_add16(v, s_acc, [&](int idx) {
+                        const int q = q0 + (idx >> 3), r = idx & 7;
+                        if (q >= p.cls_hidden || r == 7) return -1;
+                        return r == 0 ? kSlotBc1 + q : kSlotWc1 + q * kEF + r - 1;
+                    });
+                }
+            } else if (p.cls_hidden > 0) {
+                {
+                    const float s = wave_reduce_sum(dz);
+                    if (lane == 0 && s != 0.f) atomicAdd(&s_acc[kSlotBc2], s);
+                }
+                // two hidden units per reduction: slots [8u + 0] d W2[q], [8u + 1] d b1[q], [8u + 2 + f] d W1[q][f]
+                for (int q0 = 0; q0 < p.cls_hidden; q0 += 2) {
+                    float v[16];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int q = min(q0 + u, p.cls_hidden - 1);
+                        const bool on = q0 + u < p.cls_hidden;
+                        float z1 = bc1[q];
+#pragma unroll
+                        for (int f = 0; f < kEF; ++f) z1 = fmaf(Wc1[q * kEF + f], es[f], z1);
+                        const float gz1 = (on && z1 > 0.f) ? Wc2[q] * dz : 0.f;
+                        v[8 * u] = on ? dz * fmaxf(z1, 0.f) : 0.f;
+                        v[8 * u + 1] = gz1;
+#pragma unroll
+                        for (int f = 0; f < kEF; ++f) {
+                            v[8 * u + 2 + f] = gz1 * es[f];
+                            ge[f] = fmaf(Wc1[q * kEF + f], gz1, ge[f]);
+                        }
+                    }
+                    wave_lds_add16(v, s_acc, [&](int idx) {
+                        const int q = q0 + (idx >> 3), r = idx & 7;
+                        if (q >= p.cls_hidden) return -1;
+                        return r == 0 ? kSlotWc2 + q : (r == 1 ? kSlotBc1 + q : kSlotWc1 + q * kEF + r - 2);
+                    });
+                }
+            } else {
+                float v[16];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) v[q] = 0.f;
+                v[0] = dz;
+#pragma unroll
+                for (int f = 0; f < kEF; ++f) {
+                    v[1 + f] = dz * es[f];
+                    ge[f] = fmaf(Wc1[f], dz, ge[f]);
+                }
+                wave_lds_add16(v, s_acc, [&](int idx) { return idx == 0 ? kSlotBc1 : (idx <= kEF ? kSlotWc1 + idx - 1 : -1); });
+            }
+        }
+        // ---- node update -----------------------------------------------------------------------------------------
+        if (p.g_h) {
+            const float inv = p.deg ? 1.f / (float)max(p.deg[i], 1) : 1.f;
+            // two channels per reduction: slots [8u + 0] d b_n[c0+u], [8u + 1 + f] d W_ne[c0+u][f]
+#pragma unroll
+            for (int c0 = 0; c0 < kH; c0 += 2) {
                 float v[16];
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
-                    const int q = min(q0 + u, p.cls_hidden - 1);
-                    float z1 = p.bc1[q];
+                    const int c = c0 + u;
+                    float b = q_row[c];
 #pragma unroll
-                    for (int f = 0; f < kEF; ++f) z1 = fmaf(p.Wc1[q * kEF + f], es[f], z1);
-                    const float zh = (z1 - p.bn_stat[2 * q]) * p.bn_stat[2 * q + 1];
-                    const float y = fmaf(p.bn_gamma[q], zh, p.bn_beta[q]);
-                    const float gy = y > 0.f ? p.Wc2[q] * dz : 0.f;
-                    float gz1 = live * p.bn_gamma[q] * p.bn_stat[2 * q + 1] * (gy - p.bn_red[2 * q] - zh * p.bn_red[2 * q + 1]);
-                    if (q0 + u >= p.cls_hidden) gz1 = 0.f;
-                    v[8 * u] = gz1;
+                    for (int f = 0; f < kEF; ++f) b = fmaf(Wn[c * (kH + kEF) + kH + f], es[f], b);
+                    const float gb = b > 0.f ? gh_row[c] * inv * live : 0.f;
+                    v[8 * u] = gb;
                     v[8 * u + 7] = 0.f;
 #pragma unroll
                     for (int f = 0; f < kEF; ++f) {
-                        v[8 * u + 1 + f] = gz1 * es[f];
-                        ge[f] = fmaf(p.Wc1[q * kEF + f], gz1, ge[f]);
+                        v[8 * u + 1 + f] = gb * es[f];
+                        ge[f] = fmaf(Wn[c * (kH + kEF) + kH + f], gb, ge[f]);
                     }
+                    if (gb != 0.f) add_row(12 + c, gb);
                 }
-                wave_atomic_add16(v, [&](int idx) -> float* {
-                    const int q = q0 + (idx >> 3), r = idx & 7;
-                    if (q >= p.cls_hidden || r == 7) return nullptr;
-                    return r == 0 ? p.gbc1 + q : p.gWc1 + q * kEF + r - 1;
+                wave_lds_add16(v, s_acc, [&](int idx) {
+                    const int c = c0 + (idx >> 3), r = idx & 7;
+                    if (r == 7) return -1;
+                    return r == 0 ? kSlotBn + c : kSlotWn + c * kEF + r - 1;
                 });
             }
-        } else if (p.cls_hidden > 0) {
-            wave_atomic_add(p.gbc2, dz);
-            // two hidden units per reduction: slots [8u + 0] d W2[q], [8u + 1] d b1[q], [8u + 2 + f] d W1[q][f]
-            for (int q0 = 0; q0 < p.cls_hidden; q0 += 2) {
-                float v[16];
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int q = min(q0 + u, p.cls_hidden - 1);
-                    const bool on = q0 + u < p.cls_hidden;
-                    float z1 = p.bc1[q];
-#pragma unroll
-                    for (int f = 0; f < kEF; ++f) z1 = fmaf(p.Wc1[q * kEF + f], es[f], z1);
-                    const float gz1 = (on && z1 > 0.f) ? p.Wc2[q] * dz : 0.f;
-                    v[8 * u] = on ? dz * fmaxf(z1, 0.f) : 0.f;
-                    v[8 * u + 1] = gz1;
-#pragma unroll
-                    for (int f = 0; f < kEF; ++f) {
-                        v[8 * u + 2 + f] = gz1 * es[f];
-                        ge[f] = fmaf(p.Wc1[q * kEF + f], gz1, ge[f]);
-                    }
-                }
-                wave_atomic_add16(v, [&](int idx) -> float* {
-                    const int q = q0 + (idx >> 3), r = idx & 7;
-                    if (q >= p.cls_hidden) return nullptr;
-                    return r == 0 ? p.gWc2 + q : (r == 1 ? p.gbc1 + q : p.gWc1 + q * kEF + r - 2);
-                });
-            }
-        } else {
-            float v[16];
-#pragma unroll
-            for (int q = 0; q < 16; ++q) v[q] = 0.f;
-            v[0] = dz;
-#pragma unroll
-            for (int f = 0; f < kEF; ++f) {
-                v[1 + f] = dz * es[f];
-                ge[f] = fmaf(p.Wc1[f], dz, ge[f]);
-            }
-            wave_atomic_add16(v, [&](int idx) -> float* { return idx == 0 ? p.gbc1 : (idx <= kEF ? p.gWc1 + idx - 1 : nullptr); });
         }
-    }
-    // ---- node update -------------------------------------------------------------------------------------------
-    if (p.g_h) {
-        const float inv = p.deg ? 1.f / (float)max(p.deg[i], 1) : 1.f;
-        // two channels per reduction: slots [8u + 0] d b_n[c0+u], [8u + 1 + f] d W_ne[c0+u][f]
-        for (int c0 = 0; c0 < kH; c0 += 2) {
+        // ---- edge update -----------------------------------------------------------------------------------------
+        float ga[kEF];
+#pragma unroll
+        for (int f = 0; f < kEF; ++f) {
+            ga[f] = es[f] > 0.f ? ge[f] : 0.f;
+            if (ga[f] != 0.f) {
+                add_row(f, ga[f]);
+                atomicAdd(&p.dP[(size_t)j * 44 + 6 + f], ga[f]);
+            }
+        }
+        // two output features per reduction: slots [8u + 0] d b_e[f0+u], [8u + 1 + g] d W_ee[f0+u][g]
+#pragma unroll
+        for (int f0 = 0; f0 < kEF; f0 += 2) {
             float v[16];
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                const int c = c0 + u;
-                float b = p.Q[(size_t)i * kH + c];
-#pragma unroll
-                for (int f = 0; f < kEF; ++f) b = fmaf(p.Wn[c * (kH + kEF) + kH + f], es[f], b);
-                const float gb = b > 0.f ? p.g_h[(size_t)i * kH + c] * inv * live : 0.f;
-                v[8 * u] = gb;
+                v[8 * u] = ga[f0 + u];
                 v[8 * u + 7] = 0.f;
 #pragma unroll
-                for (int f = 0; f < kEF; ++f) {
-                    v[8 * u + 1 + f] = gb * es[f];
-                    ge[f] = fmaf(p.Wn[c * (kH + kEF) + kH + f], gb, ge[f]);
-                }
-                if (gb != 0.f) atomicAdd(&p.dP[(size_t)i * 44 + 12 + c], gb);
+                for (int g = 0; g < kEF; ++g) v[8 * u + 1 + g] = ga[f0 + u] * ep[g];
             }
-            wave_atomic_add16(v, [&](int idx) -> float* {
-                const int c = c0 + (idx >> 3), r = idx & 7;
-                if (r == 7) return nullptr;
-                return r == 0 ? p.gbn + c : p.gWn + c * (kH + kEF) + kH + r - 1;
+            wave_lds_add16(v, s_acc, [&](int idx) {
+                const int f = f0 + (idx >> 3), r = idx & 7;
+                if (r == 7) return -1;
+                return r == 0 ? kSlotBe + f : kSlotWe + f * kEF + r - 1;
             });
         }
-    }
-    // ---- edge update ---------------------------------------------------------------------------------------------
-    float ga[kEF];
+        if (valid) {
 #pragma unroll
-    for (int f = 0; f < kEF; ++f) {
-        ga[f] = es[f] > 0.f ? ge[f] : 0.f;
-        if (ga[f] != 0.f) {
-            atomicAdd(&p.dP[(size_t)i * 44 + f], ga[f]);
-            atomicAdd(&p.dP[(size_t)j * 44 + 6 + f], ga[f]);
+            for (int g = 0; g < kEF; ++g) {
+                float s = 0.f;
+#pragma unroll
+                for (int f = 0; f < kEF; ++f) s = fmaf(We[f * 70 + 64 + g], ga[f], s);
+                p.ge_out[k * kEF + g] = s;
+            }
         }
-    }
-    // two output features per reduction: slots [8u + 0] d b_e[f0+u], [8u + 1 + g] d W_ee[f0+u][g]
-#pragma unroll
-    for (int f0 = 0; f0 < kEF; f0 += 2) {
-        float v[16];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            v[8 * u] = ga[f0 + u];
-            v[8 * u + 7] = 0.f;
-#pragma unroll
-            for (int g = 0; g < kEF; ++g) v[8 * u + 1 + g] = ga[f0 + u] * ep[g];
+        __syncthreads();
+        for (int t = threadIdx.x; t < kBwdLdsRows * 44; t += 256) {
+            const float v = s_dp[t];
+            const int r = i_first + t / 44;
+            if (v != 0.f && r < p.N) atomicAdd(&p.dP[(size_t)r * 44 + t % 44], v);
         }
-        wave_atomic_add16(v, [&](int idx) -> float* {
-            const int f = f0 + (idx >> 3), r = idx & 7;
-            if (r == 7) return nullptr;
-            return r == 0 ? p.gbe + f : p.gWe + f * 70 + 64 + r - 1;
-        });
+        __syncthreads();  // s_dp is cleared again at the top of the next chunk
     }
-    if (valid) {
-#pragma unroll
-        for (int g = 0; g < kEF; ++g) {
-            float s = 0.f;
-#pragma unroll
-            for (int f = 0; f < kEF; ++f) s = fmaf(p.We[f * 70 + 64 + g], ga[f], s);
-            p.ge_out[k * kEF + g] = s;
-        }
+    // ---- the workgroup's parameter-gradient sums -> global memory, one atomic each --------------------------------
+    __syncthreads();
+    for (int t = threadIdx.x; t < kBwdSlots; t += 256) {
+        const float v = s_acc[t];
+        if (v == 0.f) continue;
+        float* dst;
+        if (t < kSlotBe) dst = p.gWe + (t / kEF) * 70 + 64 + t % kEF;
+        else if (t < kSlotWn) dst = p.gbe + (t - kSlotBe);
+        else if (t < kSlotBn) dst = p.gWn + ((t - kSlotWn) / kEF) * (kH + kEF) + kH + (t - kSlotWn) % kEF;
+        else if (t < kSlotWc1) dst = p.gbn + (t - kSlotBn);
+        else if (t < kSlotBc1) dst = p.gWc1 + (t - kSlotWc1);
+        else if (t < kSlotWc2) dst = p.gbc1 + (t - kSlotBc1);
+        else if (t < kSlotBc2) dst = p.gWc2 + (t - kSlotWc2);
+        else dst = p.gbc2;
+        atomicAdd(dst, v);
     }
 }
 
@@ -377,15 +466,22 @@ __global__ __launch_bounds__(256) void bwd_node_kernel(const float* __restrict__
 // on the fp32 MFMA pipe.  Both operands of v_mfma_f32_32x32x2_f32 are read straight from global memory in their
 // natural layout -- lane (l % 32, l / 32) holds A[n + l/32][o0 + l%32] and B[n + l/32][k0 + l%32] -- so there is no
 // LDS staging: the reduction index n (rows) is the MFMA's k, two rows per instruction.  One wave owns a 32 x 64
-// output tile over a chunk of `rows_per_chunk` rows; partial tiles are added to `out` with one atomic per element.
+// output tile over a chunk of `rows_per_chunk` rows; partial tiles are added to the output with one atomic per element.
 // The column sum comes from a third MFMA against a B that is 1 in column 0 (k-tile 0 only).
-constexpr int kOuterRows = 256;
+// Rows of the product may be routed to up to three destination matrices (the per-node gradient table dP holds
+// d P_src | d P_dst | d Q side by side, and their products with h go to three different weight blocks).
+struct OuterOut {
+    float* ptr[3];
+    int ld[3];
+    int row_begin[4];  // rows [row_begin[j], row_begin[j+1]) of the product -> ptr[j] (nullptr: dropped)
+};
+
 __global__ __launch_bounds__(64) void bwd_outer_mfma_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B,
-                                                            int ldb, float* __restrict__ out, int ldo, float* __restrict__ colsum,
-                                                            int N, int O, int K) {
+                                                            int ldb, const OuterOut out, float* __restrict__ colsum, int N, int O,
+                                                            int K, int rows_per_chunk) {
     const int lane = threadIdx.x, half = lane >> 5, l32 = lane & 31;
     const int k0 = blockIdx.x * 64, o0 = blockIdx.y * 32;
-    const int n0 = blockIdx.z * kOuterRows, n1 = min(n0 + kOuterRows, N);
+    const int n0 = blockIdx.z * rows_per_chunk, n1 = min(n0 + rows_per_chunk, N);
     const int o = o0 + l32;
     const bool o_ok = o < O, k_ok0 = k0 + l32 < K, k_ok1 = k0 + 32 + l32 < K;
     const bool want_cs = colsum != nullptr && blockIdx.x == 0;
@@ -396,10 +492,10 @@ __global__ __launch_bounds__(64) void bwd_outer_mfma_kernel(const float* __restr
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc0[i] = acc1[i] = acc2[i] = 0.f;
     const float one = l32 == 0 ? 1.f : 0.f;
-    for (int n = n0; n < n1; n += 8) {  // four MFMA k-steps (8 rows) per round: 12 loads in flight
-        float a[4], b0[4], b1[4];
+    for (int n = n0; n < n1; n += 16) {  // eight MFMA k-steps (16 rows) per round: 24 loads in flight
+        float a[8], b0[8], b1[8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 8; ++u) {
             const int r = n + 2 * u + half;
             const bool ok = r < n1;
             const size_t rr = (size_t)(ok ? r : n0);
@@ -409,7 +505,7 @@ __global__ __launch_bounds__(64) void bwd_outer_mfma_kernel(const float* __restr
             b1[u] = k_ok1 ? bv1 : 0.f;
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 8; ++u) {
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b0[u], acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b1[u], acc1, 0, 0, 0);
             if (want_cs) acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], one, acc2, 0, 0, 0);
@@ -420,18 +516,36 @@ __global__ __launch_bounds__(64) void bwd_outer_mfma_kernel(const float* __restr
     for (int r = 0; r < 16; ++r) {
         const int oo = o0 + (r & 3) + 8 * (r >> 2) + 4 * half;
         if (oo < O) {
-            if (k_ok0 && acc0[r] != 0.f) atomicAdd(&out[(size_t)oo * ldo + k0 + l32], acc0[r]);
-            if (k_ok1 && acc1[r] != 0.f) atomicAdd(&out[(size_t)oo * ldo + k0 + 32 + l32], acc1[r]);
+            const int j = oo >= out.row_begin[2] ? 2 : (oo >= out.row_begin[1] ? 1 : 0);
+            float* dst = out.ptr[j];
+            if (dst != nullptr) {
+                dst += (size_t)(oo - out.row_begin[j]) * out.ld[j] + k0 + l32;
+                if (k_ok0 && acc0[r] != 0.f) atomicAdd(dst, acc0[r]);
+                if (k_ok1 && acc1[r] != 0.f) atomicAdd(dst + 32, acc1[r]);
+            }
             if (want_cs && l32 == 0 && acc2[r] != 0.f) atomicAdd(&colsum[oo], acc2[r]);
         }
     }
 }
 
+static hipError_t launch_outer_multi(const float* A, int lda, const float* B, int ldb, const OuterOut& out, float* colsum, int N,
+                                     int O, int K, hipStream_t st) {
+    // rows per wave: few output tiles -> short row chunks, so that ~1000 waves share the reduction over N
+    const long long tiles = (long long)((K + 63) / 64) * ((O + 31) / 32);
+    long long rows = ((long long)N * tiles / 1024 + 15) / 16 * 16;
+    rows = std::max<long long>(16, std::min<long long>(rows, 256));
+    const dim3 grid((unsigned)((K + 63) / 64), (unsigned)((O + 31) / 32), (unsigned)((N + rows - 1) / rows));
+    hipLaunchKernelGGL(bwd_outer_mfma_kernel, grid, dim3(64), 0, st, A, lda, B, ldb, out, colsum, N, O, K, (int)rows);
+    return hipGetLastError();
+}
+
 static hipError_t launch_outer(const float* A, int lda, const float* B, int ldb, float* out, int ldo, float* colsum, int N, int O,
                                int K, hipStream_t st) {
-    const dim3 grid((unsigned)((K + 63) / 64), (unsigned)((O + 31) / 32), (unsigned)((N + kOuterRows - 1) / kOuterRows));
-    hipLaunchKernelGGL(bwd_outer_mfma_kernel, grid, dim3(64), 0, st, A, lda, B, ldb, out, ldo, colsum, N, O, K);
-    return hipGetLastError();
+    OuterOut oo;
+    oo.ptr[0] = out, oo.ptr[1] = oo.ptr[2] = nullptr;
+    oo.ld[0] = ldo, oo.ld[1] = oo.ld[2] = 0;
+    oo.row_begin[0] = 0, oo.row_begin[1] = oo.row_begin[2] = oo.row_begin[3] = O;
+    return launch_outer_multi(A, lda, B, ldb, oo, colsum, N, O, K, st);
 }
 
 // g[t] = y[t] > 0 ? g[t] : 0     (ReLU backward from the saved output)
@@ -452,40 +566,48 @@ __global__ __launch_bounds__(256) void bwd_matmul_mask_kernel(const float* __res
     out[t] = y[t] > 0.f ? acc : 0.f;
 }
 
-// edge encoder backward: g_e0 -> ReLU' -> d W_e0 [6][A], d b_e0
+// edge encoder backward: g_e0 -> ReLU' -> d W_e0 [6][A], d b_e0.  Persistent grid with LDS-resident sums like
+// bwd_edge_kernel (A <= 7; wider raw edge attributes take one atomic per wave and value).
 __global__ __launch_bounds__(256) void bwd_edge_enc_kernel(const float* __restrict__ ge0, const float* __restrict__ e0,
                                                            const float* __restrict__ attr, int A, long long E,
                                                            float* __restrict__ gW, float* __restrict__ gb) {
-    const long long k0 = (long long)blockIdx.x * 256 + threadIdx.x;
-    const bool valid = k0 < E;
-    const long long k = valid ? k0 : E - 1;
-    if (A <= 7) {  // two output features per reduction: slots [8u + 0] d b[f0+u], [8u + 1 + a] d W[f0+u][a]
-        float at[7];
+    __shared__ float s_acc[kEF * 8];  // [f][0] d b[f], [f][1 + a] d W[f][a]
+    for (int t = threadIdx.x; t < kEF * 8; t += 256) s_acc[t] = 0.f;
+    __syncthreads();
+    for (long long chunk = blockIdx.x; chunk * 256 < E; chunk += gridDim.x) {
+        const long long k0 = chunk * 256 + threadIdx.x;
+        const bool valid = k0 < E;
+        const long long k = valid ? k0 : E - 1;
+        if (A <= 7) {  // two output features per reduction: slots [8u + 0] d b[f0+u], [8u + 1 + a] d W[f0+u][a]
+            float at[7];
 #pragma unroll
-        for (int a = 0; a < 7; ++a) at[a] = a < A ? attr[k * A + a] : 0.f;
+            for (int a = 0; a < 7; ++a) at[a] = a < A ? attr[k * A + a] : 0.f;
 #pragma unroll
-        for (int f0 = 0; f0 < kEF; f0 += 2) {
-            float v[16];
+            for (int f0 = 0; f0 < kEF; f0 += 2) {
+                float v[16];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int f = f0 + u;
-                const float g = (valid && e0[k * kEF + f] > 0.f) ? ge0[k * kEF + f] : 0.f;
-                v[8 * u] = g;
+                for (int u = 0; u < 2; ++u) {
+                    const int f = f0 + u;
+                    const float g = (valid && e0[k * kEF + f] > 0.f) ? ge0[k * kEF + f] : 0.f;
+                    v[8 * u] = g;
 #pragma unroll
-                for (int a = 0; a < 7; ++a) v[8 * u + 1 + a] = g * at[a];
+                    for (int a = 0; a < 7; ++a) v[8 * u + 1 + a] = g * at[a];
+                }
+                wave_lds_add16(v, s_acc, [&](int idx) { return (idx & 7) > A ? -1 : (f0 + (idx >> 3)) * 8 + (idx & 7); });
             }
-            wave_atomic_add16(v, [&](int idx) -> float* {
-                const int f = f0 + (idx >> 3), r = idx & 7;
-                if (r > A) return nullptr;
-                return r == 0 ? gb + f : gW + f * A + r - 1;
-            });
+        } else {
+            for (int f = 0; f < kEF; ++f) {
+                const float g = (valid && e0[k * kEF + f] > 0.f) ? ge0[k * kEF + f] : 0.f;
+                wave_atomic_add(gb + f, g);
+                for (int a = 0; a < A; ++a) wave_atomic_add(gW + f * A + a, g * attr[k * A + a]);
+            }
         }
-        return;
     }
-    for (int f = 0; f < kEF; ++f) {
-        const float g = (valid && e0[k * kEF + f] > 0.f) ? ge0[k * kEF + f] : 0.f;
-        wave_atomic_add(gb + f, g);
-        for (int a = 0; a < A; ++a) wave_atomic_add(gW + f * A + a, g * attr[k * A + a]);
+    __syncthreads();
+    for (int t = threadIdx.x; t < kEF * 8; t += 256) {
+        const float v = s_acc[t];
+        const int f = t >> 3, r = t & 7;
+        if (v != 0.f) atomicAdd(r == 0 ? gb + f : gW + f * A + r - 1, v);
     }
 }
 

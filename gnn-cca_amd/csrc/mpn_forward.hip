@@ -466,7 +466,8 @@ size_t gnncca_backward_workspace_bytes(const gnncca_mpn_dims* d, int64_t n_nodes
     if (!dims_valid(d) || !backward_ok(d) || n_nodes < 0 || n_edges < 0) return 0;
     const size_t N = (size_t)n_nodes, E = (size_t)n_edges, F1 = (size_t)d->enc_node.layers[0].out_dim;
     auto up = [](size_t v) { return (v + 255) / 256 * 256; };
-    return up(N * 4) + up(N * kH * 4) + up(N * 44 * 4) + 2 * up(N * kH * 4) + 2 * up(E * kEF * 4) + 2 * up(N * F1 * 4) +
+    const size_t L = (size_t)std::max(d->num_enc_steps, 1);
+    return up(N * 4) + up(N * kH * 4) + up(L * N * 44 * 4) + 2 * up(N * kH * 4) + 2 * up(E * kEF * 4) + 2 * up(N * F1 * 4) +
            up(32 * N * F1 * 4) + up(sizeof(double) * 128) + up(sizeof(float) * 128);
 }
 
@@ -504,6 +505,15 @@ int gnncca_mpn_backward(const gnncca_mpn_dims* d, const float* const* params_dev
                         const int64_t* edge_index, const float* edge_attr, int64_t n_nodes, int64_t n_edges,
                         const gnncca_trace* saved, const float* cls_bn_stat, const float* grad_logits,
                         float* const* grads_dev, void* workspace, size_t workspace_bytes, gnncca_stream_t stream) {
+    return gnncca_mpn_backward_ex(d, params_dev, n_params, x, edge_index, edge_attr, n_nodes, n_edges, saved, cls_bn_stat,
+                                  grad_logits, grads_dev, workspace, workspace_bytes, 0u, stream);
+}
+
+int gnncca_mpn_backward_ex(const gnncca_mpn_dims* d, const float* const* params_dev, int n_params, const float* x,
+                           const int64_t* edge_index, const float* edge_attr, int64_t n_nodes, int64_t n_edges,
+                           const gnncca_trace* saved, const float* cls_bn_stat, const float* grad_logits,
+                           float* const* grads_dev, void* workspace, size_t workspace_bytes, uint32_t options,
+                           gnncca_stream_t stream) {
     if (!dims_valid(d) || n_nodes < 0 || n_edges < 0) return GNNCCA_ERR_INVALID_ARG;
     if (!backward_ok(d)) return GNNCCA_ERR_UNSUPPORTED;
     if (n_params != gnncca_param_count(d) || !params_dev || !grads_dev) return GNNCCA_ERR_INVALID_ARG;
@@ -516,7 +526,7 @@ int gnncca_mpn_backward(const gnncca_mpn_dims* d, const float* const* params_dev
     const int L = d->num_enc_steps, first_cls = L - d->num_class_steps + 1;
     const int c1 = d->cls_edge.n_layers == 2 ? d->cls_edge.layers[0].out_dim : 0;
     // zero every gradient
-    {
+    if (!(options & GNNCCA_BWD_GRADS_ZEROED)) {
         const gnncca_mlp* all[5] = {&d->enc_node, &d->enc_edge, &d->edge_mlp, &d->node_mlp, &d->cls_edge};
         int pi = 0;
         for (const gnncca_mlp* m : all)
@@ -538,7 +548,7 @@ int gnncca_mpn_backward(const gnncca_mpn_dims* d, const float* const* params_dev
     auto take = [&](size_t bytes) { char* q = base + off; off += up(bytes); return q; };
     int* deg = reinterpret_cast<int*>(take((size_t)N * 4));
     float* Q = reinterpret_cast<float*>(take((size_t)N * kH * 4));
-    float* dP = reinterpret_cast<float*>(take((size_t)N * 44 * 4));
+    float* dP_all = reinterpret_cast<float*>(take((size_t)std::max(L, 1) * N * 44 * 4));  // one table per step, cleared once
     float* Hb[2] = {reinterpret_cast<float*>(take((size_t)N * kH * 4)), reinterpret_cast<float*>(take((size_t)N * kH * 4))};
     float* Gb[2] = {reinterpret_cast<float*>(take((size_t)E * kEF * 4)), reinterpret_cast<float*>(take((size_t)E * kEF * 4))};
     float* a1 = reinterpret_cast<float*>(take((size_t)N * F1 * 4));
@@ -562,6 +572,7 @@ int gnncca_mpn_backward(const gnncca_mpn_dims* d, const float* const* params_dev
         hipLaunchKernelGGL(bwd_degree_kernel, grid1((size_t)E, 256), dim3(256), 0, st, ei, (long long)E, N, deg);
         HIP_TRY(hipGetLastError());
     }
+    HIP_TRY(hipMemsetAsync(dP_all, 0, (size_t)std::max(L, 1) * N * 44 * 4, st));
     const float* g_h = nullptr;   // d loss / d h_s of the step being processed (null for s = L: its node update is dead)
     const float* ge_in = nullptr; // d loss / d e_s arriving from step s+1
     int out_idx = gnncca_num_outputs(d) - 1;
@@ -573,7 +584,7 @@ int gnncca_mpn_backward(const gnncca_mpn_dims* d, const float* const* params_dev
             hipLaunchKernelGGL(bwd_q_kernel, grid1((size_t)N * kH, 256), dim3(256), 0, st, h_prev, Wn, bn, Q, N);
             HIP_TRY(hipGetLastError());
         }
-        HIP_TRY(hipMemsetAsync(dP, 0, (size_t)N * 44 * 4, st));
+        float* dP = dP_all + (size_t)(s - 1) * N * 44;
         BwdEdgeParams bp;
         std::memset(&bp, 0, sizeof(bp));
         bp.ei = ei;
@@ -616,20 +627,29 @@ int gnncca_mpn_backward(const gnncca_mpn_dims* d, const float* const* params_dev
         bp.E = E;
         bp.N = N;
         bp.cls_hidden = c1;
-        hipLaunchKernelGGL(bwd_edge_kernel, grid1((size_t)E, 256), dim3(256), 0, st, bp);
+        {   // persistent grid: enough workgroups to fill the chip, few enough that the final flush of the LDS-resident
+            // parameter-gradient sums stays a few thousand atomics
+            const unsigned chunks = (unsigned)(((size_t)E + 255) / 256);
+            hipLaunchKernelGGL(bwd_edge_kernel, dim3(std::min(chunks, 512u)), dim3(256), 0, st, bp);
+        }
         HIP_TRY(hipGetLastError());
         float* g_h_prev = Hb[s & 1];
         hipLaunchKernelGGL(bwd_node_kernel, grid1((size_t)N * kH, 256), dim3(256), 0, st, (const float*)dP, We, Wn, g_h_prev, N);
         HIP_TRY(hipGetLastError());
         // d W_src, d W_dst (columns 0..31, 32..63 of the edge-MLP weight), d W_nx (columns 0..31 of the node-MLP weight)
-        HIP_TRY(launch_outer(dP, 44, h_prev, kH, gWe, 70, nullptr, N, 6, kH, st));
-        HIP_TRY(launch_outer(dP + 6, 44, h_prev, kH, gWe + kH, 70, nullptr, N, 6, kH, st));
-        if (g_h) HIP_TRY(launch_outer(dP + 12, 44, h_prev, kH, gWn, kH + kEF, nullptr, N, kH, kH, st));
+        {   // one product dP^T h_prev [44][32], rows routed to the three weight blocks
+            OuterOut oo;
+            oo.ptr[0] = gWe, oo.ptr[1] = gWe + kH, oo.ptr[2] = g_h ? gWn : nullptr;
+            oo.ld[0] = oo.ld[1] = 70, oo.ld[2] = kH + kEF;
+            oo.row_begin[0] = 0, oo.row_begin[1] = 6, oo.row_begin[2] = 12, oo.row_begin[3] = 44;
+            HIP_TRY(launch_outer_multi(dP, 44, h_prev, kH, oo, nullptr, N, g_h ? 44 : 12, kH, st));
+        }
         g_h = g_h_prev;
         ge_in = Gb[s & 1];
     }
     // ---- encoders ---------------------------------------------------------------------------------------------------
-    hipLaunchKernelGGL(bwd_edge_enc_kernel, grid1((size_t)E, 256), dim3(256), 0, st, ge_in, saved->e_enc, edge_attr, A, (long long)E,
+    hipLaunchKernelGGL(bwd_edge_enc_kernel, dim3(std::min((unsigned)(((size_t)E + 255) / 256), 512u)), dim3(256), 0, st, ge_in,
+                       saved->e_enc, edge_attr, A, (long long)E,
                        gWe0, gbe0);
     HIP_TRY(hipGetLastError());
     {   // a1 = ReLU(x W1^T + b1) is recomputed instead of stored: the forward's split-K MFMA GEMM + its reduce kernel

@@ -103,15 +103,22 @@ class _MPNTrainFunction(torch.autograd.Function):
         dev = x.device
         n, e = x.shape[0], edge_index.shape[1]
         g = grad_out.reshape(grad_out.shape[0], -1).float().contiguous()
-        grads = [torch.empty_like(p, dtype=torch.float32) for p in params]
+        # every gradient is a view of ONE flat buffer cleared by a single fill (GNNCCA_BWD_GRADS_ZEROED)
+        offs, total = [], 0
+        for p in params:
+            offs.append(total)
+            total += (p.numel() + 3) // 4 * 4
+        flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        grads = [flat[o:o + p.numel()].view(p.shape) for o, p in zip(offs, params)]
         pp = (C.c_void_p * len(params))(*[p.data_ptr() for p in params])
         gp = (C.c_void_p * len(params))(*[t.data_ptr() for t in grads])
         ws = torch.empty(lib.gnncca_backward_workspace_bytes(C.byref(d), n, e) + 256, dtype=torch.uint8, device=dev)
         saved = nat.Trace(h_enc.data_ptr(), e_enc.data_ptr(), h_steps.data_ptr(), e_steps.data_ptr())
         with torch.cuda.device(dev):
-            st = lib.gnncca_mpn_backward(C.byref(d), pp, len(params), x.data_ptr(), edge_index.data_ptr(), edge_attr.data_ptr(),
-                                         n, e, C.byref(saved), bn_stat.data_ptr() if ctx.has_bn else None, g.data_ptr(), gp,
-                                         ws.data_ptr(), ws.numel(), torch.cuda.current_stream(dev).cuda_stream)
+            st = lib.gnncca_mpn_backward_ex(C.byref(d), pp, len(params), x.data_ptr(), edge_index.data_ptr(),
+                                            edge_attr.data_ptr(), n, e, C.byref(saved),
+                                            bn_stat.data_ptr() if ctx.has_bn else None, g.data_ptr(), gp, ws.data_ptr(),
+                                            ws.numel(), nat.BWD_GRADS_ZEROED, torch.cuda.current_stream(dev).cuda_stream)
         nat.check(st, "gnncca_mpn_backward")
         return (None, None, None, None, *[gr if p.requires_grad else None for gr, p in zip(grads, params)])
 
@@ -157,6 +164,7 @@ class MOTMPNet(nn.Module):
         self._workspace = None     # grow-only device scratch
         self._weights_dirty = True
         self._param_cache = None
+        self._trainable_checked = False
         self._pack_state = None    # (device copy of the pack program, persistent blob) for the on-GPU repack
         self.last_workspace_bytes = 0
         # 'fp32' (default: bit-faithful to the reference within summation order) or 'bf16': the edge latents are kept
@@ -236,6 +244,7 @@ class MOTMPNet(nn.Module):
 
     def train(self, mode=True):
         self._weights_dirty = True  # parameters may have been updated in place while training
+        self._trainable_checked = False
         return super().train(mode)
 
     def pack_weights_host(self):
@@ -339,6 +348,8 @@ class MOTMPNet(nn.Module):
         return None
 
     def _check_trainable(self):
+        if self._trainable_checked:  # reset by .train() / _apply(); Dropout.p edited by hand afterwards is not re-read
+            return
         lib, d = nat.lib(), self.native_dims()
         if lib.gnncca_backward_supported(C.byref(d)) != nat.OK:
             raise NotImplementedError(
@@ -348,6 +359,7 @@ class MOTMPNet(nn.Module):
         for mod in self.modules():
             if isinstance(mod, nn.Dropout) and mod.p > 0:
                 raise NotImplementedError("Dropout with p > 0 in train mode is not implemented on the HIP path")
+        self._trainable_checked = True
 
     def _forward_train(self, data):
         self._check_trainable()
