@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""profiles/r01_*_pmc_summary.json -> profiles/pmc_index.json, the table bench.py reads `roofline.traffic` and
+`rocprof_avg_launch_us` from (keyed "<graphs>x<nodes>_L<L>[_bf16]").  The dominant kernel is the middle message-passing
+step, mpn_step_fast_kernel<FIRST=false, CLS=true, MSG=true, ...>."""
+import glob
+import json
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+index = {}
+for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r01_*_pmc_summary.json"))):
+    s = json.load(open(path))
+    cmd = s["command"]
+    def arg(name, default):
+        m = re.search(rf"--{name} (\S+)", cmd)
+        return m.group(1) if m else default
+    key = f"{arg('graphs', '1')}x{arg('nodes', '256')}_L{arg('L', '4')}" + ("_bf16" if arg("edge-state", "f32") == "bf16" else "")
+    best = None
+    for name, e in s["kernels"].items():
+        if re.search(r"mpn_step_fast_kernel<false, true, true", name) and "hbm_bytes_per_launch" in e:
+            if best is None or e["calls"] > best[1]["calls"]:
+                best = (name, e)
+    if best:
+        index[key] = {"kernel": best[0], "hbm_bytes_per_launch": best[1]["hbm_bytes_per_launch"],
+                      "rocprof_avg_us": best[1]["avg_ns"] / 1e3, "source": os.path.relpath(path, ROOT)}
+json.dump(index, open(os.path.join(ROOT, "profiles", "pmc_index.json"), "w"), indent=1)
+print(json.dumps(index, indent=1))
