@@ -106,6 +106,31 @@ def step_algorithmic_bytes(E, L, n_cls, msg_only=True, e_bytes=24):
     return per_launch
 
 
+def scale_probe(params, device, args, graphs=64):
+    """The SAME step kernel on a batch of `graphs` graphs of the headline size, where the edge state (200 MB) no longer
+    fits any cache: the HBM-relevant operating point of the dominant kernel, measured live (HIP events around each
+    launch, `forward_profiled`), reported next to the latency-bound single-graph figure.  Not part of `value`."""
+    import copy
+    model = build_model(copy.deepcopy(params), args.nodes).to(device)
+    model.edge_state_dtype = "bf16" if args.edge_state == "bf16" else "fp32"
+    data = make_data(args.nodes, graphs, 1, device)
+    E = data.edge_index.shape[1]
+    ms = []
+    with torch.no_grad():
+        for _ in range(3):
+            model(data)
+        for _ in range(8):
+            _, times = model.forward_profiled(data)
+            ms += [t for kind, t in times if kind == "step"]
+    per_launch = step_algorithmic_bytes(E, args.L, 3, e_bytes=12 if args.edge_state == "bf16" else 24)
+    alg = float(np.mean(per_launch))
+    step_ms = float(np.mean(ms))
+    achieved = alg / (step_ms * 1e-3) / 1e9
+    return {"workload": f"{graphs} x dense{args.nodes} graphs in one forward (E={E})", "bound": "hbm", "achieved": achieved,
+            "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "avg_launch_us": step_ms * 1e3,
+            "algorithmic_bytes_per_launch": alg, "kernel": "mpn_step_fast_kernel (same kernel as `roofline`)"}
+
+
 def cpu_baseline(params, model, n_nodes, n_graphs, budget_s=20.0):
     """The reference-shaped CPU path (oracle.TorchOracle: index/cat/addmm/relu/index_add_, the torch CPU kernels the
     reference itself runs) on a bounded sample of the same workload."""
@@ -155,6 +180,7 @@ def main():
                          "auto: time 50 steps of each after warm-up and keep the faster (reported in config.mode)")
     ap.add_argument("--edge-state", choices=["fp32", "bf16"], default="fp32",
                     help="storage of the edge latents between steps (bf16: GNNCCA_OPT_EDGE_STATE_BF16; arithmetic stays fp32)")
+    ap.add_argument("--no-scale-probe", action="store_true", help="skip the 64-graph batch probe of the step kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--single-device", action="store_true",
@@ -310,6 +336,8 @@ def main():
                          if E * 48 < 200e6 else ""},
             "kernels_us": {k: float(np.mean(v)) * 1e3 for k, v in kernel_ms.items()},
         }
+        if world == 1 and args.graphs == 1 and not args.no_scale_probe:
+            res["roofline_at_scale"] = scale_probe(params, device, args)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(params, model, args.nodes, args.graphs)
             res["config"]["gpu_over_cpu"] = res["value"] / res["cpu_baseline"]["value"]
