@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void enc_gemm_split_direct_kernel(const float*
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int row0 = blockIdx.x * 128 + wave * 32;
     const int kbeg = blockIdx.y * kslice;
-    const size_t plane = (size_t)O * K;
+    const size_t plane = (size_t)O * BK;  // w3 is [K/32][3 pieces][O][32]: a chunk's 24 KB are contiguous
     const int h = lane >> 5;
     const float* __restrict__ xrow = x + (size_t)min(row0 + (lane & 31), M - 1) * K + kbeg + 8 * h;
     int wp[6], wcol[6], wk[6];
@@ -130,7 +130,15 @@ __global__ __launch_bounds__(256) void enc_gemm_split_direct_kernel(const float*
     f32x4 xreg[4];   // chunk's x: k-step 0 -> [0],[1]; k-step 1 -> [2],[3]   (8 consecutive k each)
     bf16x8 wreg[6];
     bf16x8 afrag[2][3];
+    // Every workgroup walks its k-slice from a different starting chunk (wrapping around): rows of x are 8 KB apart
+    // and rows of the W planes 4 KB apart, so the 32 rows one load instruction touches -- and the same chunk of
+    // every other workgroup -- fall into the same L2 channel; staggering the chunk order spreads the workgroups
+    // that are in flight together over all channels.
+    const int nk = min(kslice, K - kbeg) / BK;
+    const int kt0 = (int)((blockIdx.x * 7u + blockIdx.y * 3u) % (unsigned)nk);
     auto load_next = [&](int kt) {
+        kt += kt0;
+        if (kt >= nk) kt -= nk;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             xreg[2 * ks] = *reinterpret_cast<const f32x4*>(xrow + kt * BK + ks * 16);
@@ -138,7 +146,7 @@ __global__ __launch_bounds__(256) void enc_gemm_split_direct_kernel(const float*
         }
 #pragma unroll
         for (int u = 0; u < 6; ++u)
-            wreg[u] = *reinterpret_cast<const bf16x8*>(w3 + wp[u] * plane + (size_t)wcol[u] * K + kbeg + kt * BK + wk[u]);
+            wreg[u] = *reinterpret_cast<const bf16x8*>(w3 + ((size_t)(kbeg / BK + kt) * 3 + wp[u]) * plane + wcol[u] * BK + wk[u]);
     };
     auto convert_x = [&]() {
 #pragma unroll
@@ -164,7 +172,6 @@ __global__ __launch_bounds__(256) void enc_gemm_split_direct_kernel(const float*
     for (int c = 0; c < 4; ++c)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[c][i] = 0.f;
-    const int nk = min(kslice, K - kbeg) / BK;
     load_next(0);
     store_w(0);
     convert_x();

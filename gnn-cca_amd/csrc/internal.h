@@ -42,7 +42,7 @@ struct BlobHeader {
     int32_t cls_layers, cls_hidden;         // 1: Linear(6,1);  2: Linear(6,C1)+ReLU, Linear(C1,1)
     int32_t cls_w1, cls_b1, cls_w2, cls_b2;
     int32_t fast_consts;                    // [kFastConsts] contiguous copy of the per-step scalars (see below), or 0
-    int32_t enc_w3;                         // first encoder weight split into 3 bf16 planes [3][out][in], or 0
+    int32_t enc_w3;                         // first encoder weight as 3 bf16 pieces, [in/32][3][out][32], or 0
     int32_t pad[6];
 };
 
@@ -73,7 +73,7 @@ struct PackSeg {
     int32_t rows, cols;         // rows = output units (the BatchNorm channel of element (r, c) is unit0 + r)
     int32_t unit0;
     int32_t drs, dcs, srs, scs; // destination / source strides per row and per column
-    int32_t plane;              // kind 2: elements per bf16 plane
+    int32_t plane;              // kind 2: out * 32, the piece stride inside a 32-deep k-chunk of [in/32][3][out][32]
     int32_t pad[3];
 };
 constexpr int kMaxPackSegs = 96;

@@ -266,8 +266,8 @@ bool pack_program(const gnncca_mpn_dims* d, PackProgram* out) {
         if (i == 0 && p.h.enc_w3) {
             if (n >= kMaxPackSegs) return false;
             PackSeg& g = out->segs[n++];
-            g.kind = 2, g.dst = p.h.enc_w3, g.param = L.w, g.bn = L.bn, g.rows = L.out, g.cols = L.in, g.drs = L.in, g.dcs = 1;
-            g.srs = L.in, g.scs = 1, g.plane = L.in * L.out;
+            g.kind = 2, g.dst = p.h.enc_w3, g.param = L.w, g.bn = L.bn, g.rows = L.out, g.cols = L.in, g.drs = 0, g.dcs = 0;
+            g.srs = L.in, g.scs = 1, g.plane = L.out * 32;  // [in/32][3 pieces][out][32]: see gnncca_pack_weights
         }
         if (i == d->enc_node.n_layers - 1) weight(L, p.h.enc_last_wT, 0, kH, L.in, 0, 1, kH, L.in, 1);
     }
@@ -386,18 +386,22 @@ int gnncca_pack_weights(const gnncca_mpn_dims* d, const float* const* params, in
         if (i == 0 && p.h.enc_w3) {
             // w = w0 + w1 + w2 with bf16 pieces (24 mantissa bits in all): the split-bf16 GEMM multiplies the
             // pieces on the bf16 MFMA pipe and recovers fp32-level accuracy
+            // Layout [in/32][3 pieces][out][32]: the 32-deep k-chunk a GEMM workgroup stages per iteration (all three
+            // pieces of all output columns, 24 KB for out = 128) is one contiguous run -- full-line coalesced loads.
             uint16_t* w3 = reinterpret_cast<uint16_t*>(blob + p.h.enc_w3);
-            const size_t n = f.w.size();
-            for (size_t k = 0; k < n; ++k) {
-                const float v = f.w[k];
-                const uint16_t h0 = bf16_rne(v);
-                const float r1 = v - bf16_to_float(h0);
-                const uint16_t h1 = bf16_rne(r1);
-                const float r2 = r1 - bf16_to_float(h1);
-                w3[k] = h0;
-                w3[n + k] = h1;
-                w3[2 * n + k] = bf16_rne(r2);
-            }
+            const size_t plane = (size_t)f.out * 32;
+            for (int o = 0; o < f.out; ++o)
+                for (int i = 0; i < f.in; ++i) {
+                    const float v = f.w[(size_t)o * f.in + i];
+                    const uint16_t h0 = bf16_rne(v);
+                    const float r1 = v - bf16_to_float(h0);
+                    const uint16_t h1 = bf16_rne(r1);
+                    const float r2 = r1 - bf16_to_float(h1);
+                    const size_t k = (size_t)(i / 32) * 3 * plane + (size_t)o * 32 + (size_t)(i % 32);
+                    w3[k] = h0;
+                    w3[plane + k] = h1;
+                    w3[2 * plane + k] = bf16_rne(r2);
+                }
         }
         if (i == d->enc_node.n_layers - 1)
             for (int o = 0; o < kH; ++o)

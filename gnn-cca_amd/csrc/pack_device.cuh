@@ -42,7 +42,8 @@ __global__ __launch_bounds__(256) void pack_device_kernel(const PackProgram* __r
             else
                 v = (float)__dmul_rn((double)v, s);
         }
-        const size_t k = (size_t)r * g.drs + (size_t)c * g.dcs;
+        size_t k = (size_t)r * g.drs + (size_t)c * g.dcs;
+        if (g.kind == 2) k = (size_t)(c / 32) * 3 * (size_t)g.plane + (size_t)r * 32 + (size_t)(c % 32);  // [in/32][3][out][32]
         if (g.kind == 2) {
             unsigned short* w3 = reinterpret_cast<unsigned short*>(blob + g.dst);
             const unsigned short h0 = pack_bf16_rne(v);

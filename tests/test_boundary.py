@@ -242,6 +242,7 @@ def run_pack_program(prog, params, nbytes):
                 v = (v.astype(np.float64) * s).astype(np.float32)
         k = r * g.drs + c * g.dcs
         if g.kind == 2:
+            k = (c // 32) * 3 * g.plane + r * 32 + (c % 32)   # [in/32][3 pieces][out][32]
             h0 = _bf16_rne(v)
             r1 = v - (h0.astype(np.uint32) << 16).view(np.float32)
             h1 = _bf16_rne(r1)
