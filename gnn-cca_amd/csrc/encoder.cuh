@@ -215,6 +215,147 @@ __global__ __launch_bounds__(256) void enc_gemm_split_direct_kernel(const float*
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Structure ("both operands through LDS", N >= 16 K rows): rocprofv3 counters on the direct-A kernel above showed the
+// L1 (TCP) as its limit -- 93 % active, TA 68 % busy and 35 % stalled by it: a fragment-shaped x load (lane = row)
+// touches 64 cache lines for 1 KB, eight times the line accesses of a full-line load.  Here x is read in full 128-B
+// lines (a wave instruction = 8 rows x 128 B), converted ONCE to its three bf16 pieces by the loading thread and
+// written to LDS in the fragment image; W arrives the same way from its chunk-contiguous blob layout.
+//   workgroup = 8 waves = 256 rows x 128 columns, wave = 64 x 64 (2 x 2 MFMA tiles: A and B fragments each reused
+//   twice), BK = 32, two LDS stages of (A 48 KB + B 24 KB), one barrier per chunk.
+//   LDS image: [stage][piece][row][32 k] bf16, 64-B rows, the 16-B granule kc of row r stored at kc ^ ((r >> 2) & 3):
+//   ds_read_b128 of 16 consecutive rows at one kc hits 64 distinct banks (no padding: 144 KB must fit 160 KB).
+// Measured (N = 65 536): TCP line accesses 52.9 M -> 18.4 M, TA busy 82 M -> 32 M cycles, LDS bank conflicts 0, MFMA
+// pipe 39 % -> 51 % busy, 188 -> 176 us.  Requesting the operands two chunks ahead (two register sets, 215 VGPRs)
+// did not help either kernel (176 -> 184 us here): what remains is not load latency.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int kLdsGemmRows = 256;
+constexpr size_t kLdsGemmBytes = (size_t)2 * 3 * (kLdsGemmRows + 128) * 32 * 2;  // 147 456
+__global__ __launch_bounds__(512) void enc_gemm_split_lds_kernel(const float* __restrict__ x, const unsigned short* __restrict__ w3,
+                                                                 float* __restrict__ out, int M, int K, int O, int kslice) {
+    constexpr int BK = 32, RA = kLdsGemmRows, RB = 128;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    __bf16* sa = reinterpret_cast<__bf16*>(lds_raw);                 // [2][3][RA][32]
+    __bf16* sb = sa + (size_t)2 * 3 * RA * BK;                       // [2][3][RB][32]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1, h = lane >> 5, l32 = lane & 31;
+    const int row0 = blockIdx.x * RA;
+    const int kbeg = blockIdx.y * kslice;
+    const int nk = min(kslice, K - kbeg) / BK;
+    const int kt0 = (int)((blockIdx.x * 7u + blockIdx.y * 3u) % (unsigned)nk);  // staggered chunk order (see above)
+    // loader roles: x chunk = 256 rows x 8 float4 -> 4 per thread; W chunk = 1536 16-B granules -> 3 per thread
+    const float* xsrc[4];
+    int xdst[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int q = tid + 512 * u, row = q >> 3, c4 = q & 7;
+        xsrc[u] = x + (size_t)min(row0 + row, M - 1) * K + kbeg + c4 * 4;
+        xdst[u] = row * BK + (((c4 >> 1) ^ ((row >> 2) & 3)) << 3) + ((c4 & 1) << 2);
+    }
+    int wdst[3];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        const int g = tid + 512 * u, p = g >> 9, col = (g & 511) >> 2, kc = g & 3;
+        wdst[u] = (p * RB + col) * BK + ((kc ^ ((col >> 2) & 3)) << 3);
+    }
+    const size_t wchunk = (size_t)3 * O * BK;  // bf16 elements per k-chunk of w3
+    f32x4 xreg[4];
+    bf16x8 wreg[3];
+    auto load_next = [&](int kt) {
+        kt += kt0;
+        if (kt >= nk) kt -= nk;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) xreg[u] = *reinterpret_cast<const f32x4*>(xsrc[u] + kt * BK);
+#pragma unroll
+        for (int u = 0; u < 3; ++u)
+            wreg[u] = *reinterpret_cast<const bf16x8*>(w3 + (size_t)(kbeg / BK + kt) * wchunk + (size_t)(tid + 512 * u) * 8);
+    };
+    auto store_stage = [&](int stage) {
+        __bf16* a = sa + (size_t)stage * 3 * RA * BK;
+        __bf16* b = sb + (size_t)stage * 3 * RB * BK;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            bf16x4 p0, p1, p2;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float v = xreg[u][q];
+                const __bf16 h0 = (__bf16)v;
+                const float r1 = v - (float)h0;
+                const __bf16 h1 = (__bf16)r1;
+                const float r2 = r1 - (float)h1;
+                p0[q] = h0, p1[q] = h1, p2[q] = (__bf16)r2;
+            }
+            *reinterpret_cast<bf16x4*>(a + xdst[u]) = p0;
+            *reinterpret_cast<bf16x4*>(a + RA * BK + xdst[u]) = p1;
+            *reinterpret_cast<bf16x4*>(a + 2 * RA * BK + xdst[u]) = p2;
+        }
+#pragma unroll
+        for (int u = 0; u < 3; ++u) *reinterpret_cast<bf16x8*>(b + wdst[u]) = wreg[u];
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[rt][ct][i] = 0.f;
+    // fragment addresses (elements), per row tile / column tile; the k granule is kc = 2 ks + h
+    int arow[2], brow[2], aswz[2], bswz[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int ra = wr * 64 + t * 32 + l32, cb = wc * 64 + t * 32 + l32;
+        arow[t] = ra * BK, aswz[t] = (ra >> 2) & 3;
+        brow[t] = cb * BK, bswz[t] = (cb >> 2) & 3;
+    }
+    load_next(0);
+    store_stage(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int stage = kt & 1;
+        if (kt + 1 < nk) load_next(kt + 1);
+        const __bf16* a = sa + (size_t)stage * 3 * RA * BK;
+        const __bf16* b = sb + (size_t)stage * 3 * RB * BK;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int kc = 2 * ks + h;
+            bf16x8 af[2][3], bf[2][3];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    af[t][p] = *reinterpret_cast<const bf16x8*>(a + p * RA * BK + arow[t] + ((kc ^ aswz[t]) << 3));
+                    bf[t][p] = *reinterpret_cast<const bf16x8*>(b + p * RB * BK + brow[t] + ((kc ^ bswz[t]) << 3));
+                }
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) {
+                    // smallest terms first
+                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[rt][2], bf[ct][0], acc[rt][ct], 0, 0, 0);
+                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[rt][1], bf[ct][1], acc[rt][ct], 0, 0, 0);
+                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[rt][0], bf[ct][2], acc[rt][ct], 0, 0, 0);
+                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[rt][1], bf[ct][0], acc[rt][ct], 0, 0, 0);
+                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[rt][0], bf[ct][1], acc[rt][ct], 0, 0, 0);
+                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[rt][0], bf[ct][0], acc[rt][ct], 0, 0, 0);
+                }
+        }
+        if (kt + 1 < nk) store_stage(stage ^ 1);
+        __syncthreads();
+    }
+    float* __restrict__ dst = out + (size_t)blockIdx.y * M * O;
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            const int col = wc * 64 + ct * 32 + l32;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = row0 + wr * 64 + rt * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                if (row < M) dst[(size_t)row * O + col] = acc[rt][ct][i];
+            }
+        }
+}
+
 // act[M][O] = [ReLU](bias + sum_ks part[ks][M][O]) -- only for encoders deeper than two layers.
 __global__ __launch_bounds__(256) void reduce_bias_act_kernel(const float* __restrict__ part, const float* __restrict__ bias,
                                                               float* __restrict__ act, int M, int O, int ks, int relu) {

@@ -120,10 +120,24 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
         int ks_split = 1;
         if (split) {  // big batches: split-bf16 MFMA GEMM; the plan gets its own launch
             const unsigned short* w3 = reinterpret_cast<const unsigned short*>(blob + hdr.enc_w3);
-            // 128-row workgroups (a wave = 32 rows x 128 columns); split-K until >= 512 workgroups are in flight
-            while (ks_split < ws.ksplit && ((N + 127) / 128) * ks_split < 512 && (K / (ks_split * 2)) % 32 == 0) ks_split *= 2;
-            hipLaunchKernelGGL(enc_gemm_split_direct_kernel, dim3((N + 127) / 128, ks_split), dim3(256), 0, st, cur_in, w3, part, N,
-                               K, O, K / ks_split);
+            if (N >= 16384 && O == 128) {
+                // 256-row workgroups, both operands through LDS (144 KB: one workgroup per CU, 8 waves); split-K until every
+                // CU has one
+                while (ks_split < ws.ksplit && ((N + 255) / 256) * ks_split < 256 && (K / (ks_split * 2)) % 32 == 0) ks_split *= 2;
+                static bool attr_set = false;
+                if (!attr_set) {
+                    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(enc_gemm_split_lds_kernel),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsGemmBytes));
+                    attr_set = true;
+                }
+                hipLaunchKernelGGL(enc_gemm_split_lds_kernel, dim3((N + 255) / 256, ks_split), dim3(512), kLdsGemmBytes, st, cur_in,
+                                   w3, part, N, K, O, K / ks_split);
+            } else {
+                // 128-row workgroups (a wave = 32 rows x 128 columns); split-K until >= 512 workgroups are in flight
+                while (ks_split < ws.ksplit && ((N + 127) / 128) * ks_split < 512 && (K / (ks_split * 2)) % 32 == 0) ks_split *= 2;
+                hipLaunchKernelGGL(enc_gemm_split_direct_kernel, dim3((N + 127) / 128, ks_split), dim3(256), 0, st, cur_in, w3, part,
+                                   N, K, O, K / ks_split);
+            }
             HIP_TRY(hipGetLastError());
             PROF_MARK(GNNCCA_K_ENC_GEMM);
         }

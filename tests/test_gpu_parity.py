@@ -218,6 +218,36 @@ def test_big_batch_split_bf16_encoder_vs_oracle():
         assert np.abs(o.cpu().numpy() - r).max() <= TOL_TIGHT * 2
 
 
+@pytest.mark.parametrize("n_nodes", [16384, 16384 + 77, 40000])
+def test_lds_staged_split_gemm_vs_fp64_oracle(n_nodes):
+    """N >= 16 384 nodes: the first encoder layer runs on the 256-row, both-operands-through-LDS split-bf16 GEMM
+    (ragged N exercises the clamped loads / masked stores, 40 000 the un-split k range).  A sparse ring graph keeps the
+    oracle cheap; the encoder output is judged against an fp64 evaluation, the logits against the fp32 oracle."""
+    params, arch, sd = _default_model(1.0)
+    rng = np.random.default_rng(n_nodes)
+    x = rng.standard_normal((n_nodes, 2048)).astype(np.float32)
+    x /= np.linalg.norm(x, axis=0, keepdims=True)
+    src = np.repeat(np.arange(n_nodes), 2)
+    dst = (src + np.tile([1, 5], n_nodes)) % n_nodes
+    ei = np.stack([src, dst]).astype(np.int64)
+    ea = rng.random((ei.shape[1], 4)).astype(np.float32)
+    orc = NumpyOracle(params, arch, sd, np.float32)
+    tr = {}
+    ref = orc.forward(x, ei, ea, tr)
+    m = build(params, arch, sd)
+    d = Data(torch.from_numpy(x).cuda(), torch.from_numpy(ei).cuda(), torch.from_numpy(ea).cuda())
+    trace = {}
+    with torch.no_grad():
+        out = [t.clone() for t in m(d)["classified_edges"]]
+        m(d, trace=trace)
+    h64 = NumpyOracle(params, arch, sd, np.float64)._mlp("encoder.node_mlp", x.astype(np.float64))
+    err_gpu = np.abs(trace["h_enc"].cpu().numpy() - h64).max()
+    err_ref = np.abs(tr["h_enc"] - h64).max()
+    assert err_gpu <= max(4 * err_ref, 2e-7), (err_gpu, err_ref)
+    for o, r in zip(out, ref):
+        assert np.abs(o.cpu().numpy() - r).max() <= TOL_TIGHT * 2
+
+
 @pytest.mark.parametrize("name", ["dense64", "terrace32", "union3", "ragged_mean", "dense24_shuffled", "steps_L8", "bdnet512"])
 def test_bf16_edge_state_option(name):
     """GNNCCA_OPT_EDGE_STATE_BF16: edge latents stored as bf16 between steps, arithmetic fp32.  The logits must stay
