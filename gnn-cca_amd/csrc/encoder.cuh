@@ -225,9 +225,12 @@ __global__ __launch_bounds__(256) void enc_gemm_split_direct_kernel(const float*
 //   twice), BK = 32, two LDS stages of (A 48 KB + B 24 KB), one barrier per chunk.
 //   LDS image: [stage][piece][row][32 k] bf16, 64-B rows, the 16-B granule kc of row r stored at kc ^ ((r >> 2) & 3):
 //   ds_read_b128 of 16 consecutive rows at one kc hits 64 distinct banks (no padding: 144 KB must fit 160 KB).
-// Measured (N = 65 536): TCP line accesses 52.9 M -> 18.4 M, TA busy 82 M -> 32 M cycles, LDS bank conflicts 0, MFMA
-// pipe 39 % -> 51 % busy, 188 -> 176 us.  Requesting the operands two chunks ahead (two register sets, 215 VGPRs)
-// did not help either kernel (176 -> 184 us here): what remains is not load latency.
+// Measured (N = 65 536, counters): TCP line accesses 52.9 M -> 18.4 M, TA busy 82 M -> 32 M cycles, LDS bank
+// conflicts 0.  Time, A/B in one process on one box (GNNCCA_GEMM_DIRECT=1 selects the kernel above): 195-197 us ->
+// 189-192 us at N = 65 536, 59.9 -> 57.4 us at N = 16 384 -- the L1 pressure was real but is not what bounds the
+// kernel.  Requesting the operands two chunks ahead (two register sets, 215 VGPRs) did not help either kernel (+4 %
+// here): what remains is not load latency either; the waves spend 60 % of their cycles waiting on instruction issue
+// with the MFMA pipe ~50 % busy, i.e. the dependent six-product MFMA chains and the per-chunk barrier.
 // ------------------------------------------------------------------------------------------------------------
 constexpr int kLdsGemmRows = 256;
 constexpr size_t kLdsGemmBytes = (size_t)2 * 3 * (kLdsGemmRows + 128) * 32 * 2;  // 147 456

@@ -120,7 +120,8 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
         int ks_split = 1;
         if (split) {  // big batches: split-bf16 MFMA GEMM; the plan gets its own launch
             const unsigned short* w3 = reinterpret_cast<const unsigned short*>(blob + hdr.enc_w3);
-            if (N >= 16384 && O == 128) {
+            static const bool force_direct = std::getenv("GNNCCA_GEMM_DIRECT") != nullptr;  // diagnostics: A/B the two GEMMs
+            if (N >= 16384 && O == 128 && !force_direct) {
                 // 256-row workgroups, both operands through LDS (144 KB: one workgroup per CU, 8 waves); split-K until every
                 // CU has one
                 while (ks_split < ws.ksplit && ((N + 255) / 256) * ks_split < 256 && (K / (ks_split * 2)) % 32 == 0) ks_split *= 2;
