@@ -125,11 +125,13 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
                 // 256-row workgroups, both operands through LDS (144 KB: one workgroup per CU, 8 waves); split-K until every
                 // CU has one
                 while (ks_split < ws.ksplit && ((N + 255) / 256) * ks_split < 256 && (K / (ks_split * 2)) % 32 == 0) ks_split *= 2;
-                static bool attr_set = false;
-                if (!attr_set) {
+                static thread_local int attr_dev = -1;  // once per device and thread: the attribute is per device
+                int dev = 0;
+                HIP_TRY(hipGetDevice(&dev));
+                if (attr_dev != dev) {
                     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(enc_gemm_split_lds_kernel),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsGemmBytes));
-                    attr_set = true;
+                    attr_dev = dev;
                 }
                 hipLaunchKernelGGL(enc_gemm_split_lds_kernel, dim3((N + 255) / 256, ks_split), dim3(512), kLdsGemmBytes, st, cur_in,
                                    w3, part, N, K, O, K / ks_split);
