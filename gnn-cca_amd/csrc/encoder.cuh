@@ -130,15 +130,8 @@ __global__ __launch_bounds__(256) void enc_gemm_split_direct_kernel(const float*
     f32x4 xreg[4];   // chunk's x: k-step 0 -> [0],[1]; k-step 1 -> [2],[3]   (8 consecutive k each)
     bf16x8 wreg[6];
     bf16x8 afrag[2][3];
-    // Every workgroup walks its k-slice from a different starting chunk (wrapping around): rows of x are 8 KB apart
-    // and rows of the W planes 4 KB apart, so the 32 rows one load instruction touches -- and the same chunk of
-    // every other workgroup -- fall into the same L2 channel; staggering the chunk order spreads the workgroups
-    // that are in flight together over all channels.
     const int nk = min(kslice, K - kbeg) / BK;
-    const int kt0 = (int)((blockIdx.x * 7u + blockIdx.y * 3u) % (unsigned)nk);
     auto load_next = [&](int kt) {
-        kt += kt0;
-        if (kt >= nk) kt -= nk;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             xreg[2 * ks] = *reinterpret_cast<const f32x4*>(xrow + kt * BK + ks * 16);
@@ -245,7 +238,6 @@ __global__ __launch_bounds__(512) void enc_gemm_split_lds_kernel(const float* __
     const int row0 = blockIdx.x * RA;
     const int kbeg = blockIdx.y * kslice;
     const int nk = min(kslice, K - kbeg) / BK;
-    const int kt0 = (int)((blockIdx.x * 7u + blockIdx.y * 3u) % (unsigned)nk);  // staggered chunk order (see above)
     // loader roles: x chunk = 256 rows x 8 float4 -> 4 per thread; W chunk = 1536 16-B granules -> 3 per thread
     const float* xsrc[4];
     int xdst[4];
@@ -265,8 +257,6 @@ __global__ __launch_bounds__(512) void enc_gemm_split_lds_kernel(const float* __
     f32x4 xreg[4];
     bf16x8 wreg[3];
     auto load_next = [&](int kt) {
-        kt += kt0;
-        if (kt >= nk) kt -= nk;
 #pragma unroll
         for (int u = 0; u < 4; ++u) xreg[u] = *reinterpret_cast<const f32x4*>(xsrc[u] + kt * BK);
 #pragma unroll

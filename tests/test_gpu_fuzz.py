@@ -118,3 +118,40 @@ def test_config5_size_vs_oracle():
         out = m(Data(torch.from_numpy(x).cuda(), torch.from_numpy(ei).cuda(), torch.from_numpy(ea).cuda()))
     for o, r in zip(out["classified_edges"], ref):
         assert np.abs(o.cpu().numpy() - r).max() <= 2e-5
+
+
+def test_config4_size_replicated_graph_property():
+    """BASELINE config 4 at full size on one GPU: 512 dense 128-node graphs (N = 65 536, E = 8.3 M) in one forward.  The
+    oracle cannot run this in seconds, so the check is a size-independent property: the batch is 512 COPIES of one graph,
+    hence (a) every copy's logits equal the first copy's bit for bit (no cross-graph leakage, deterministic reductions)
+    and (b) they match the single-graph forward, which itself is pinned to the oracle elsewhere (different encoder GEMM
+    kernel, so within tolerance rather than bitwise)."""
+    from gnn_cca_amd import MOTMPNet
+    params, arch, sd, _ = load_case(os.path.join(GOLDEN_DIR, "dense64.npz"))
+    sd = dict(sd)
+    for k in list(sd):
+        if k.startswith("MPNet.node_model"):
+            sd[k] = (sd[k] * np.float32(63.0 / 127.0)).astype(np.float32)
+    g, n = 512, 128
+    rng = np.random.default_rng(4)
+    x1 = rng.standard_normal((n, 2048)).astype(np.float32)
+    x1 /= np.linalg.norm(x1, axis=0, keepdims=True)
+    i, j = np.meshgrid(np.arange(n), np.arange(n), indexing="ij")
+    keep = i != j
+    ei1 = np.stack([i[keep], j[keep]]).astype(np.int64)
+    ea1 = rng.random((ei1.shape[1], 4)).astype(np.float32)
+    m = MOTMPNet(copy.deepcopy(params), None, arch)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    m = m.cuda().eval()
+    x1d, ei1d, ea1d = torch.from_numpy(x1).cuda(), torch.from_numpy(ei1).cuda(), torch.from_numpy(ea1).cuda()
+    e1 = ei1.shape[1]
+    offs = (torch.arange(g, device="cuda") * n).view(g, 1, 1)
+    ei = (ei1d.unsqueeze(0) + offs).permute(1, 0, 2).reshape(2, -1).contiguous()
+    with torch.no_grad():
+        single = [t.clone() for t in m(Data(x1d, ei1d, ea1d))["classified_edges"]]
+        out = m(Data(x1d.repeat(g, 1), ei, ea1d.repeat(g, 1)))["classified_edges"]
+    assert m.graph_flags() == 0
+    for o, s in zip(out, single):
+        copies = o.view(g, e1)
+        assert torch.equal(copies, copies[0:1].expand(g, e1))
+        assert float((copies[0] - s.view(-1)).abs().max()) <= 2e-5
