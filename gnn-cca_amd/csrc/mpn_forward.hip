@@ -152,7 +152,7 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
             ep.blockflags = blockflags;
             ep.E = E;
             ep.N = N;
-            plan_blocks = (E + 255) / 256;
+            plan_blocks = plan_num_blocks(E);
         }
         if (ep.gemm_blocks + plan_blocks > 0) {
             hipLaunchKernelGGL(enc_gemm_plan_kernel, dim3(ep.gemm_blocks + plan_blocks), dim3(256), 0, st, ep);
@@ -395,7 +395,7 @@ int gnncca_post_prune_cluster(const int64_t* edge_index, const int64_t* predicti
         ep.blockflags = blockflags;
         ep.E = E;
         ep.N = N;
-        hipLaunchKernelGGL(enc_gemm_plan_kernel, dim3((E + 255) / 256), dim3(256), 0, st, ep);
+        hipLaunchKernelGGL(enc_gemm_plan_kernel, dim3(plan_num_blocks(E)), dim3(256), 0, st, ep);
         HIP_TRY(hipGetLastError());
     }
     hipLaunchKernelGGL(gen_plan_finish_kernel, dim3(1), dim3(256), 0, st, ei, E, N, seg_ptr, col32, perm, cursor, flags,

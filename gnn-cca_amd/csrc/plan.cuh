@@ -61,37 +61,52 @@ __device__ void plan_sort_fallback(const long long* __restrict__ ei, int E, int 
     }
 }
 
-// Thread-per-edge part of the plan.  Every workgroup reports its findings in its OWN word (`blockflags[b]`, always
+// Edges one plan workgroup (256 threads) covers: one per thread on small graphs (the plan rides in the latency-bound
+// GEMM launch there), four per thread from 2^20 edges on (four independent 8-byte loads in flight per thread and a
+// quarter of the workgroups: the thread-per-edge form was bound by per-workgroup latency, 2.8 TB/s).
+__host__ __device__ inline int plan_edges_per_block(int E) { return E >= (1 << 20) ? 1024 : 256; }
+__host__ __device__ inline int plan_num_blocks(int E) { return (E + plan_edges_per_block(E) - 1) / plan_edges_per_block(E); }
+
+// Per-edge part of the plan.  Every workgroup reports its findings in its OWN word (`blockflags[b]`, always
 // written, so there is no state to clear between forwards); the tail launch ORs them into flags[0].
 __device__ __forceinline__ void plan_block(int pb, const long long* __restrict__ ei, int E, int N,
                                            int* __restrict__ seg_ptr, int* __restrict__ col32,
                                            unsigned* __restrict__ blockflags, unsigned* s_fl) {
     if (threadIdx.x == 0) *s_fl = 0u;
     __syncthreads();
-    const int k = pb * 256 + threadIdx.x;
-    if (k < E) {
-        const long long r = ei[k], c = ei[(size_t)E + k];
-        if (r < 0 || r >= N || c < 0 || c >= N) {
-            atomicOr(s_fl, GNNCCA_GRAPH_BAD_INDEX);
-        } else {
-            col32[k] = (int)c;
-            long long rp = -1;
-            bool prev_ok = true;
-            if (k > 0) {
-                rp = ei[k - 1];
-                prev_ok = rp >= 0 && rp < N;  // otherwise its owner raises the flag
+    const int per = plan_edges_per_block(E) / 256;
+    const int k0 = pb * 256 * per + threadIdx.x;
+    long long r[4], c[4], rp[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {  // all loads first
+        const int k = k0 + u * 256;
+        const bool on = u < per && k < E;
+        r[u] = on ? ei[k] : 0;
+        c[u] = on ? ei[(size_t)E + k] : 0;
+        rp[u] = (on && k > 0) ? ei[k - 1] : -1;
+    }
+    unsigned fl = 0u;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int k = k0 + u * 256;
+        if (!(u < per && k < E)) continue;
+        if (r[u] < 0 || r[u] >= N || c[u] < 0 || c[u] >= N) {
+            fl |= GNNCCA_GRAPH_BAD_INDEX;
+            continue;
+        }
+        col32[k] = (int)c[u];
+        const bool prev_ok = k == 0 || (rp[u] >= 0 && rp[u] < N);  // otherwise its owner raises the flag
+        if (prev_ok) {
+            if (r[u] < rp[u]) {
+                fl |= GNNCCA_GRAPH_UNSORTED;
+            } else {
+                for (long long n = rp[u] + 1; n <= r[u]; ++n) seg_ptr[n] = k;
             }
-            if (prev_ok) {
-                if (r < rp) {
-                    atomicOr(s_fl, GNNCCA_GRAPH_UNSORTED);
-                } else {
-                    for (long long n = rp + 1; n <= r; ++n) seg_ptr[n] = k;
-                }
-                if (k == E - 1)
-                    for (long long n = r + 1; n <= N; ++n) seg_ptr[n] = E;
-            }
+            if (k == E - 1)
+                for (long long n = r[u] + 1; n <= N; ++n) seg_ptr[n] = E;
         }
     }
+    if (fl) atomicOr(s_fl, fl);
     __syncthreads();
     if (threadIdx.x == 0) blockflags[pb] = *s_fl;
 }
@@ -101,7 +116,7 @@ __device__ void plan_finish(const long long* __restrict__ ei, int E, int N, int*
                             int* cursor, unsigned* flags, const unsigned* __restrict__ blockflags, unsigned* smem) {
     const int tid = threadIdx.x;
     unsigned fl = 0u;
-    const int nb = (E + 255) / 256;
+    const int nb = plan_num_blocks(E);
     for (int i = tid; i < nb; i += 256) fl |= blockflags[i];
     smem[tid] = fl;
     __syncthreads();
