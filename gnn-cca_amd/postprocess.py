@@ -5,8 +5,6 @@
 utils.compute_SCC_and_Clusters (libs/utils.py:295-317) returns for the pruned edge set -- without the networkx /
 Python-list round trips through the host.  The bridge-based rounding and splitting heuristics are not reproduced here.
 """
-import ctypes as C
-
 import torch
 
 from . import _native as nat

@@ -13,7 +13,7 @@ import pytest
 import torch
 
 from conftest import GOLDEN_DIR, ROOT, golden_cases
-from oracle.mpn_oracle import NumpyOracle, load_case
+from oracle.mpn_oracle import load_case
 
 
 def _model(name):

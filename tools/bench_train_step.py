@@ -13,7 +13,6 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
-from gnn_cca_amd import MOTMPNet  # noqa: E402
 from oracle.mpn_oracle import TorchTrainOracle  # noqa: E402
 
 frames = int(sys.argv[1]) if len(sys.argv) > 1 else 64
