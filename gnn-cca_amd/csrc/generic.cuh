@@ -8,8 +8,8 @@ namespace gnncca {
 // multi-layer edge / node MLPs, deeper classifiers ...).  None of the shipped configs needs it; it exists so
 // that the module is a drop-in for the whole constructor contract (models/mpn.py:154-247).  It follows the
 // reference op for op -- virtual concatenation, Linear(+folded BN)(+ReLU) layer by layer, aggregation over the
-// CSR segments in the caller's edge order (the order torch's CPU index_add_ sums in) -- with plain one-thread-
-// per-output kernels: correctness first, no tuning.
+// CSR segments in the caller's edge order (the order torch's CPU index_add_ sums in).  Two kernels do all the work:
+// an LDS-tiled dense layer (eight outputs per thread) and a wave-per-node ordered aggregator.
 // ============================================================================================================
 struct GenSeg {
     const float* ptr;   // [rows][ld]
@@ -18,27 +18,64 @@ struct GenSeg {
 };
 
 // out[r][o] = [ReLU](b[o] + sum over the concatenated segments of W[o][:] . in[r][:])
-__global__ __launch_bounds__(256) void gen_dense_kernel(GenSeg s0, GenSeg s1, GenSeg s2, const float* __restrict__ W,
+// Weights arrive transposed and padded, Wt[k][OP] with OP = ceil8(O) (pack_generic).  A thread owns one row and EIGHT
+// consecutive outputs; a workgroup = 256 / (OP / 8) rows.  The weights of a k-tile are staged in LDS once per
+// workgroup (contiguous copy, k-major) and read back as two 16-B broadcasts per k; the row's inputs come straight
+// from global memory (the OP / 8 threads of a row read the same address; consecutive k hit the same line).
+constexpr int kGenTileFloats = 8192;  // 32 KB of LDS per k-tile
+__global__ __launch_bounds__(256) void gen_dense_kernel(GenSeg s0, GenSeg s1, GenSeg s2, const float* __restrict__ Wt,
                                                         const float* __restrict__ b, float* __restrict__ out, long long M,
-                                                        int K, int O, int ld_out, int relu) {
-    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (t >= M * O) return;
-    const long long r = t / O;
-    const int o = (int)(t - r * O);
-    const float* __restrict__ w = W + (size_t)o * K;
-    float acc = b[o];
+                                                        int K, int O, int ldw, int ld_out, int relu) {
+    __shared__ __attribute__((aligned(16))) float s_w[kGenTileFloats];
+    const int OP = (O + 7) / 8 * 8, OC = OP / 8;
+    const int rows_per_block = 256 / OC;
+    const int tid = threadIdx.x;
+    const int rl = tid / OC, c = tid - rl * OC;
+    const long long r = (long long)blockIdx.x * rows_per_block + rl;
+    const bool live = rl < rows_per_block && r < M;
+    const int kt_max = max(1, kGenTileFloats / OP);
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = live ? b[8 * c + j] : 0.f;  // bias is padded to OP
     const GenSeg segs[3] = {s0, s1, s2};
     int koff = 0;
-#pragma unroll
     for (int q = 0; q < 3; ++q) {
-        const GenSeg& sg = segs[q];
+        const GenSeg sg = segs[q];
         if (sg.width == 0) continue;
-        const long long rr = sg.idx ? (long long)sg.idx[r] : r;
+        const long long rr = live ? (sg.idx ? (long long)sg.idx[r] : r) : 0;
         const float* __restrict__ src = sg.ptr + (size_t)rr * sg.ld;
-        for (int k = 0; k < sg.width; ++k) acc = fmaf(w[koff + k], src[k], acc);
+        for (int k0 = 0; k0 < sg.width; k0 += kt_max) {
+            const int kt = min(kt_max, sg.width - k0);
+            __syncthreads();  // the previous tile is no longer being read
+            // rows of Wt are ldw floats apart (ldw == OP unless this launch covers one column group of a wider layer)
+            const int op4 = OP / 4;
+            for (int i = tid; i < kt * op4; i += 256) {
+                const int kk = i / op4, o4 = i - kk * op4;
+                reinterpret_cast<f32x4*>(s_w)[i] = *reinterpret_cast<const f32x4*>(Wt + (size_t)(koff + k0 + kk) * ldw + 4 * o4);
+            }
+            __syncthreads();
+            if (live) {
+                for (int kk = 0; kk < kt; ++kk) {
+                    const float xv = src[k0 + kk];
+                    const f32x4 w0 = *reinterpret_cast<const f32x4*>(s_w + kk * OP + 8 * c);
+                    const f32x4 w1 = *reinterpret_cast<const f32x4*>(s_w + kk * OP + 8 * c + 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        acc[j] = fmaf(w0[j], xv, acc[j]);
+                        acc[4 + j] = fmaf(w1[j], xv, acc[4 + j]);
+                    }
+                }
+            }
+        }
         koff += sg.width;
     }
-    out[(size_t)r * ld_out + o] = relu ? fmaxf(acc, 0.f) : acc;
+    if (live) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int o = 8 * c + j;
+            if (o < O) out[(size_t)r * ld_out + o] = relu ? fmaxf(acc[j], 0.f) : acc[j];
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void gen_index32_kernel(const long long* __restrict__ ei, int E, int N,
@@ -57,29 +94,40 @@ __global__ __launch_bounds__(256) void gen_plan_finish_kernel(const long long* _
     plan_finish(ei, E, N, seg_ptr, col32, perm, cursor, flags, blockflags, smem);
 }
 
-// h[i][c] = agg over the segment of node i of m[k][c], k in the caller's edge order (models/mpn.py:99,192-202)
+// h[i][c] = agg over the segment of node i of m[k][c], k in the caller's edge order (models/mpn.py:99,192-202).
+// One wave per node, lane = channel (channels beyond 64 in further passes): every edge row is one coalesced read; eight
+// rows are requested before they are added, IN ORDER, so the sum is the sequential one torch's CPU index_add_ forms.
 __global__ __launch_bounds__(256) void gen_aggregate_kernel(const float* __restrict__ m, const int* __restrict__ seg_ptr,
                                                             const int* __restrict__ perm, const unsigned* __restrict__ flags,
                                                             float* __restrict__ h, int N, int H, int agg) {
-    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (t >= (long long)N * H) return;
-    const int i = (int)(t / H), c = (int)(t - (long long)i * H);
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= N) return;
     const unsigned fl = flags[0];
-    if (fl & GNNCCA_GRAPH_BAD_INDEX) {
-        h[t] = __builtin_nanf("");
-        return;
-    }
     const bool unsorted = (fl & GNNCCA_GRAPH_UNSORTED) != 0;
     const int s = seg_ptr[i], e = seg_ptr[i + 1];
-    float v = agg == GNNCCA_AGG_MAX ? -INFINITY : 0.f;
-    for (int p = s; p < e; ++p) {
-        const int k = unsorted ? perm[p] : p;
-        const float x = m[(size_t)k * H + c];
-        v = agg == GNNCCA_AGG_MAX ? fmaxf(v, x) : v + x;
+    for (int c = lane; c < H; c += 64) {
+        if (fl & GNNCCA_GRAPH_BAD_INDEX) {
+            h[(size_t)i * H + c] = __builtin_nanf("");
+            continue;
+        }
+        float v = agg == GNNCCA_AGG_MAX ? -INFINITY : 0.f;
+        for (int p0 = s; p0 < e; p0 += 8) {
+            float x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int p = min(p0 + u, e - 1);
+                const int k = unsorted ? perm[p] : p;
+                x[u] = m[(size_t)k * H + c];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (p0 + u < e) v = agg == GNNCCA_AGG_MAX ? fmaxf(v, x[u]) : v + x[u];
+        }
+        if (agg == GNNCCA_AGG_MEAN) v = v / (float)max(e - s, 1);
+        if (e == s) v = 0.f;
+        h[(size_t)i * H + c] = v;
     }
-    if (agg == GNNCCA_AGG_MEAN) v = v / (float)max(e - s, 1);
-    if (e == s) v = 0.f;
-    h[t] = v;
 }
 
 __global__ __launch_bounds__(256) void gen_poison_kernel(float* __restrict__ out, long long n, const unsigned* __restrict__ flags) {
@@ -100,8 +148,14 @@ static int gen_run_mlp(const gnncca_mlp& mlp, const float* blob, const int32_t* 
         const int ld = last ? ld_final : ld_tmp;
         const long long total = M * L.out_dim;
         if (total > 0) {
-            hipLaunchKernelGGL(gen_dense_kernel, grid1((size_t)total, 256), dim3(256), 0, st, a, b, c, blob + woff[l],
-                               blob + boff[l], dst, M, L.in_dim, L.out_dim, ld, L.relu);
+            const int op_total = (L.out_dim + 7) / 8 * 8;
+            for (int o0 = 0; o0 < L.out_dim; o0 += 2048) {  // column groups of at most 2048 outputs (256 threads x 8)
+                const int og = std::min(2048, L.out_dim - o0);
+                const int rows_per_block = 256 / ((og + 7) / 8);
+                hipLaunchKernelGGL(gen_dense_kernel, dim3((unsigned)((M + rows_per_block - 1) / rows_per_block)), dim3(256), 0, st,
+                                   a, b, c, blob + woff[l] + o0, blob + boff[l] + o0, dst + o0, M, L.in_dim, og, op_total, ld,
+                                   L.relu);
+            }
             HIP_TRY(hipGetLastError());
         }
         a = GenSeg{dst, nullptr, ld, L.out_dim};
@@ -240,7 +294,7 @@ static int forward_generic(const gnncca_mpn_dims* d, const void* packed_dev, con
                             GenSeg{e_new, nullptr, ew, EF}, none, E, msg, H, eb[0], eb[1], ew, st);
             if (s != GNNCCA_OK) return s;
             float* hn = h_lat[step & 1];
-            hipLaunchKernelGGL(gen_aggregate_kernel, grid1((size_t)N * H, 256), dim3(256), 0, st, (const float*)msg,
+            hipLaunchKernelGGL(gen_aggregate_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, st, (const float*)msg,
                                (const int*)seg_ptr, (const int*)perm, (const unsigned*)flags, hn, N, H, d->agg);
             HIP_TRY(hipGetLastError());
             h_cur = hn;

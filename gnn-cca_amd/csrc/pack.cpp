@@ -94,8 +94,10 @@ static GenBlobPlan plan_gen_blob(const gnncca_mpn_dims* d) {
     for (int m = 0; m < 5; ++m) {
         const gnncca_mlp& mlp = mlp_by_index(d, m);
         for (int l = 0; l < mlp.n_layers; ++l) {
-            p.h.w[m][l] = take((size_t)mlp.layers[l].in_dim * mlp.layers[l].out_dim);
-            p.h.b[m][l] = take(mlp.layers[l].out_dim);
+            // transposed and padded: [in][ceil8(out)] and [ceil8(out)] -- gen_dense_kernel reads 8 outputs per thread
+            const size_t op = ((size_t)mlp.layers[l].out_dim + 7) / 8 * 8;
+            p.h.w[m][l] = take((size_t)mlp.layers[l].in_dim * op);
+            p.h.b[m][l] = take(op);
         }
     }
     p.total_floats = off;
@@ -481,7 +483,9 @@ static int pack_generic(const gnncca_mpn_dims* d, const float* const* params, vo
         const gnncca_mlp& mlp = mlp_by_index(d, m);
         for (int l = 0; l < mlp.n_layers; ++l) {
             Folded f = fold_layer(mlp.layers[l], cur);
-            std::memcpy(blob + p.h.w[m][l], f.w.data(), f.w.size() * sizeof(float));
+            const size_t op = ((size_t)f.out + 7) / 8 * 8;  // padding stays zero
+            for (int o = 0; o < f.out; ++o)
+                for (int k = 0; k < f.in; ++k) blob[p.h.w[m][l] + (size_t)k * op + o] = f.w[(size_t)o * f.in + k];
             std::memcpy(blob + p.h.b[m][l], f.b.data(), f.b.size() * sizeof(float));
         }
     }
