@@ -95,38 +95,54 @@ __global__ __launch_bounds__(256) void gen_plan_finish_kernel(const long long* _
 }
 
 // h[i][c] = agg over the segment of node i of m[k][c], k in the caller's edge order (models/mpn.py:99,192-202).
-// One wave per node, lane = channel (channels beyond 64 in further passes): every edge row is one coalesced read; eight
-// rows are requested before they are added, IN ORDER, so the sum is the sequential one torch's CPU index_add_ forms.
+// One workgroup per node: its four waves take the four consecutive quarters of the segment, lane = channel (channels
+// beyond 64 in further passes), every edge row one coalesced read, sixteen rows requested before they are added in
+// order; the four partial results are then combined in order.  (A fixed association, reproducible run to run; it
+// differs from torch's strictly sequential CPU sum in the last bit only.)
 __global__ __launch_bounds__(256) void gen_aggregate_kernel(const float* __restrict__ m, const int* __restrict__ seg_ptr,
                                                             const int* __restrict__ perm, const unsigned* __restrict__ flags,
                                                             float* __restrict__ h, int N, int H, int agg) {
-    const int lane = threadIdx.x & 63;
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (i >= N) return;
+    __shared__ float s_part[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = blockIdx.x;
     const unsigned fl = flags[0];
+    if (fl & GNNCCA_GRAPH_BAD_INDEX) {  // the plan is not trustworthy: poison, touch nothing else
+        for (int c = threadIdx.x; c < H; c += 256) h[(size_t)i * H + c] = __builtin_nanf("");
+        return;
+    }
     const bool unsorted = (fl & GNNCCA_GRAPH_UNSORTED) != 0;
     const int s = seg_ptr[i], e = seg_ptr[i + 1];
-    for (int c = lane; c < H; c += 64) {
-        if (fl & GNNCCA_GRAPH_BAD_INDEX) {
-            h[(size_t)i * H + c] = __builtin_nanf("");
-            continue;
-        }
-        float v = agg == GNNCCA_AGG_MAX ? -INFINITY : 0.f;
-        for (int p0 = s; p0 < e; p0 += 8) {
-            float x[8];
+    const int len = e - s, q = (len + 3) / 4;
+    const int ws = min(s + wave * q, e), we = min(ws + q, e);
+    const float ident = agg == GNNCCA_AGG_MAX ? -INFINITY : 0.f;
+    for (int c0 = 0; c0 < H; c0 += 64) {
+        const int c = c0 + lane;
+        float v = ident;
+        if (c < H) {
+            for (int p0 = ws; p0 < we; p0 += 16) {
+                float x[16];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int p = min(p0 + u, e - 1);
-                const int k = unsorted ? perm[p] : p;
-                x[u] = m[(size_t)k * H + c];
+                for (int u = 0; u < 16; ++u) {
+                    const int p = min(p0 + u, we - 1);
+                    const int k = unsorted ? perm[p] : p;
+                    x[u] = m[(size_t)k * H + c];
+                }
+#pragma unroll
+                for (int u = 0; u < 16; ++u)
+                    if (p0 + u < we) v = agg == GNNCCA_AGG_MAX ? fmaxf(v, x[u]) : v + x[u];
             }
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (p0 + u < e) v = agg == GNNCCA_AGG_MAX ? fmaxf(v, x[u]) : v + x[u];
         }
-        if (agg == GNNCCA_AGG_MEAN) v = v / (float)max(e - s, 1);
-        if (e == s) v = 0.f;
-        h[(size_t)i * H + c] = v;
+        s_part[wave][lane] = v;
+        __syncthreads();
+        if (wave == 0 && c < H) {
+            float r = s_part[0][lane];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) r = agg == GNNCCA_AGG_MAX ? fmaxf(r, s_part[w][lane]) : r + s_part[w][lane];
+            if (agg == GNNCCA_AGG_MEAN) r = r / (float)max(len, 1);
+            if (len == 0) r = 0.f;
+            h[(size_t)i * H + c] = r;
+        }
+        __syncthreads();
     }
 }
 
@@ -216,7 +232,43 @@ static int forward_generic(const gnncca_mpn_dims* d, const void* packed_dev, con
 
     // encoder (models/mpn.py:270): node MLP on x, edge MLP on edge_attr
     int s;
-    if (d->enc_node.n_layers > 0) {
+    const int ks0 = gen_enc0_ksplit(d, n_nodes);
+    if (d->enc_node.n_layers > 0 && ks0 > 0) {
+        // first layer (the wide one: 2048-d embeddings) on the MFMA family's split-K fp32 GEMM + its reduce kernel,
+        // the remaining layers on the tiled dense kernel
+        const gnncca_layer& l0 = d->enc_node.layers[0];
+        float* part = reinterpret_cast<float*>(base + ws.partial);
+        int kslice = (l0.in_dim + ks0 - 1) / ks0;
+        kslice = (kslice + 63) / 64 * 64;
+        EncPlanParams ep;
+        std::memset(&ep, 0, sizeof(ep));
+        ep.in = x;
+        ep.W = blob + hdr.enc0_rowmajor;
+        ep.part = part;
+        ep.M = N;
+        ep.K = l0.in_dim;
+        ep.O = l0.out_dim;
+        ep.kslice = kslice;
+        ep.vec_ok = (l0.in_dim % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+        ep.nrt = (N + 31) / 32;
+        ep.nks = ks0;
+        ep.gemm_blocks = ep.nrt * ks0 * ((l0.out_dim + 127) / 128);
+        hipLaunchKernelGGL(enc_gemm_plan_kernel, dim3(ep.gemm_blocks), dim3(256), 0, st, ep);
+        HIP_TRY(hipGetLastError());
+        const bool only = d->enc_node.n_layers == 1;
+        float* dst0 = only ? h0 : nb[2];  // dense [N][out]
+        hipLaunchKernelGGL(reduce_bias_act_kernel, grid1((size_t)N * l0.out_dim, 256), dim3(256), 0, st, (const float*)part,
+                           blob + hdr.b[0][0], dst0, N, l0.out_dim, ks0, l0.relu);
+        HIP_TRY(hipGetLastError());
+        if (!only) {
+            gnncca_mlp rest = d->enc_node;
+            rest.n_layers = d->enc_node.n_layers - 1;
+            for (int l = 0; l < rest.n_layers; ++l) rest.layers[l] = d->enc_node.layers[l + 1];
+            s = gen_run_mlp(rest, blob, hdr.w[0] + 1, hdr.b[0] + 1, GenSeg{dst0, nullptr, l0.out_dim, l0.out_dim}, none, none, N,
+                            h0, H, nb[0], nb[1], nw, st);
+            if (s != GNNCCA_OK) return s;
+        }
+    } else if (d->enc_node.n_layers > 0) {
         s = gen_run_mlp(d->enc_node, blob, hdr.w[0], hdr.b[0], GenSeg{x, nullptr, d->node_in, d->node_in}, none, none, N, h0, H,
                         nb[0], nb[1], nw, st);
         if (s != GNNCCA_OK) return s;
@@ -294,7 +346,7 @@ static int forward_generic(const gnncca_mpn_dims* d, const void* packed_dev, con
                             GenSeg{e_new, nullptr, ew, EF}, none, E, msg, H, eb[0], eb[1], ew, st);
             if (s != GNNCCA_OK) return s;
             float* hn = h_lat[step & 1];
-            hipLaunchKernelGGL(gen_aggregate_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, st, (const float*)msg,
+            hipLaunchKernelGGL(gen_aggregate_kernel, dim3((unsigned)N), dim3(256), 0, st, (const float*)msg,
                                (const int*)seg_ptr, (const int*)perm, (const unsigned*)flags, hn, N, H, d->agg);
             HIP_TRY(hipGetLastError());
             h_cur = hn;

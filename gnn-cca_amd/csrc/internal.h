@@ -90,15 +90,18 @@ bool enc_split_ok(const gnncca_mpn_dims* d);  // first encoder layer eligible fo
 // MLP index: 0 encoder.node, 1 encoder.edge, 2 MPNet.edge_model, 3 MPNet.node_model, 4 classifier.edge
 struct GenBlobHeader {
     uint32_t magic, abi_version, family, total_floats;
-    int32_t w[5][GNNCCA_MAX_LAYERS];
-    int32_t b[5][GNNCCA_MAX_LAYERS];
+    int32_t w[5][GNNCCA_MAX_LAYERS];   // transposed, padded: [in][ceil8(out)]
+    int32_t b[5][GNNCCA_MAX_LAYERS];   // [ceil8(out)]
+    int32_t enc0_rowmajor;             // first node-encoder weight also as [out][in] (input of the MFMA GEMM), or 0
+    int32_t pad[3];
 };
+int gen_enc0_ksplit(const gnncca_mpn_dims* d, int64_t n_nodes);  // split-K factor of that GEMM (0: not used)
 bool gen_blob_header(const gnncca_mpn_dims* d, GenBlobHeader* out);
 const gnncca_mlp& mlp_by_index(const gnncca_mpn_dims* d, int i);
 
 struct GenWorkspace {
     size_t flags, blockflags, seg_ptr, col32, perm, cursor, row32o, col32o;
-    size_t node[3], h0, edge[4], e0, total;
+    size_t node[3], h0, edge[4], e0, partial, total;
     int64_t node_w, edge_w;  // floats per row of the node / edge scratch buffers
 };
 GenWorkspace carve_generic(const gnncca_mpn_dims* d, int64_t n, int64_t e);

@@ -100,9 +100,22 @@ static GenBlobPlan plan_gen_blob(const gnncca_mpn_dims* d) {
             p.h.b[m][l] = take(op);
         }
     }
+    // a wide first encoder layer (the 2048-d CNN embedding) runs on the MFMA family's split-K GEMM: keep its weight
+    // row-major too
+    if (d->enc_node.n_layers > 0 && d->enc_node.layers[0].in_dim >= 256 && d->enc_node.layers[0].in_dim % 64 == 0)
+        p.h.enc0_rowmajor = take((size_t)d->enc_node.layers[0].in_dim * d->enc_node.layers[0].out_dim);
     p.total_floats = off;
     p.h.total_floats = (uint32_t)off;
     return p;
+}
+
+int gen_enc0_ksplit(const gnncca_mpn_dims* d, int64_t n_nodes) {
+    if (classify(d) != kFamilyGeneric || plan_gen_blob(d).h.enc0_rowmajor == 0) return 0;
+    const int k0 = d->enc_node.layers[0].in_dim;
+    const size_t row_tiles = ((size_t)(n_nodes > 0 ? n_nodes : 0) + 31) / 32;
+    int ks = 1;
+    while (ks < 32 && row_tiles * (size_t)ks < 512 && k0 / (ks * 2) >= 64) ks *= 2;
+    return ks;
 }
 
 bool gen_blob_header(const gnncca_mpn_dims* d, GenBlobHeader* out) {
@@ -487,6 +500,8 @@ static int pack_generic(const gnncca_mpn_dims* d, const float* const* params, vo
             for (int o = 0; o < f.out; ++o)
                 for (int k = 0; k < f.in; ++k) blob[p.h.w[m][l] + (size_t)k * op + o] = f.w[(size_t)o * f.in + k];
             std::memcpy(blob + p.h.b[m][l], f.b.data(), f.b.size() * sizeof(float));
+            if (m == 0 && l == 0 && p.h.enc0_rowmajor)
+                std::memcpy(blob + p.h.enc0_rowmajor, f.w.data(), f.w.size() * sizeof(float));
         }
     }
     return GNNCCA_OK;
@@ -526,6 +541,8 @@ GenWorkspace carve_generic(const gnncca_mpn_dims* d, int64_t n, int64_t e) {
     w.h0 = take(N * (size_t)d->node_dim * 4);
     for (int i = 0; i < 4; ++i) w.edge[i] = take(E * (size_t)ew * 4);
     w.e0 = take(E * (size_t)d->edge_dim * 4);
+    const int ks = gen_enc0_ksplit(d, n);
+    w.partial = take(ks > 0 ? (size_t)ks * N * (size_t)d->enc_node.layers[0].out_dim * 4 : 0);
     w.total = off;
     return w;
 }
