@@ -291,7 +291,9 @@ class MOTMPNet(nn.Module):
 
     def _packed_weights(self, device):
         if self._weights_dirty or self._packed is None or self._packed[1].device != device \
-                or self._packed[0] != self._version_key():
+                or self._packed[0] != self._version_key() \
+                or (self.training and torch.cuda.is_current_stream_capturing()):
+            # (a training step being captured into a HIP graph must contain the repack: replays run no Python)
             blob = self._pack_weights_device(device)
             self.set_packed_weights(blob if blob is not None else self.pack_weights_host().to(device))
         return self._packed[1]
