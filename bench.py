@@ -289,7 +289,7 @@ def main():
         # per-kernel durations (HIP events around every launch; separate pass so the timed region is undisturbed)
         kernel_ms = {}
         for _ in range(args.profile_reps):
-            for _q in range(4):  # keep the queue busy so the bracketing events time execution, not host launch gaps
+            for _q in range(4):  # a warm queue, as in the timed region
                 model(data)
             _, times = model.forward_profiled(data)
             for kind, ms in times:

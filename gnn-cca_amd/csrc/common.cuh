@@ -1,6 +1,7 @@
 #pragma once
 // Shared by every kernel file: vector typedefs, error / profiling helpers, the diagnostic stamp macro.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <cmath>
@@ -43,42 +44,61 @@ __device__ unsigned long long* g_stamps = nullptr;
         }                                              \
     } while (0)
 
-// Per-kernel timing for bench.py / rocprof cross-checks: one hipEvent after every launch (diagnostic entry point only).
+// Per-kernel timing for bench.py / rocprof cross-checks (diagnostic entry point only).  The events are ATTACHED TO
+// THE DISPATCH (hipExtLaunchKernelGGL start / stop events), so a slot's elapsed time is the kernel's own execution
+// time, the quantity rocprofv3 --kernel-trace reports -- not launch-to-launch time with the cost of an event packet
+// in it (which is 2-3 us, more than half of a 5 us launch).
 struct Profiler {
     gnncca_profile* out;
-    hipEvent_t ev[GNNCCA_PROFILE_MAX + 1];
+    hipEvent_t start[GNNCCA_PROFILE_MAX], stop[GNNCCA_PROFILE_MAX];
     int n;
 };
+static thread_local Profiler* t_prof = nullptr;  // non-null only inside gnncca_mpn_forward_profiled
 
-static int prof_begin(Profiler* p, hipStream_t st) {
-    if (!p) return GNNCCA_OK;
+static int prof_begin(Profiler* p) {
     p->n = 0;
-    for (int i = 0; i <= GNNCCA_PROFILE_MAX; ++i) HIP_TRY(hipEventCreate(&p->ev[i]));
-    HIP_TRY(hipEventRecord(p->ev[0], st));
+    for (int i = 0; i < GNNCCA_PROFILE_MAX; ++i) {
+        HIP_TRY(hipEventCreate(&p->start[i]));
+        HIP_TRY(hipEventCreate(&p->stop[i]));
+    }
+    t_prof = p;
     return GNNCCA_OK;
 }
 
-static int prof_mark(Profiler* p, int kind, hipStream_t st) {
+// the launch that precedes this call used slot n (GNNCCA_LAUNCH): name it and move on
+static int prof_mark(Profiler* p, int kind) {
     if (!p || p->n >= GNNCCA_PROFILE_MAX) return GNNCCA_OK;
     p->out->kind[p->n] = kind;
     p->n++;
-    HIP_TRY(hipEventRecord(p->ev[p->n], st));
     return GNNCCA_OK;
 }
 
 static int prof_end(Profiler* p, hipStream_t st) {
-    if (!p) return GNNCCA_OK;
+    t_prof = nullptr;
     HIP_TRY(hipStreamSynchronize(st));
     p->out->count = p->n;
-    for (int i = 0; i < p->n; ++i) HIP_TRY(hipEventElapsedTime(&p->out->ms[i], p->ev[i], p->ev[i + 1]));
-    for (int i = 0; i <= GNNCCA_PROFILE_MAX; ++i) HIP_TRY(hipEventDestroy(p->ev[i]));
+    for (int i = 0; i < p->n; ++i) HIP_TRY(hipEventElapsedTime(&p->out->ms[i], p->start[i], p->stop[i]));
+    for (int i = 0; i < GNNCCA_PROFILE_MAX; ++i) {
+        HIP_TRY(hipEventDestroy(p->start[i]));
+        HIP_TRY(hipEventDestroy(p->stop[i]));
+    }
     return GNNCCA_OK;
 }
 
 #define PROF_MARK(kind)                                  \
     do {                                                 \
-        int _s = prof_mark(prof, (kind), st);            \
+        int _s = prof_mark(prof, (kind));                \
         if (_s != GNNCCA_OK) return _s;                  \
+    } while (0)
+
+// Kernel launch of the forward path: plain, or with the profiler's events attached to this very dispatch.
+#define GNNCCA_LAUNCH(kernel, grid, block, lds, st, ...)                                                              \
+    do {                                                                                                              \
+        if (t_prof != nullptr && t_prof->n < GNNCCA_PROFILE_MAX)                                                      \
+            hipExtLaunchKernelGGL(kernel, grid, block, lds, st, t_prof->start[t_prof->n], t_prof->stop[t_prof->n], 0, \
+                                  __VA_ARGS__);                                                                       \
+        else                                                                                                          \
+            hipLaunchKernelGGL(kernel, grid, block, lds, st, __VA_ARGS__);                                            \
     } while (0)
 
 

@@ -133,12 +133,12 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsGemmBytes));
                     attr_dev = dev;
                 }
-                hipLaunchKernelGGL(enc_gemm_split_lds_kernel, dim3((N + 255) / 256, ks_split), dim3(512), kLdsGemmBytes, st, cur_in,
+                GNNCCA_LAUNCH(enc_gemm_split_lds_kernel, dim3((N + 255) / 256, ks_split), dim3(512), kLdsGemmBytes, st, cur_in,
                                    w3, part, N, K, O, K / ks_split);
             } else {
                 // 128-row workgroups (a wave = 32 rows x 128 columns); split-K until >= 512 workgroups are in flight
                 while (ks_split < ws.ksplit && ((N + 127) / 128) * ks_split < 512 && (K / (ks_split * 2)) % 32 == 0) ks_split *= 2;
-                hipLaunchKernelGGL(enc_gemm_split_direct_kernel, dim3((N + 127) / 128, ks_split), dim3(256), 0, st, cur_in, w3, part,
+                GNNCCA_LAUNCH(enc_gemm_split_direct_kernel, dim3((N + 127) / 128, ks_split), dim3(256), 0, st, cur_in, w3, part,
                                    N, K, O, K / ks_split);
             }
             HIP_TRY(hipGetLastError());
@@ -155,14 +155,14 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
             plan_blocks = plan_num_blocks(E);
         }
         if (ep.gemm_blocks + plan_blocks > 0) {
-            hipLaunchKernelGGL(enc_gemm_plan_kernel, dim3(ep.gemm_blocks + plan_blocks), dim3(256), 0, st, ep);
+            GNNCCA_LAUNCH(enc_gemm_plan_kernel, dim3(ep.gemm_blocks + plan_blocks), dim3(256), 0, st, ep);
             HIP_TRY(hipGetLastError());
             PROF_MARK(split ? GNNCCA_K_PLAN_ROWS : GNNCCA_K_ENC_GEMM);
         }
         ks_last = split ? ks_split : ks;
         if (g < n_gemm - 1) {
             float* dst = act + (size_t)(g & 1) * N * O;
-            hipLaunchKernelGGL(reduce_bias_act_kernel, grid1((size_t)N * O, 256), dim3(256), 0, st, (const float*)part,
+            GNNCCA_LAUNCH(reduce_bias_act_kernel, grid1((size_t)N * O, 256), dim3(256), 0, st, (const float*)part,
                                blob + hdr.enc_node_b[g], dst, N, O, ks, l.relu);
             HIP_TRY(hipGetLastError());
             PROF_MARK(GNNCCA_K_ENC_REDUCE);
@@ -208,7 +208,7 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
         tp.blockflags = blockflags;
         tp.E = E;
         const unsigned blocks = (unsigned)std::min<size_t>(((size_t)N + 3) / 4, 2048) + 1;  // + plan-repair workgroup
-        hipLaunchKernelGGL(enc_tail_kernel, dim3(blocks), dim3(256), std::max<size_t>(lds, 4096), st, tp);
+        GNNCCA_LAUNCH(enc_tail_kernel, dim3(blocks), dim3(256), std::max<size_t>(lds, 4096), st, tp);
         HIP_TRY(hipGetLastError());
         PROF_MARK(GNNCCA_K_ENC_TAIL);
     }
@@ -328,7 +328,7 @@ int gnncca_mpn_forward_profiled(const gnncca_mpn_dims* d, const void* packed_dev
     Profiler p;
     p.out = profile;
     profile->count = 0;
-    int s = prof_begin(&p, st);
+    int s = prof_begin(&p);
     if (s != GNNCCA_OK) return s;
     s = forward_impl(d, packed_dev, x, edge_index, edge_attr, n_nodes, n_edges, workspace, workspace_bytes, logits_out,
                      nullptr, stream, &p, profile->options);

@@ -286,7 +286,7 @@ static hipError_t launch_step_t(const StepParams& sp, hipStream_t st) {
     const int npg = 4 / sp.wps;
     const unsigned blocks = (unsigned)((sp.N + npg - 1) / npg);
     const size_t lds = ((MSG ? (size_t)sp.hin * kProjOut : 0) + 4 * kH + (sp.pd_lds ? (size_t)sp.N * kPdStride : 0)) * sizeof(float);
-    hipLaunchKernelGGL((mpn_step_kernel<RE, MSG, MX>), dim3(blocks), dim3(256), lds, st, sp);
+    GNNCCA_LAUNCH((mpn_step_kernel<RE, MSG, MX>), dim3(blocks), dim3(256), lds, st, sp);
     return hipGetLastError();
 }
 

@@ -147,8 +147,9 @@ GNNCCA_API int gnncca_mpn_forward(const gnncca_mpn_dims* dims, const void* packe
                        int64_t n_edges, void* workspace, size_t workspace_bytes, float* logits_out,
                        const gnncca_trace* trace, gnncca_stream_t stream);
 
-/* Diagnostic twin of gnncca_mpn_forward for bench.py: records a hipEvent after every kernel launch,
- * SYNCHRONISES the stream and returns the per-launch elapsed times.  Never used on the product path. */
+/* Diagnostic twin of gnncca_mpn_forward for bench.py: attaches a start and a stop hipEvent to every kernel dispatch
+ * (hipExtLaunchKernelGGL), SYNCHRONISES the stream and returns each kernel's own execution time -- what
+ * rocprofv3 --kernel-trace reports.  Never used on the product path. */
 #define GNNCCA_PROFILE_MAX 64
 enum { GNNCCA_K_PLAN_ROWS = 0, GNNCCA_K_PLAN_SORT = 1, GNNCCA_K_ENC_GEMM = 2, GNNCCA_K_ENC_REDUCE = 3,
        GNNCCA_K_ENC_TAIL = 4, GNNCCA_K_STEP = 5, GNNCCA_K_STEP_LAST = 6 };
@@ -156,7 +157,7 @@ typedef struct gnncca_profile {
     uint32_t options;                   /* in: GNNCCA_OPT_* for the profiled forward */
     int32_t count;                      /* launches recorded */
     int32_t kind[GNNCCA_PROFILE_MAX];   /* GNNCCA_K_* */
-    float ms[GNNCCA_PROFILE_MAX];       /* hipEventElapsedTime between the events before / after the launch */
+    float ms[GNNCCA_PROFILE_MAX];       /* hipEventElapsedTime(start, stop) of the dispatch's own events */
 } gnncca_profile;
 GNNCCA_API int gnncca_mpn_forward_profiled(const gnncca_mpn_dims* dims, const void* packed_dev, const float* x,
                                 const int64_t* edge_index, const float* edge_attr, int64_t n_nodes,
