@@ -108,7 +108,7 @@ def step_algorithmic_bytes(E, L, n_cls, msg_only=True, e_bytes=24):
 
 def scale_probe(params, device, args, graphs=64):
     """The SAME step kernel on a batch of `graphs` graphs of the headline size, where the edge state (200 MB) no longer
-    fits any cache: the HBM-relevant operating point of the dominant kernel, measured live (HIP events around each
+    fits any cache: the HBM-relevant operating point of the dominant kernel, measured live (HIP events attached to each
     launch, `forward_profiled`), reported next to the latency-bound single-graph figure.  Not part of `value`."""
     import copy
     model = build_model(copy.deepcopy(params), args.nodes).to(device)
@@ -286,7 +286,7 @@ def main():
             out = static_out
         ok = all(torch.isfinite(o).all().item() for o in out["classified_edges"])
 
-        # per-kernel durations (HIP events around every launch; separate pass so the timed region is undisturbed)
+        # per-kernel durations (HIP events attached to every dispatch; separate pass so the timed region is undisturbed)
         kernel_ms = {}
         for _ in range(args.profile_reps):
             for _q in range(4):  # a warm queue, as in the timed region
