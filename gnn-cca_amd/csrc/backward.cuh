@@ -57,6 +57,8 @@ struct BwdEdgeParams {
     const float* Q;        // [N][32]
     const float* g_h;      // [N][32] d loss / d h_s, or null on the last step (its node update is dead)
     const int* deg;        // [N] (mean) or null
+    const int* hmax;       // [N][32] ('max'): bit pattern of the largest positive message per node and channel, or null
+    const int* hcnt;       // [N][32] ('max'): how many of the node's edges attain it (ties share the gradient)
     const float* g_logit;  // [E] or null
     const float* ge_in;    // [E][6] from step s+1, or null
     float* ge_out;         // [E][6] d loss / d e_{s-1}
@@ -82,6 +84,36 @@ struct BwdEdgeParams {
     long long E;
     int N, cls_hidden;     // cls_hidden == 0: single Linear(6,1)
 };
+
+// 'max' aggregation, pass 1: hmax[i][c] = bit pattern of max over the edges of node i of the (positive) message
+// pre-activation b = Q[i][c] + W_ne[c] . e', recomputed with exactly the arithmetic bwd_edge_kernel uses, so that its
+// equality test selects the same edge.  Positive floats order like their bit patterns: atomicMax on int.
+// Pass 2 (COUNT): hcnt[i][c] = number of edges that attain it.
+template <bool COUNT>
+__global__ __launch_bounds__(256) void bwd_max_kernel(const long long* __restrict__ ei, const float* __restrict__ e_cur,
+                                                      const float* __restrict__ Q, const float* __restrict__ Wn_, long long E,
+                                                      int* __restrict__ hmax, int* __restrict__ hcnt) {
+    const long long k = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (k >= E) return;
+    typedef const float __attribute__((address_space(4))) cfloat;
+    cfloat* Wn = (cfloat*)(unsigned long long)Wn_;
+    const int i = (int)ei[k];
+    float es[kEF];
+#pragma unroll
+    for (int f = 0; f < kEF; ++f) es[f] = e_cur[k * kEF + f];
+    for (int c = 0; c < kH; ++c) {
+        float b = Q[(size_t)i * kH + c];
+#pragma unroll
+        for (int f = 0; f < kEF; ++f) b = fmaf(Wn[c * (kH + kEF) + kH + f], es[f], b);
+        if (b > 0.f) {
+            if (COUNT) {
+                if (__float_as_int(b) == hmax[(size_t)i * kH + c]) atomicAdd(&hcnt[(size_t)i * kH + c], 1);
+            } else {
+                atomicMax(&hmax[(size_t)i * kH + c], __float_as_int(b));
+            }
+        }
+    }
+}
 
 // Workgroup-resident accumulators of the parameter gradients this kernel produces (LDS slots):
 constexpr int kSlotWe = 0;                    // [6][6]  d W_ee
@@ -148,6 +180,11 @@ __global__ __launch_bounds__(256) void bwd_edge_kernel(const BwdEdgeParams p) {
         };
         // the row's Q and d h rows, requested up front (16 x 16 B per lane) so that the channel loop has no loads
         float q_row[kH], gh_row[kH];
+        int hm_row[kH];
+        if (p.g_h && p.hmax) {
+#pragma unroll
+            for (int c = 0; c < kH; ++c) hm_row[c] = p.hmax[(size_t)i * kH + c];
+        }
         if (p.g_h) {
             const f32x4* __restrict__ q4 = reinterpret_cast<const f32x4*>(p.Q + (size_t)i * kH);
             const f32x4* __restrict__ g4 = reinterpret_cast<const f32x4*>(p.g_h + (size_t)i * kH);
@@ -255,7 +292,18 @@ __global__ __launch_bounds__(256) void bwd_edge_kernel(const BwdEdgeParams p) {
                     float b = q_row[c];
 #pragma unroll
                     for (int f = 0; f < kEF; ++f) b = fmaf(Wn[c * (kH + kEF) + kH + f], es[f], b);
-                    const float gb = b > 0.f ? gh_row[c] * inv * live : 0.f;
+                    // 'max': only the edge(s) that attain the node's maximum pass the gradient on (a maximum of 0, i.e. no
+                    // positive message, passes nothing: ReLU' = 0 there anyway)
+                    // Ties are real: an edge whose six features are all dead (e' = 0) has b = Q[row][c], the same for every such
+                    // edge of the node.  They share the gradient equally (torch's amax backward; torch_scatter hands it to one
+                    // of them -- the same total, and tied edges are indistinguishable downstream).
+                    float gb = 0.f;
+                    if (b > 0.f) {
+                        if (p.hmax == nullptr)
+                            gb = gh_row[c] * inv * live;
+                        else if (__float_as_int(b) == hm_row[c])
+                            gb = gh_row[c] * live / (float)max(p.hcnt[(size_t)i * kH + c], 1);
+                    }
                     v[8 * u] = gb;
                     v[8 * u + 7] = 0.f;
 #pragma unroll

@@ -419,7 +419,7 @@ int gnncca_post_prune_cluster(const int64_t* edge_index, const int64_t* predicti
 // ---- backward ---------------------------------------------------------------------------
 static bool backward_ok(const gnncca_mpn_dims* d) {
     if (classify(d) != kFamilyMfma32x6) return false;
-    if (d->reattach_nodes || d->reattach_edges || d->agg == GNNCCA_AGG_MAX || d->num_enc_steps < 1) return false;
+    if (d->reattach_nodes || d->reattach_edges || d->num_enc_steps < 1) return false;
     if (d->enc_node.n_layers != 2) return false;
     const gnncca_mlp* all[5] = {&d->enc_node, &d->enc_edge, &d->edge_mlp, &d->node_mlp, &d->cls_edge};
     for (int mi = 0; mi < 5; ++mi)
@@ -484,7 +484,7 @@ size_t gnncca_backward_workspace_bytes(const gnncca_mpn_dims* d, int64_t n_nodes
     const size_t N = (size_t)n_nodes, E = (size_t)n_edges, F1 = (size_t)d->enc_node.layers[0].out_dim;
     auto up = [](size_t v) { return (v + 255) / 256 * 256; };
     const size_t L = (size_t)std::max(d->num_enc_steps, 1);
-    return up(N * 4) + up(N * kH * 4) + up(L * N * 44 * 4) + 2 * up(N * kH * 4) + 2 * up(E * kEF * 4) + 2 * up(N * F1 * 4) +
+    return up(N * 4) + up(N * kH * 4) + up(2 * N * kH * 4) + up(L * N * 44 * 4) + 2 * up(N * kH * 4) + 2 * up(E * kEF * 4) + 2 * up(N * F1 * 4) +
            up(32 * N * F1 * 4) + up(sizeof(double) * 128) + up(sizeof(float) * 128);
 }
 
@@ -565,6 +565,8 @@ int gnncca_mpn_backward_ex(const gnncca_mpn_dims* d, const float* const* params_
     auto take = [&](size_t bytes) { char* q = base + off; off += up(bytes); return q; };
     int* deg = reinterpret_cast<int*>(take((size_t)N * 4));
     float* Q = reinterpret_cast<float*>(take((size_t)N * kH * 4));
+    int* hmax = reinterpret_cast<int*>(take((size_t)2 * N * kH * 4));  // 'max' aggregation only: maxima, then tie counts
+    int* hcnt = hmax + (size_t)N * kH;
     float* dP_all = reinterpret_cast<float*>(take((size_t)std::max(L, 1) * N * 44 * 4));  // one table per step, cleared once
     float* Hb[2] = {reinterpret_cast<float*>(take((size_t)N * kH * 4)), reinterpret_cast<float*>(take((size_t)N * kH * 4))};
     float* Gb[2] = {reinterpret_cast<float*>(take((size_t)E * kEF * 4)), reinterpret_cast<float*>(take((size_t)E * kEF * 4))};
@@ -610,6 +612,16 @@ int gnncca_mpn_backward_ex(const gnncca_mpn_dims* d, const float* const* params_
         bp.Q = Q;
         bp.g_h = g_h;
         bp.deg = d->agg == GNNCCA_AGG_MEAN ? deg : nullptr;
+        if (g_h && d->agg == GNNCCA_AGG_MAX) {  // which edge attained each node's maximum
+            HIP_TRY(hipMemsetAsync(hmax, 0, (size_t)2 * N * kH * 4, st));
+            hipLaunchKernelGGL(bwd_max_kernel<false>, grid1((size_t)E, 256), dim3(256), 0, st, ei, e_cur, (const float*)Q, Wn,
+                               (long long)E, hmax, hcnt);
+            hipLaunchKernelGGL(bwd_max_kernel<true>, grid1((size_t)E, 256), dim3(256), 0, st, ei, e_cur, (const float*)Q, Wn,
+                               (long long)E, hmax, hcnt);
+            HIP_TRY(hipGetLastError());
+            bp.hmax = hmax;
+            bp.hcnt = hcnt;
+        }
         bp.g_logit = s >= first_cls ? grad_logits + (size_t)out_idx * E : nullptr;
         if (bp.g_logit && cls_bn) {  // reductions the BatchNorm backward needs before any per-edge gradient
             const float* stat = cls_bn_stat + (size_t)out_idx * c1 * 2;

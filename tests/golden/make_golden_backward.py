@@ -66,6 +66,7 @@ def main():
     n, ei = cross_camera_edges([8, 8, 8, 8])
     run(MOTMPNet, "terrace32", make_params(**tiny), "tiny64", n, ei, 303, 304, 1.0 / 24)
     run(MOTMPNet, "terrace32_mean", make_params(agg="mean", **tiny), "tiny64", n, ei, 305, 306, 1.0)
+    run(MOTMPNet, "terrace32_max", make_params(agg="max", **tiny), "tiny64", n, ei, 311, 312, 1.0)
     n, ei = dense_edges(20)
     perm = np.random.default_rng(9).permutation(ei.shape[1])
     run(MOTMPNet, "dense20_shuf", make_params(L=3, n_cls=2, **tiny), "tiny64", n, ei[:, perm], 307, 308, 1.0 / 19)
