@@ -13,7 +13,8 @@
 // global memory with one float atomic per value and (persistent) workgroup; sums of outer products over nodes run on
 // the fp32 MFMA pipe (bwd_outer_mfma_kernel).  The result depends
 // on arrival order in the last bits exactly like the reference on CUDA (cuBLAS / torch_scatter atomics).
-// Supported: the MFMA family without reattach flags, without BatchNorm, 'sum' / 'mean', two-layer node encoder.
+// Supported: the MFMA family without reattach flags, BatchNorm nowhere or inside the classifier only, all three
+// aggregators, two-layer node encoder.
 // Part of the single translation unit mpn_forward.hip.
 namespace gnncca {
 
