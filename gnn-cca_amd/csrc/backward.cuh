@@ -13,8 +13,8 @@
 // global memory with one float atomic per value and (persistent) workgroup; sums of outer products over nodes run on
 // the fp32 MFMA pipe (bwd_outer_mfma_kernel).  The result depends
 // on arrival order in the last bits exactly like the reference on CUDA (cuBLAS / torch_scatter atomics).
-// Supported: the MFMA family without reattach flags, BatchNorm nowhere or inside the classifier only, all three
-// aggregators, two-layer node encoder.
+// Supported: the MFMA family -- both reattach flags, all three aggregators -- with BatchNorm nowhere or inside the
+// classifier only and a two-layer node encoder.
 // Part of the single translation unit mpn_forward.hip.
 namespace gnncca {
 
@@ -37,15 +37,23 @@ __global__ __launch_bounds__(256) void bwd_degree_kernel(const long long* __rest
     if (r >= 0 && r < N) atomicAdd(&deg[r], 1);
 }
 
-// Q[i][c] = b_n[c] + sum_c' W_n[c][c'] h[i][c']   (W_n row-major [32][38], node part = columns 0..31)
-__global__ __launch_bounds__(256) void bwd_q_kernel(const float* __restrict__ h, const float* __restrict__ Wn,
-                                                    const float* __restrict__ bn, float* __restrict__ Q, int N) {
+// Q[i][c] = b_n[c] + sum_d W_n[c][d] hin[i][d]   (W_n row-major [32][HI + 6]; hin = h, or cat(h0, h) with
+// reattach_initial_nodes: HI = 64, models/mpn.py:285)
+__global__ __launch_bounds__(256) void bwd_q_kernel(const float* __restrict__ h0, const float* __restrict__ h,
+                                                    const float* __restrict__ Wn, const float* __restrict__ bn,
+                                                    float* __restrict__ Q, int N, int HI) {
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= N * kH) return;
     const int i = t / kH, c = t - i * kH;
+    const float* __restrict__ w = Wn + (size_t)c * (HI + kEF);
     float acc = bn[c];
+    if (HI > kH) {
 #pragma unroll
-    for (int d = 0; d < kH; ++d) acc = fmaf(Wn[c * (kH + kEF) + d], h[(size_t)i * kH + d], acc);
+        for (int d = 0; d < kH; ++d) acc = fmaf(w[d], h0[(size_t)i * kH + d], acc);
+        w += kH;
+    }
+#pragma unroll
+    for (int d = 0; d < kH; ++d) acc = fmaf(w[d], h[(size_t)i * kH + d], acc);
     Q[t] = acc;
 }
 
@@ -55,6 +63,9 @@ struct BwdEdgeParams {
     const long long* ei;
     const float* e_cur;    // [E][6] latent after this step
     const float* e_prev;   // [E][6] latent before this step (encoder output for step 1)
+    const float* e0;       // [E][6] encoder output (reattach_initial_edges: the edge MLP reads cat(e0, e_prev)), or null
+    float* ge0_acc;        // [E][6] d loss / d e0 through the reattached copies, accumulated over the steps, or null
+    int HI;                // width of the node input of both MLPs: 32, or 64 with reattach_initial_nodes
     const float* Q;        // [N][32]
     const float* g_h;      // [N][32] d loss / d h_s, or null on the last step (its node update is dead)
     const int* deg;        // [N] (mean) or null
@@ -93,7 +104,7 @@ struct BwdEdgeParams {
 template <bool COUNT>
 __global__ __launch_bounds__(256) void bwd_max_kernel(const long long* __restrict__ ei, const float* __restrict__ e_cur,
                                                       const float* __restrict__ Q, const float* __restrict__ Wn_, long long E,
-                                                      int* __restrict__ hmax, int* __restrict__ hcnt) {
+                                                      int HI, int* __restrict__ hmax, int* __restrict__ hcnt) {
     const long long k = (long long)blockIdx.x * 256 + threadIdx.x;
     if (k >= E) return;
     typedef const float __attribute__((address_space(4))) cfloat;
@@ -105,7 +116,7 @@ __global__ __launch_bounds__(256) void bwd_max_kernel(const long long* __restric
     for (int c = 0; c < kH; ++c) {
         float b = Q[(size_t)i * kH + c];
 #pragma unroll
-        for (int f = 0; f < kEF; ++f) b = fmaf(Wn[c * (kH + kEF) + kH + f], es[f], b);
+        for (int f = 0; f < kEF; ++f) b = fmaf(Wn[c * (HI + kEF) + HI + f], es[f], b);
         if (b > 0.f) {
             if (COUNT) {
                 if (__float_as_int(b) == hmax[(size_t)i * kH + c]) atomicAdd(&hcnt[(size_t)i * kH + c], 1);
@@ -117,8 +128,8 @@ __global__ __launch_bounds__(256) void bwd_max_kernel(const long long* __restric
 }
 
 // Workgroup-resident accumulators of the parameter gradients this kernel produces (LDS slots):
-constexpr int kSlotWe = 0;                    // [6][6]  d W_ee
-constexpr int kSlotBe = kSlotWe + 36;         // [6]     d b_e
+constexpr int kSlotWe = 0;                    // [6][12] d W_ee  (12 columns with reattach_initial_edges, else 6 used)
+constexpr int kSlotBe = kSlotWe + 72;         // [6]     d b_e
 constexpr int kSlotWn = kSlotBe + 6;          // [32][6] d W_ne
 constexpr int kSlotBn = kSlotWn + 192;        // [32]    d b_n
 constexpr int kSlotWc1 = kSlotBn + 32;        // [C1][6] d W_cls1   (C1 <= kMaxCls; single Linear: [1][6])
@@ -162,6 +173,9 @@ __global__ __launch_bounds__(256) void bwd_edge_kernel(const BwdEdgeParams p) {
     cfloat* bn_stat = (cfloat*)(unsigned long long)p.bn_stat;
     cfloat* bn_red = (cfloat*)(unsigned long long)p.bn_red;
     const int lane = threadIdx.x & 63;
+    const int HI = p.HI, WnLd = HI + kEF;                 // node-MLP weight rows: [x[row] (HI) | e' (6)]
+    const int EI = p.e0 ? 2 * kEF : kEF;                  // edge part of the edge-MLP input: e, or cat(e0, e)
+    const int WeLd = 2 * HI + EI, WeE = 2 * HI;           // edge-MLP weight rows: [x[row] (HI) | x[col] (HI) | edge (EI)]
 
     for (long long chunk = blockIdx.x; chunk * 256 < p.E; chunk += gridDim.x) {
         const long long k0 = chunk * 256 + threadIdx.x;
@@ -196,11 +210,12 @@ __global__ __launch_bounds__(256) void bwd_edge_kernel(const BwdEdgeParams p) {
                 for (int u = 0; u < 4; ++u) q_row[4 * c + u] = a[u], gh_row[4 * c + u] = b[u];
             }
         }
-        float es[kEF], ep[kEF], ge[kEF];
+        float es[kEF], ep[kEF], ez[kEF], ge[kEF];
 #pragma unroll
         for (int f = 0; f < kEF; ++f) {
             es[f] = p.e_cur[k * kEF + f];
             ep[f] = p.e_prev[k * kEF + f];
+            ez[f] = p.e0 ? p.e0[k * kEF + f] : 0.f;
             ge[f] = p.ge_in ? p.ge_in[k * kEF + f] * live : 0.f;
         }
         // ---- classifier ----------------------------------------------------------------------------------------
@@ -292,7 +307,7 @@ __global__ __launch_bounds__(256) void bwd_edge_kernel(const BwdEdgeParams p) {
                     const int c = c0 + u;
                     float b = q_row[c];
 #pragma unroll
-                    for (int f = 0; f < kEF; ++f) b = fmaf(Wn[c * (kH + kEF) + kH + f], es[f], b);
+                    for (int f = 0; f < kEF; ++f) b = fmaf(Wn[c * WnLd + HI + f], es[f], b);
                     // 'max': only the edge(s) that attain the node's maximum pass the gradient on (a maximum of 0, i.e. no
                     // positive message, passes nothing: ReLU' = 0 there anyway)
                     // Ties are real: an edge whose six features are all dead (e' = 0) has b = Q[row][c], the same for every such
@@ -310,7 +325,7 @@ __global__ __launch_bounds__(256) void bwd_edge_kernel(const BwdEdgeParams p) {
 #pragma unroll
                     for (int f = 0; f < kEF; ++f) {
                         v[8 * u + 1 + f] = gb * es[f];
-                        ge[f] = fmaf(Wn[c * (kH + kEF) + kH + f], gb, ge[f]);
+                        ge[f] = fmaf(Wn[c * WnLd + HI + f], gb, ge[f]);
                     }
                     if (gb != 0.f) add_row(12 + c, gb);
                 }
@@ -331,30 +346,50 @@ __global__ __launch_bounds__(256) void bwd_edge_kernel(const BwdEdgeParams p) {
                 atomicAdd(&p.dP[(size_t)j * 44 + 6 + f], ga[f]);
             }
         }
-        // two output features per reduction: slots [8u + 0] d b_e[f0+u], [8u + 1 + g] d W_ee[f0+u][g]
+        if (p.e0 == nullptr) {
+            // two output features per reduction: slots [8u + 0] d b_e[f0+u], [8u + 1 + g] d W_ee[f0+u][g]
 #pragma unroll
-        for (int f0 = 0; f0 < kEF; f0 += 2) {
-            float v[16];
+            for (int f0 = 0; f0 < kEF; f0 += 2) {
+                float v[16];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                v[8 * u] = ga[f0 + u];
-                v[8 * u + 7] = 0.f;
+                for (int u = 0; u < 2; ++u) {
+                    v[8 * u] = ga[f0 + u];
+                    v[8 * u + 7] = 0.f;
 #pragma unroll
-                for (int g = 0; g < kEF; ++g) v[8 * u + 1 + g] = ga[f0 + u] * ep[g];
+                    for (int g = 0; g < kEF; ++g) v[8 * u + 1 + g] = ga[f0 + u] * ep[g];
+                }
+                wave_lds_add16(v, s_acc, [&](int idx) {
+                    const int f = f0 + (idx >> 3), r = idx & 7;
+                    if (r == 7) return -1;
+                    return r == 0 ? kSlotBe + f : kSlotWe + f * 12 + r - 1;
+                });
             }
-            wave_lds_add16(v, s_acc, [&](int idx) {
-                const int f = f0 + (idx >> 3), r = idx & 7;
-                if (r == 7) return -1;
-                return r == 0 ? kSlotBe + f : kSlotWe + f * kEF + r - 1;
-            });
+        } else {
+            // reattach_initial_edges: the edge part of the input is cat(e0, e_prev), twelve columns -- one output feature
+            // per reduction: slots [0] d b_e[f], [1 + g] d W_ee[f][g] (g < 6: e0, g >= 6: e_prev)
+#pragma unroll
+            for (int f = 0; f < kEF; ++f) {
+                float v[16];
+                v[0] = ga[f];
+#pragma unroll
+                for (int g = 0; g < kEF; ++g) v[1 + g] = ga[f] * ez[g], v[7 + g] = ga[f] * ep[g];
+                v[13] = v[14] = v[15] = 0.f;
+                wave_lds_add16(v, s_acc, [&](int idx) { return idx == 0 ? kSlotBe + f : (idx <= 12 ? kSlotWe + f * 12 + idx - 1 : -1); });
+            }
         }
         if (valid) {
+            // gradient of the edge part of the input: W_ee^T g_a; with reattach the first six columns belong to e0
+            const int off_prev = p.e0 ? kEF : 0;
 #pragma unroll
             for (int g = 0; g < kEF; ++g) {
-                float s = 0.f;
+                float s = 0.f, s0 = 0.f;
 #pragma unroll
-                for (int f = 0; f < kEF; ++f) s = fmaf(We[f * 70 + 64 + g], ga[f], s);
+                for (int f = 0; f < kEF; ++f) {
+                    s = fmaf(We[f * WeLd + WeE + off_prev + g], ga[f], s);
+                    if (p.e0) s0 = fmaf(We[f * WeLd + WeE + g], ga[f], s0);
+                }
                 p.ge_out[k * kEF + g] = s;
+                if (p.e0) p.ge0_acc[k * kEF + g] += s0;  // this thread owns edge k: no atomic needed
             }
         }
         __syncthreads();
@@ -371,9 +406,12 @@ __global__ __launch_bounds__(256) void bwd_edge_kernel(const BwdEdgeParams p) {
         const float v = s_acc[t];
         if (v == 0.f) continue;
         float* dst;
-        if (t < kSlotBe) dst = p.gWe + (t / kEF) * 70 + 64 + t % kEF;
+        if (t < kSlotBe) {
+            if (t % 12 >= EI) continue;
+            dst = p.gWe + (t / 12) * WeLd + WeE + t % 12;
+        }
         else if (t < kSlotWn) dst = p.gbe + (t - kSlotBe);
-        else if (t < kSlotBn) dst = p.gWn + ((t - kSlotWn) / kEF) * (kH + kEF) + kH + (t - kSlotWn) % kEF;
+        else if (t < kSlotBn) dst = p.gWn + ((t - kSlotWn) / kEF) * WnLd + HI + (t - kSlotWn) % kEF;
         else if (t < kSlotWc1) dst = p.gbn + (t - kSlotBn);
         else if (t < kSlotBc1) dst = p.gWc1 + (t - kSlotWc1);
         else if (t < kSlotWc2) dst = p.gbc1 + (t - kSlotBc1);
@@ -492,22 +530,36 @@ __global__ void bwd_cls_bn_finalize_kernel(const double* __restrict__ sums, long
     g_gamma[q] += (float)sums[C1 + q];
 }
 
-// d h_{s-1}[i][c] = sum_f W_src[f][c] dP_src[i][f] + W_dst[f][c] dP_dst[i][f] + sum_o W_nx[o][c] dQ[i][o]
+// d hin[i][c] = sum_f W_src[f][c] dP_src[i][f] + W_dst[f][c] dP_dst[i][f] + sum_o W_nx[o][c] dQ[i][o],  c < HI.
+// hin = h_{s-1} (HI = 32), or cat(h0, h_{s-1}) with reattach_initial_nodes (HI = 64): columns 0..31 then belong to the
+// encoder output h0 (accumulated over the steps in g_h0_acc), columns 32..63 to h_{s-1}.
 __global__ __launch_bounds__(256) void bwd_node_kernel(const float* __restrict__ dP, const float* __restrict__ We,
-                                                       const float* __restrict__ Wn, float* __restrict__ g_h_prev, int N) {
+                                                       const float* __restrict__ Wn, float* __restrict__ g_h_prev,
+                                                       float* __restrict__ g_h0_acc, int N, int HI, int WeLd) {
     const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= N * kH) return;
-    const int i = t / kH, c = t - i * kH;
+    if (t >= N * HI) return;
+    const int i = t / HI, c = t - i * HI;
     const float* __restrict__ d = dP + (size_t)i * 44;
     float acc = 0.f;
 #pragma unroll
     for (int f = 0; f < kEF; ++f) {
-        acc = fmaf(We[f * 70 + c], d[f], acc);
-        acc = fmaf(We[f * 70 + kH + c], d[6 + f], acc);
+        acc = fmaf(We[f * WeLd + c], d[f], acc);
+        acc = fmaf(We[f * WeLd + HI + c], d[6 + f], acc);
     }
 #pragma unroll
-    for (int o = 0; o < kH; ++o) acc = fmaf(Wn[o * (kH + kEF) + c], d[12 + o], acc);
-    g_h_prev[t] = acc;
+    for (int o = 0; o < kH; ++o) acc = fmaf(Wn[o * (HI + kEF) + c], d[12 + o], acc);
+    if (HI == kH)
+        g_h_prev[t] = acc;
+    else if (c < kH)
+        g_h0_acc[(size_t)i * kH + c] += acc;  // one thread per element and launch: no atomic needed
+    else
+        g_h_prev[(size_t)i * kH + c - kH] = acc;
+}
+
+// a[t] += b[t]
+__global__ __launch_bounds__(256) void bwd_add_kernel(float* __restrict__ a, const float* __restrict__ b, long long n) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t < n) a[t] += b[t];
 }
 
 // Parameter gradients that are sums of outer products over rows (nodes or edges):

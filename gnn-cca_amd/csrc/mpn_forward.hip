@@ -419,7 +419,7 @@ int gnncca_post_prune_cluster(const int64_t* edge_index, const int64_t* predicti
 // ---- backward ---------------------------------------------------------------------------
 static bool backward_ok(const gnncca_mpn_dims* d) {
     if (classify(d) != kFamilyMfma32x6) return false;
-    if (d->reattach_nodes || d->reattach_edges || d->num_enc_steps < 1) return false;
+    if (d->num_enc_steps < 1) return false;
     if (d->enc_node.n_layers != 2) return false;
     const gnncca_mlp* all[5] = {&d->enc_node, &d->enc_edge, &d->edge_mlp, &d->node_mlp, &d->cls_edge};
     for (int mi = 0; mi < 5; ++mi)
@@ -484,7 +484,7 @@ size_t gnncca_backward_workspace_bytes(const gnncca_mpn_dims* d, int64_t n_nodes
     const size_t N = (size_t)n_nodes, E = (size_t)n_edges, F1 = (size_t)d->enc_node.layers[0].out_dim;
     auto up = [](size_t v) { return (v + 255) / 256 * 256; };
     const size_t L = (size_t)std::max(d->num_enc_steps, 1);
-    return up(N * 4) + up(N * kH * 4) + up(2 * N * kH * 4) + up(L * N * 44 * 4) + 2 * up(N * kH * 4) + 2 * up(E * kEF * 4) + 2 * up(N * F1 * 4) +
+    return up(N * kH * 4) + up(E * kEF * 4) + up(N * 4) + up(N * kH * 4) + up(2 * N * kH * 4) + up(L * N * 44 * 4) + 2 * up(N * kH * 4) + 2 * up(E * kEF * 4) + 2 * up(N * F1 * 4) +
            up(32 * N * F1 * 4) + up(sizeof(double) * 128) + up(sizeof(float) * 128);
 }
 
@@ -563,6 +563,8 @@ int gnncca_mpn_backward_ex(const gnncca_mpn_dims* d, const float* const* params_
     char* base = static_cast<char*>(workspace);
     size_t off = 0;
     auto take = [&](size_t bytes) { char* q = base + off; off += up(bytes); return q; };
+    float* gh0_acc = reinterpret_cast<float*>(take((size_t)N * kH * 4));   // reattach_initial_nodes: d loss / d h0 via the copies
+    float* ge0_acc = reinterpret_cast<float*>(take((size_t)E * kEF * 4));  // reattach_initial_edges: d loss / d e0 via the copies
     int* deg = reinterpret_cast<int*>(take((size_t)N * 4));
     float* Q = reinterpret_cast<float*>(take((size_t)N * kH * 4));
     int* hmax = reinterpret_cast<int*>(take((size_t)2 * N * kH * 4));  // 'max' aggregation only: maxima, then tie counts
@@ -592,6 +594,10 @@ int gnncca_mpn_backward_ex(const gnncca_mpn_dims* d, const float* const* params_
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipMemsetAsync(dP_all, 0, (size_t)std::max(L, 1) * N * 44 * 4, st));
+    const bool re_n = d->reattach_nodes != 0, re_e = d->reattach_edges != 0;
+    const int HI = re_n ? 2 * kH : kH, WeLd = 2 * HI + (re_e ? 2 * kEF : kEF), WnLd = HI + kEF;
+    if (re_n) HIP_TRY(hipMemsetAsync(gh0_acc, 0, (size_t)N * kH * 4, st));
+    if (re_e) HIP_TRY(hipMemsetAsync(ge0_acc, 0, (size_t)E * kEF * 4, st));
     const float* g_h = nullptr;   // d loss / d h_s of the step being processed (null for s = L: its node update is dead)
     const float* ge_in = nullptr; // d loss / d e_s arriving from step s+1
     int out_idx = gnncca_num_outputs(d) - 1;
@@ -600,7 +606,7 @@ int gnncca_mpn_backward_ex(const gnncca_mpn_dims* d, const float* const* params_
         const float* e_cur = saved->e_steps + (size_t)(s - 1) * E * kEF;
         const float* e_prev = s == 1 ? saved->e_enc : saved->e_steps + (size_t)(s - 2) * E * kEF;
         if (g_h) {
-            hipLaunchKernelGGL(bwd_q_kernel, grid1((size_t)N * kH, 256), dim3(256), 0, st, h_prev, Wn, bn, Q, N);
+            hipLaunchKernelGGL(bwd_q_kernel, grid1((size_t)N * kH, 256), dim3(256), 0, st, saved->h_enc, h_prev, Wn, bn, Q, N, HI);
             HIP_TRY(hipGetLastError());
         }
         float* dP = dP_all + (size_t)(s - 1) * N * 44;
@@ -609,15 +615,18 @@ int gnncca_mpn_backward_ex(const gnncca_mpn_dims* d, const float* const* params_
         bp.ei = ei;
         bp.e_cur = e_cur;
         bp.e_prev = e_prev;
+        bp.e0 = re_e ? saved->e_enc : nullptr;
+        bp.ge0_acc = re_e ? ge0_acc : nullptr;
+        bp.HI = HI;
         bp.Q = Q;
         bp.g_h = g_h;
         bp.deg = d->agg == GNNCCA_AGG_MEAN ? deg : nullptr;
         if (g_h && d->agg == GNNCCA_AGG_MAX) {  // which edge attained each node's maximum
             HIP_TRY(hipMemsetAsync(hmax, 0, (size_t)2 * N * kH * 4, st));
             hipLaunchKernelGGL(bwd_max_kernel<false>, grid1((size_t)E, 256), dim3(256), 0, st, ei, e_cur, (const float*)Q, Wn,
-                               (long long)E, hmax, hcnt);
+                               (long long)E, HI, hmax, hcnt);
             hipLaunchKernelGGL(bwd_max_kernel<true>, grid1((size_t)E, 256), dim3(256), 0, st, ei, e_cur, (const float*)Q, Wn,
-                               (long long)E, hmax, hcnt);
+                               (long long)E, HI, hmax, hcnt);
             HIP_TRY(hipGetLastError());
             bp.hmax = hmax;
             bp.hcnt = hcnt;
@@ -663,19 +672,30 @@ int gnncca_mpn_backward_ex(const gnncca_mpn_dims* d, const float* const* params_
         }
         HIP_TRY(hipGetLastError());
         float* g_h_prev = Hb[s & 1];
-        hipLaunchKernelGGL(bwd_node_kernel, grid1((size_t)N * kH, 256), dim3(256), 0, st, (const float*)dP, We, Wn, g_h_prev, N);
+        hipLaunchKernelGGL(bwd_node_kernel, grid1((size_t)N * HI, 256), dim3(256), 0, st, (const float*)dP, We, Wn, g_h_prev, gh0_acc, N,
+                           HI, WeLd);
         HIP_TRY(hipGetLastError());
         // d W_src, d W_dst (columns 0..31, 32..63 of the edge-MLP weight), d W_nx (columns 0..31 of the node-MLP weight)
-        {   // one product dP^T h_prev [44][32], rows routed to the three weight blocks
+        // d W_src, d W_dst (columns [0, HI) and [HI, 2 HI) of the edge-MLP weight), d W_nx (columns [0, HI) of the node-MLP
+        // weight): one product dP^T hin [44][HI], rows routed to the three weight blocks; hin = cat(h0, h_prev) with
+        // reattach_initial_nodes, i.e. two 32-column products
+        for (int part = 0; part < (re_n ? 2 : 1); ++part) {
+            const float* hsrc = (re_n && part == 0) ? saved->h_enc : h_prev;
+            const int coff = part * kH;
             OuterOut oo;
-            oo.ptr[0] = gWe, oo.ptr[1] = gWe + kH, oo.ptr[2] = g_h ? gWn : nullptr;
-            oo.ld[0] = oo.ld[1] = 70, oo.ld[2] = kH + kEF;
+            oo.ptr[0] = gWe + coff, oo.ptr[1] = gWe + HI + coff, oo.ptr[2] = g_h ? gWn + coff : nullptr;
+            oo.ld[0] = oo.ld[1] = WeLd, oo.ld[2] = WnLd;
             oo.row_begin[0] = 0, oo.row_begin[1] = 6, oo.row_begin[2] = 12, oo.row_begin[3] = 44;
-            HIP_TRY(launch_outer_multi(dP, 44, h_prev, kH, oo, nullptr, N, g_h ? 44 : 12, kH, st));
+            HIP_TRY(launch_outer_multi(dP, 44, hsrc, kH, oo, nullptr, N, g_h ? 44 : 12, kH, st));
         }
         g_h = g_h_prev;
         ge_in = Gb[s & 1];
     }
+    // gradients that reached the encoder outputs through the reattached copies
+    if (re_n) hipLaunchKernelGGL(bwd_add_kernel, grid1((size_t)N * kH, 256), dim3(256), 0, st, const_cast<float*>(g_h),
+                                 (const float*)gh0_acc, (long long)N * kH);
+    if (re_e) hipLaunchKernelGGL(bwd_add_kernel, grid1((size_t)E * kEF, 256), dim3(256), 0, st, const_cast<float*>(ge_in),
+                                 (const float*)ge0_acc, (long long)E * kEF);
     // ---- encoders ---------------------------------------------------------------------------------------------------
     hipLaunchKernelGGL(bwd_edge_enc_kernel, dim3(std::min((unsigned)(((size_t)E + 255) / 256), 512u)), dim3(256), 0, st, ge_in,
                        saved->e_enc, edge_attr, A, (long long)E,

@@ -356,7 +356,7 @@ class MOTMPNet(nn.Module):
         if lib.gnncca_backward_supported(C.byref(d)) != nat.OK:
             raise NotImplementedError(
                 "train-mode forward/backward on the HIP path covers the shipped config shapes (BatchNorm nowhere or only "
-                "inside the classifier, no reattach flags, two-layer node encoder); this configuration is "
+                "inside the classifier, two-layer node encoder); this configuration is "
                 "outside it (SURVEY.md 8f row N3)")
         for mod in self.modules():
             if isinstance(mod, nn.Dropout) and mod.p > 0:

@@ -223,8 +223,8 @@ GNNCCA_API int gnncca_post_prune_cluster(const int64_t* edge_index, const int64_
                                          int32_t* labels_out, int32_t* n_clusters_out, gnncca_stream_t stream);
 
 /* ---- backward pass (training through the HIP kernels, train.py:454-494) -----------------
- * Supported (GNNCCA_OK from gnncca_backward_supported): the MFMA family without reattach flags, all three
- * aggregators, two-layer node encoder, L >= 1, BatchNorm nowhere or only between the classifier's two layers -- i.e.
+ * Supported (GNNCCA_OK from gnncca_backward_supported): the MFMA family (both reattach flags, all three
+ * aggregators), two-layer node encoder, L >= 1, BatchNorm nowhere or only between the classifier's two layers -- i.e.
  * both shipped config shapes (config_training.yaml:94-181, config_inference.yaml:76-163).  `saved` holds the latents written by gnncca_mpn_forward's trace taps for the same
  * inputs and weights; `params_dev` / `grads_dev` are DEVICE pointers to the raw parameters / their gradients in the
  * canonical order of gnncca_param_count (row-major, un-split, exactly the nn.Parameter layouts).  grads are

@@ -67,6 +67,10 @@ def main():
     run(MOTMPNet, "terrace32", make_params(**tiny), "tiny64", n, ei, 303, 304, 1.0 / 24)
     run(MOTMPNet, "terrace32_mean", make_params(agg="mean", **tiny), "tiny64", n, ei, 305, 306, 1.0)
     run(MOTMPNet, "terrace32_max", make_params(agg="max", **tiny), "tiny64", n, ei, 311, 312, 1.0)
+    run(MOTMPNet, "terrace32_reatt_n", make_params(reattach_nodes=True, **tiny), "tiny64", n, ei, 313, 314, 1.0 / 24)
+    run(MOTMPNet, "terrace32_reatt_e", make_params(reattach_edges=True, **tiny), "tiny64", n, ei, 315, 316, 1.0 / 24)
+    run(MOTMPNet, "terrace32_reatt_ne_mean", make_params(reattach_nodes=True, reattach_edges=True, agg="mean", **tiny), "tiny64",
+        n, ei, 317, 318, 1.0)
     n, ei = dense_edges(20)
     perm = np.random.default_rng(9).permutation(ei.shape[1])
     run(MOTMPNet, "dense20_shuf", make_params(L=3, n_cls=2, **tiny), "tiny64", n, ei[:, perm], 307, 308, 1.0 / 19)

@@ -103,6 +103,50 @@ def test_sgd_steps_track_the_oracle():
         m(d)  # eval after training: the blob is rebuilt from the updated parameters
 
 
+@pytest.mark.parametrize("agg,re_n,re_e", [("sum", True, True), ("max", True, False), ("mean", False, True)])
+def test_random_graphs_reattach_gradients_vs_oracle(agg, re_n, re_e):
+    """The reattach_initial_nodes / reattach_initial_edges variants (models/mpn.py:283-285) on irregular graphs: randomly
+    initialised weights of the widened shapes, every parameter gradient against torch autograd over the CPU oracle."""
+    from gnn_cca_amd import MOTMPNet
+    from oracle.mpn_oracle import load_case
+    from test_gpu_fuzz import random_graph
+    params, arch, _, _ = load_case(os.path.join(GOLDEN_DIR, "n8_sum.npz"))
+    params = copy.deepcopy(params)
+    params.update(node_agg_fn=agg, reattach_initial_nodes=re_n, reattach_initial_edges=re_e)
+    params["classifier_feats_dict"]["use_batchnorm"] = False
+    torch.manual_seed(11)
+    m = MOTMPNet(copy.deepcopy(params), None, arch)
+    with torch.no_grad():
+        for prm in m.MPNet.node_model.node_mlp.parameters():
+            prm.mul_(0.25 if agg == "sum" else 1.0)
+    sd = {k: v.detach().numpy().copy() for k, v in m.state_dict().items()}
+    m = m.cuda().train()
+    orc = TorchTrainOracle(params, arch, sd)
+    import zlib
+    rng = np.random.default_rng(zlib.crc32(repr((agg, re_n, re_e)).encode()))
+    for it in range(16):
+        kind = ["chunks", "sparse", "frames", "frames"][it % 4]
+        n, ei = random_graph(rng, kind)
+        if it % 4 == 3:
+            ei = ei[:, rng.permutation(ei.shape[1])]  # unsorted rows
+        while ei.shape[1] < 2:
+            n, ei = random_graph(rng, "frames")
+        x = (rng.standard_normal((n, 64)) * 0.5).astype(np.float32)
+        ea = rng.random((ei.shape[1], 4)).astype(np.float32)
+        labels = (rng.random(ei.shape[1]) < 0.3).astype(np.float32)
+        ref_loss, _, ref = orc.loss_and_grads(x, ei, ea, labels)
+        m.zero_grad(set_to_none=True)
+        out = m(Data(torch.from_numpy(x).cuda(), torch.from_numpy(ei).cuda(), torch.from_numpy(ea).cuda()))
+        loss = loss_of(out, torch.from_numpy(labels).cuda())
+        loss.backward()
+        assert abs(float(loss) - ref_loss) <= 1e-5, (it, float(loss), ref_loss)
+        for k, prm in m.named_parameters():
+            r = ref[k].numpy()
+            scale = max(1.0, float(np.abs(r).max()))
+            err = float(np.abs(prm.grad.cpu().numpy() - r).max())
+            assert err <= 3e-5 * scale, (it, n, ei.shape, k, err)
+
+
 @pytest.mark.parametrize("agg", ["sum", "mean", "max"])
 def test_random_graphs_gradients_vs_oracle(agg):
     """Irregular inputs for the backward kernels: hubs whose degree straddles the 64-edge chunks and the 256-edge
