@@ -161,7 +161,8 @@ class MOTMPNet(nn.Module):
         self._enc = dict(encoder_feats_dict)
         self._dims = None          # nat.MpnDims, built lazily (needs the finished module tree)
         self._packed = None        # (key, device blob)
-        self._workspace = None     # grow-only device scratch
+        self._workspace = None     # workspace of the last forward
+        self._workspaces = {}      # (device index, stream) -> grow-only device scratch
         self._weights_dirty = True
         self._param_cache = None
         self._trainable_checked = False
@@ -236,6 +237,7 @@ class MOTMPNet(nn.Module):
         self._weights_dirty = True
         self._param_cache = None
         self._pack_state = None
+        self._workspace, self._workspaces = None, {}
         return super()._apply(fn, *a, **k)
 
     def load_state_dict(self, *a, **k):
@@ -299,9 +301,13 @@ class MOTMPNet(nn.Module):
         return self._packed[1]
 
     def _scratch(self, nbytes, device):
-        ws = self._workspace
-        if ws is None or ws.device != device or ws.numel() < nbytes:
-            ws = self._workspace = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=device)
+        """Grow-only HBM workspace (CSR plan, edge state, node tables) of the CURRENT STREAM: forwards of one module on
+        different streams run concurrently on separate workspaces (the packed weights are shared, read-only)."""
+        key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+        ws = self._workspaces.get(key)
+        if ws is None or ws.numel() < nbytes:
+            ws = self._workspaces[key] = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=device)
+        self._workspace = ws  # the last one used: graph_flags() reads it
         return ws
 
     # -- forward -----------------------------------------------------------------------------------------------

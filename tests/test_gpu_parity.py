@@ -294,3 +294,30 @@ def test_device_repack_follows_parameter_updates():
         assert torch.equal(m._packed[1].cpu(), m2.pack_weights_host())
         assert not torch.equal(before, after)
         assert torch.allclose(after, m2(data)["classified_edges"][-1], atol=0, rtol=0)
+
+
+def test_concurrent_streams_one_module():
+    """One module, three streams, three different graphs in flight at once (a workspace per stream, shared packed
+    weights): every stream's logits equal the ones the same graph produces alone."""
+    params, arch, sd, a = load_case(os.path.join(GOLDEN_DIR, "dense64.npz"))
+    m = build(params, arch, sd)
+    rng = np.random.default_rng(3)
+    datas = []
+    for s in range(3):
+        x = a["x"] + (0.01 * s) * rng.standard_normal(a["x"].shape).astype(np.float32)
+        ea = rng.random(a["edge_attr"].shape).astype(np.float32)
+        datas.append(Data(torch.from_numpy(x).cuda(), torch.from_numpy(a["edge_index"]).cuda(), torch.from_numpy(ea).cuda()))
+    with torch.no_grad():
+        alone = [[t.clone() for t in m(d)["classified_edges"]] for d in datas]
+        torch.cuda.synchronize()
+        streams = [torch.cuda.Stream() for _ in datas]
+        outs = [None] * 3
+        for rep in range(20):  # interleaved issue: the three forwards overlap on the GPU
+            for s, (d, st) in enumerate(zip(datas, streams)):
+                with torch.cuda.stream(st):
+                    outs[s] = m(d)["classified_edges"]
+        torch.cuda.synchronize()
+    assert len(m._workspaces) >= 3
+    for s in range(3):
+        for o, r in zip(outs[s], alone[s]):
+            assert torch.equal(o, r), s
