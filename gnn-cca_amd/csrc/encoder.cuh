@@ -533,5 +533,85 @@ __global__ __launch_bounds__(256) void enc_tail_kernel(const TailParams p) {
 }
 
 
+// ------------------------------------------------------------------------------------------------------------
+// Encoder tail, register-resident form for the shipped shape (previous layer 128 wide, last layer 128 -> 32, no
+// reattach): the same arithmetic as enc_tail_kernel with NO LDS and no barrier.  A wave keeps its share of the two
+// small matrices in VGPRs for all the nodes it processes -- lane (o = l & 31, half = l >> 5) holds W2[f][o] for the 64
+// values f = 2 i + half, lane o < 48 holds the 32 projection weights W_p[c][o] -- and broadcasts the node's
+// activations with v_readlane (SGPR operands) instead of LDS reads: the last layer is 64 x (2 readlane + select + FMA),
+// the projection 32 x (readlane + FMA).  rocprofv3 / s_memtime on the LDS form at N = 256: last layer 1.4 us +
+// projection 0.7 us + LDS staging and two barriers 1.3 us of a 6.6 us wave lifetime; at N = 65 536 it was LDS-bound.
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void enc_tail_fast_kernel(const TailParams p) {
+    constexpr int F = 128;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* __restrict__ blob = p.blob;
+    if (blockIdx.x == gridDim.x - 1) {  // the plan workgroup: fold the per-block findings, repair if needed
+        __shared__ unsigned smem[1024];
+        plan_finish(p.ei, p.E, p.N, p.seg_ptr, p.col32, p.perm, p.cursor, p.flags, p.blockflags, smem);
+        return;
+    }
+    const int nblk = gridDim.x - 1;
+    const int o = lane & 31, half = lane >> 5;
+    // split-K partial sum of one node row: lane (rg = half, rc = o) sums the slabs s = rg, rg + 2, ... of columns 4 rc .. 4 rc + 3
+    auto partial_sum = [&](int node) {
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        if (node < p.N) {
+            const float* __restrict__ src = p.part + (size_t)node * F + 4 * o;
+            const size_t sstride = (size_t)p.N * F;
+#pragma unroll 8
+            for (int s = half; s < p.ks; s += 2) a += *reinterpret_cast<const f32x4*>(src + s * sstride);
+        }
+        return a;
+    };
+    f32x4 pre = partial_sum(blockIdx.x * 4 + wave);
+    // the wave's share of the weights, once
+    float w2[64], wp[kH];
+#pragma unroll
+    for (int i = 0; i < 64; ++i) w2[i] = blob[p.off_lastWT + (2 * i + half) * kH + o];
+    const int po = min(lane, kProjOut - 1);
+#pragma unroll
+    for (int c = 0; c < kH; ++c) wp[c] = blob[p.off_projwT + c * kProjOut + po];
+    const f32x4 b1 = *reinterpret_cast<const f32x4*>(blob + p.off_prev_b + 4 * o);
+    const float last_b = blob[p.off_last_b + o];
+    const float proj_b = blob[p.off_projb + po];
+    for (int grp = blockIdx.x; grp * 4 < p.N; grp += nblk) {
+        const int node = grp * 4 + wave;
+        f32x4 row = pre;
+        pre = partial_sum((grp + nblk) * 4 + wave);  // next node of this wave, in flight during the arithmetic below
+        if (node >= p.N) continue;
+        // both halves -> the full split-K sum, + bias, ReLU: lane l holds columns 4 (l & 31) .. + 3 of the 128-wide row
+        // (same association as enc_tail_kernel, so that both tails agree bit for bit: (bias + even slabs) + odd slabs)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float other = __shfl_xor(row[u], 32);
+            const float v = (b1[u] + (half ? other : row[u])) + (half ? row[u] : other);
+            row[u] = p.relu_prev ? fmaxf(v, 0.f) : v;
+        }
+        // last layer: column f of the row sits in lane f >> 2, component f & 3; half h takes the columns f = 2 i + h into
+        // four accumulators by i & 3 (enc_tail_kernel's order)
+        float acc4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 64; ++i) {
+            const float xa = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(row[(2 * i) & 3]), (2 * i) >> 2));
+            const float xb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(row[(2 * i + 1) & 3]), (2 * i + 1) >> 2));
+            acc4[i & 3] = fmaf(half ? xb : xa, w2[i], acc4[i & 3]);
+        }
+        float acc = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
+        acc += __shfl_xor(acc, 32);
+        const float hv = fmaxf(acc + last_b, 0.f);  // lanes o and o + 32 both hold h[o]
+        if (lane < kH) p.h0[(size_t)node * kH + lane] = hv;
+        // step-1 projections: slot o < 48
+        float pr = proj_b;
+#pragma unroll
+        for (int c = 0; c < kH; ++c) pr = fmaf(wp[c], __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hv), c)), pr);
+        if (lane < kPdStride)
+            p.pd_out[(size_t)node * kPdStride + lane] = pr;
+        else if (lane < kProjOut)
+            p.psq_out[(size_t)node * kPsQStride + lane - kPdStride] = pr;
+    }
+}
+
+
 
 }  // namespace gnncca

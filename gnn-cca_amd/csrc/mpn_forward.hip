@@ -208,7 +208,14 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
         tp.blockflags = blockflags;
         tp.E = E;
         const unsigned blocks = (unsigned)std::min<size_t>(((size_t)N + 3) / 4, 2048) + 1;  // + plan-repair workgroup
-        GNNCCA_LAUNCH(enc_tail_kernel, dim3(blocks), dim3(256), std::max<size_t>(lds, 4096), st, tp);
+        // register-resident tail in the latency-bound regime only: on big batches it is VALU-bound (readlane traffic) and
+        // measured 15 % slower than the LDS form (72 vs 62 us at N = 65 536)
+        const bool tail_fast = N < 4096 && tp.F == 128 && tp.has_last && !tp.reatt_n && tp.trace_h == nullptr && tp.vec_reduce &&
+                               (reinterpret_cast<uintptr_t>(part) & 15) == 0;
+        if (tail_fast)
+            GNNCCA_LAUNCH(enc_tail_fast_kernel, dim3(blocks), dim3(256), 0, st, tp);
+        else
+            GNNCCA_LAUNCH(enc_tail_kernel, dim3(blocks), dim3(256), std::max<size_t>(lds, 4096), st, tp);
         HIP_TRY(hipGetLastError());
         PROF_MARK(GNNCCA_K_ENC_TAIL);
     }
