@@ -62,6 +62,20 @@ class MLPGraphIndependent(nn.Module):
             self.edge_mlp = MLP(edge_in_dim, list(edge_fc_dims) + [edge_out_dim], dropout_p, use_batchnorm)
 
 
+def _raw_stream(device):
+    """hipStream_t of torch's current stream on `device` as an int (the fast path of torch.cuda.current_stream(...)
+    .cuda_stream: no Python Stream object; it is called once per forward on a path whose whole host cost is ~20 us)."""
+    return torch._C._cuda_getCurrentRawStream(device.index)
+
+
+class _HotState:
+    """Per-forward mutable state kept OFF nn.Module.__setattr__ (which costs ~2 us per assignment)."""
+    __slots__ = ("workspace", "workspaces", "last_workspace_bytes")
+
+    def __init__(self):
+        self.workspace, self.workspaces, self.last_workspace_bytes = None, {}, 0
+
+
 class _MPNTrainFunction(torch.autograd.Function):
     """Autograd bridge for train mode: forward = the traced HIP forward (it saves the latents the
     backward needs), backward = gnncca_mpn_backward.  Gradients flow to the module's parameters only (the reference
@@ -84,7 +98,7 @@ class _MPNTrainFunction(torch.autograd.Function):
                 with torch.cuda.device(x.device):
                     st = lib.gnncca_classifier_train(C.byref(d), pp, len(params), trace['e_steps'].data_ptr(), e,
                                                      scratch.data_ptr(), bn_stat.data_ptr(), out.data_ptr(),
-                                                     torch.cuda.current_stream(x.device).cuda_stream)
+                                                     _raw_stream(x.device))
                 nat.check(st, "gnncca_classifier_train")
                 bn.num_batches_tracked += n_out  # one BatchNorm call per classified step (models/mpn.py:292)
         ctx.module = module
@@ -118,7 +132,7 @@ class _MPNTrainFunction(torch.autograd.Function):
             st = lib.gnncca_mpn_backward_ex(C.byref(d), pp, len(params), x.data_ptr(), edge_index.data_ptr(),
                                             edge_attr.data_ptr(), n, e, C.byref(saved),
                                             bn_stat.data_ptr() if ctx.has_bn else None, g.data_ptr(), gp, ws.data_ptr(),
-                                            ws.numel(), nat.BWD_GRADS_ZEROED, torch.cuda.current_stream(dev).cuda_stream)
+                                            ws.numel(), nat.BWD_GRADS_ZEROED, _raw_stream(dev))
         nat.check(st, "gnncca_mpn_backward")
         return (None, None, None, None, *[gr if p.requires_grad else None for gr, p in zip(grads, params)])
 
@@ -161,13 +175,11 @@ class MOTMPNet(nn.Module):
         self._enc = dict(encoder_feats_dict)
         self._dims = None          # nat.MpnDims, built lazily (needs the finished module tree)
         self._packed = None        # (key, device blob)
-        self._workspace = None     # workspace of the last forward
-        self._workspaces = {}      # (device index, stream) -> grow-only device scratch
+        self._hot = _HotState()    # workspace of the last forward; (device index, stream) -> grow-only device scratch
         self._weights_dirty = True
         self._param_cache = None
         self._trainable_checked = False
         self._pack_state = None    # (device copy of the pack program, persistent blob) for the on-GPU repack
-        self.last_workspace_bytes = 0
         # 'fp32' (default: bit-faithful to the reference within summation order) or 'bf16': the edge latents are kept
         # as bf16 in HBM between steps (GNNCCA_OPT_EDGE_STATE_BF16); arithmetic stays fp32
         self.edge_state_dtype = 'fp32'
@@ -237,7 +249,7 @@ class MOTMPNet(nn.Module):
         self._weights_dirty = True
         self._param_cache = None
         self._pack_state = None
-        self._workspace, self._workspaces = None, {}
+        self._hot = _HotState()
         return super()._apply(fn, *a, **k)
 
     def load_state_dict(self, *a, **k):
@@ -287,7 +299,7 @@ class MOTMPNet(nn.Module):
         ptrs = (C.c_void_p * len(params))(*[t.data_ptr() for t in params])
         with torch.cuda.device(device):
             status = lib.gnncca_pack_weights_device(C.byref(d), ptrs, len(params), prog.data_ptr(), blob.data_ptr(), blob.numel(),
-                                                    torch.cuda.current_stream(device).cuda_stream)
+                                                    _raw_stream(device))
         nat.check(status, "gnncca_pack_weights_device")
         return blob
 
@@ -303,12 +315,22 @@ class MOTMPNet(nn.Module):
     def _scratch(self, nbytes, device):
         """Grow-only HBM workspace (CSR plan, edge state, node tables) of the CURRENT STREAM: forwards of one module on
         different streams run concurrently on separate workspaces (the packed weights are shared, read-only)."""
-        key = (device.index, torch.cuda.current_stream(device).cuda_stream)
-        ws = self._workspaces.get(key)
+        hot = self._hot
+        key = (device.index, _raw_stream(device))
+        ws = hot.workspaces.get(key)
         if ws is None or ws.numel() < nbytes:
-            ws = self._workspaces[key] = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=device)
-        self._workspace = ws  # the last one used: graph_flags() reads it
+            ws = hot.workspaces[key] = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=device)
+        hot.workspace = ws  # the last one used: graph_flags() reads it
+        hot.last_workspace_bytes = nbytes
         return ws
+
+    @property
+    def last_workspace_bytes(self):
+        return self._hot.last_workspace_bytes
+
+    @property
+    def _workspaces(self):
+        return self._hot.workspaces
 
     # -- forward -----------------------------------------------------------------------------------------------
     def _prepare(self, x, edge_index, edge_attr):
@@ -337,7 +359,6 @@ class MOTMPNet(nn.Module):
             if ws_bytes == 0:
                 nat.check(lib.gnncca_supported(C.byref(d)), "MOTMPNet configuration")
             ws = self._scratch(ws_bytes, dev)
-            self.last_workspace_bytes = ws_bytes
         return lib, d, dev, x, edge_index, edge_attr, n, e, blob, logits, ws
 
     def forward(self, data, trace=None):
@@ -402,11 +423,13 @@ class MOTMPNet(nn.Module):
             trace['e_steps'] = torch.empty((L, e, d.edge_dim), dtype=torch.float32, device=dev)
             tr = C.byref(nat.Trace(trace['h_enc'].data_ptr(), trace['e_enc'].data_ptr(),
                                    trace['h_steps'].data_ptr(), trace['e_steps'].data_ptr()))
-        with torch.cuda.device(dev):
-            stream = torch.cuda.current_stream(dev).cuda_stream
-            st = lib.gnncca_mpn_forward_ex(C.byref(d), blob.data_ptr(), x.data_ptr(), edge_index.data_ptr(),
-                                           edge_attr.data_ptr(), n, e, ws.data_ptr(), ws.numel(), logits.data_ptr(), tr,
-                                           self._options(), stream)
+        args = (C.byref(d), blob.data_ptr(), x.data_ptr(), edge_index.data_ptr(), edge_attr.data_ptr(), n, e, ws.data_ptr(),
+                ws.numel(), logits.data_ptr(), tr, self._options(), _raw_stream(dev))
+        if torch._C._cuda_getDevice() == dev.index:   # the usual case: no device guard to enter and leave
+            st = lib.gnncca_mpn_forward_ex(*args)
+        else:
+            with torch.cuda.device(dev):
+                st = lib.gnncca_mpn_forward_ex(*args)
         nat.check(st, "gnncca_mpn_forward")
         return logits
 
@@ -419,7 +442,7 @@ class MOTMPNet(nn.Module):
         prof = nat.Profile()
         prof.options = self._options()
         with torch.cuda.device(dev):
-            stream = torch.cuda.current_stream(dev).cuda_stream
+            stream = _raw_stream(dev)
             st = lib.gnncca_mpn_forward_profiled(C.byref(d), blob.data_ptr(), x.data_ptr(), edge_index.data_ptr(),
                                                  edge_attr.data_ptr(), n, e, ws.data_ptr(), ws.numel(),
                                                  logits.data_ptr(), stream, C.byref(prof))
@@ -429,10 +452,10 @@ class MOTMPNet(nn.Module):
 
     def graph_flags(self):
         """Synchronises and returns the flag word of the last forward (bit 0: unsorted rows, bit 1: bad index)."""
-        if self._workspace is None:
+        ws = self._hot.workspace
+        if ws is None:
             return 0
         out = C.c_uint32(0)
-        dev = self._workspace.device
-        nat.check(nat.lib().gnncca_read_graph_flags(self._workspace.data_ptr(), C.byref(out),
-                                                    torch.cuda.current_stream(dev).cuda_stream), "read_graph_flags")
+        dev = ws.device
+        nat.check(nat.lib().gnncca_read_graph_flags(ws.data_ptr(), C.byref(out), _raw_stream(dev)), "read_graph_flags")
         return int(out.value)
