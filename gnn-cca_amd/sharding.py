@@ -5,7 +5,7 @@ weights are shared and read-only in eval mode, so the path shards by GRAPH with 
 
   * rank r of W owns graphs [lo, hi) of the batch (`shard_range`), builds its own disjoint union with local node
     numbering (`union_graphs`) and runs the ordinary single-GPU forward on it;
-  * the only collective is a one-time broadcast of the packed weight blob (about 1.07 MB fp32) from rank 0
+  * the only collective is a one-time broadcast of the packed weight blob (2.66 MB for the shipped configs) from rank 0
     over RCCL/xGMI (`broadcast_packed_weights`; backend "nccl" is RCCL on ROCm, "gloo" in the CPU tests).
 
 The reference has no distributed code at all (single GPU, main_training.py:7).
