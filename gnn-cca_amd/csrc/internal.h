@@ -10,7 +10,8 @@ namespace gnncca {
 
 extern thread_local int g_last_hip_error;  // hipError_t of the last failed HIP call on this thread
 
-constexpr uint32_t kBlobMagic = 0x4D504E31u;  // "MPN1"
+constexpr uint32_t kBlobMagic = 0x4D504E33u;  // "MPN3": bumped with every change of the blob layout (a blob is only
+                                              // valid for the library build that packed it; load_packed_blob checks)
 constexpr int kH = 32;        // node latent width the MFMA step kernel is built for (node_out_dim)
 constexpr int kEF = 6;        // edge latent width (edge_out_dim): 3 k-steps of v_mfma_f32_32x32x2_f32
 constexpr int kProjOut = 48;  // per-node projection slots: [0,6) P_dst, [8,14) P_src+b_e, [16,48) Q+b_n

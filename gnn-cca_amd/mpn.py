@@ -277,6 +277,33 @@ class MOTMPNet(nn.Module):
         self._packed = (self._version_key(), blob_dev)
         self._weights_dirty = False
 
+    def load_packed_blob(self, blob):
+        """Install a blob that was packed EARLIER (e.g. written by `python -m gnn_cca_amd.checkpoint convert`): a host
+        uint8 tensor / bytes / file path.  The header is validated against this build's layout generation and this
+        module's configuration before anything reaches the GPU -- a blob is only valid for the library build and
+        GRAPH_NET_PARAMS that produced it."""
+        import struct
+        if isinstance(blob, str):
+            with open(blob, "rb") as f:
+                blob = f.read()
+        if isinstance(blob, (bytes, bytearray)):
+            blob = torch.frombuffer(bytearray(blob), dtype=torch.uint8)
+        blob = blob.detach().to("cpu", torch.uint8).contiguous()
+        lib, d = nat.lib(), self.native_dims()
+        expected = lib.gnncca_packed_weights_bytes(C.byref(d))
+        if blob.numel() < 16:
+            raise RuntimeError("packed blob: too short to hold a header")
+        magic, abi, _family, total_floats = struct.unpack("<4I", blob[:16].numpy().tobytes())
+        ref_magic, = struct.unpack("<I", self.pack_weights_host()[:4].numpy().tobytes())
+        if magic != ref_magic or abi != nat.ABI_VERSION:
+            raise RuntimeError("packed blob was written by a different build of libgnncca_mpn (layout generation "
+                               f"{magic:#x}, expected {ref_magic:#x}): re-run the converter")
+        if blob.numel() != expected or total_floats * 4 != expected:
+            raise RuntimeError(f"packed blob is {blob.numel()} bytes; this configuration needs {expected}")
+        dev = next(self.parameters()).device
+        self.set_packed_weights(blob.to(dev))
+        return self
+
     def _version_key(self):
         return sum(t._version for t in self.native_param_tensors())
 

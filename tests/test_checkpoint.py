@@ -57,3 +57,35 @@ def test_raw_state_dict_and_nothing_matching():
         warnings.simplefilter("always")
         _, rep = load_pretrained_weights(b, {"nope": torch.zeros(1)}, verbose=False)
     assert not rep.matched and len(w) == 1
+
+
+def test_packed_blob_header_is_validated_on_load():
+    """A blob persisted by the converter is only valid for the build and configuration that packed it."""
+    import copy
+
+    import numpy as np
+    import pytest
+    import torch
+
+    from conftest import GOLDEN_DIR
+    from gnn_cca_amd import MOTMPNet
+    from oracle.mpn_oracle import load_case
+    import os
+    params, arch, sd, _ = load_case(os.path.join(GOLDEN_DIR, "dense64.npz"))
+    m = MOTMPNet(copy.deepcopy(params), None, arch)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    good = m.pack_weights_host()
+    m.load_packed_blob(good.numpy().tobytes())          # accepted (CPU module: installs a host copy)
+    assert m._packed is not None and torch.equal(m._packed[1].cpu(), good)
+    stale = good.clone()
+    stale[0] ^= 0x01                                     # another layout generation
+    with pytest.raises(RuntimeError, match="different build"):
+        m.load_packed_blob(stale)
+    with pytest.raises(RuntimeError, match="bytes"):
+        m.load_packed_blob(good[:-4])
+    p2 = copy.deepcopy(params)
+    p2["num_enc_steps"] = 2
+    other, _, _, _ = load_case(os.path.join(GOLDEN_DIR, "n8_sum.npz"))
+    m2 = MOTMPNet(copy.deepcopy(other), None, "tiny64")
+    with pytest.raises(RuntimeError):
+        m2.load_packed_blob(good)                        # a different GRAPH_NET_PARAMS: different size
