@@ -70,10 +70,11 @@ def _raw_stream(device):
 
 class _HotState:
     """Per-forward mutable state kept OFF nn.Module.__setattr__ (which costs ~2 us per assignment)."""
-    __slots__ = ("workspace", "workspaces", "last_workspace_bytes")
+    __slots__ = ("workspace", "workspaces", "last_workspace_bytes", "n_out", "ws_shape", "ws_bytes")
 
     def __init__(self):
         self.workspace, self.workspaces, self.last_workspace_bytes = None, {}, 0
+        self.n_out, self.ws_shape, self.ws_bytes = -1, None, 0
 
 
 class _MPNTrainFunction(torch.autograd.Function):
@@ -378,11 +379,15 @@ class MOTMPNet(nn.Module):
             raise RuntimeError(f"shape mismatch: x {tuple(x.shape)}, edge_index {tuple(edge_index.shape)}, "
                                f"edge_attr {tuple(edge_attr.shape)} for node_in={d.node_in}, edge_in={d.edge_in}")
         blob = self._packed_weights(dev)
-        n_out = lib.gnncca_num_outputs(C.byref(d))
-        logits = torch.empty((n_out, e, 1), dtype=torch.float32, device=dev)
+        hot = self._hot
+        if hot.n_out < 0:
+            hot.n_out = lib.gnncca_num_outputs(C.byref(d))
+        logits = torch.empty((hot.n_out, e, 1), dtype=torch.float32, device=dev)
         ws = None
         if n > 0 and e > 0:
-            ws_bytes = lib.gnncca_workspace_bytes(C.byref(d), n, e)
+            if hot.ws_shape != (n, e):  # pure function of (dims, N, E): skip the library call while the shape repeats
+                hot.ws_shape, hot.ws_bytes = (n, e), lib.gnncca_workspace_bytes(C.byref(d), n, e)
+            ws_bytes = hot.ws_bytes
             if ws_bytes == 0:
                 nat.check(lib.gnncca_supported(C.byref(d)), "MOTMPNet configuration")
             ws = self._scratch(ws_bytes, dev)
