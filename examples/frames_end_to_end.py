@@ -43,7 +43,7 @@ def main():
         with torch.no_grad():
             out = model(batch)
         probs, preds = threshold(out["classified_edges"][-1])
-        post = prune_and_cluster(batch.edge_index, preds, n)
+        post = prune_and_cluster(batch.edge_index, preds, n, batch.node_ptr_dev, batch.edge_ptr_dev)
         return batch, probs, post
 
     # random weights put every logit on one side of 0; centre them so that the pruning / clustering steps have work

@@ -78,6 +78,9 @@ _SIGNATURES = {
     "gnncca_post_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64]),
     "gnncca_post_prune_cluster": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_size_t,
                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gnncca_post_prune_cluster_frames": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32,
+                                                   C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                   C.c_void_p, C.c_void_p]),
     "gnncca_backward_supported": (C.c_int, [C.POINTER(MpnDims)]),
     "gnncca_backward_workspace_bytes": (C.c_size_t, [C.POINTER(MpnDims), C.c_int64, C.c_int64]),
     "gnncca_mpn_backward": (C.c_int, [C.POINTER(MpnDims), C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -367,7 +367,18 @@ int gnncca_post_threshold(const float* logits, int64_t n_edges, float* probs_out
 int gnncca_post_prune_cluster(const int64_t* edge_index, const int64_t* predictions, int64_t n_nodes, int64_t n_edges,
                               void* workspace, size_t workspace_bytes, int64_t* pruned_out, int32_t* flow_out,
                               int32_t* flow_in, int32_t* labels_out, int32_t* n_clusters_out, gnncca_stream_t stream) {
-    if (n_nodes < 0 || n_edges < 0) return GNNCCA_ERR_INVALID_ARG;
+    return gnncca_post_prune_cluster_frames(edge_index, predictions, n_nodes, n_edges, nullptr, nullptr, 0, workspace,
+                                            workspace_bytes, pruned_out, flow_out, flow_in, labels_out, n_clusters_out, stream);
+}
+
+int gnncca_post_prune_cluster_frames(const int64_t* edge_index, const int64_t* predictions, int64_t n_nodes, int64_t n_edges,
+                                     const int32_t* node_ptr_dev, const int32_t* edge_ptr_dev, int32_t n_frames,
+                                     void* workspace, size_t workspace_bytes, int64_t* pruned_out, int32_t* flow_out,
+                                     int32_t* flow_in, int32_t* labels_out, int32_t* n_clusters_out,
+                                     gnncca_stream_t stream) {
+    if (n_nodes < 0 || n_edges < 0 || n_frames < 0) return GNNCCA_ERR_INVALID_ARG;
+    if ((node_ptr_dev == nullptr) != (edge_ptr_dev == nullptr) || (node_ptr_dev != nullptr && n_frames == 0))
+        return GNNCCA_ERR_INVALID_ARG;
     if (n_nodes >= (1ll << 31) - 64 || n_edges >= (1ll << 31) - 64) return GNNCCA_ERR_UNSUPPORTED;
     if (n_nodes == 0) return GNNCCA_OK;
     if (!workspace || !flow_out || !flow_in || !labels_out || !n_clusters_out) return GNNCCA_ERR_INVALID_ARG;
@@ -416,8 +427,9 @@ int gnncca_post_prune_cluster(const int64_t* edge_index, const int64_t* predicti
                            flow_out, flow_in);
         HIP_TRY(hipGetLastError());
     }
-    hipLaunchKernelGGL(post_cc_kernel, dim3(1), dim3(1024), 0, st, ei, (const long long*)pruned, (long long)E, N, labels_out,
-                       n_clusters_out);
+    HIP_TRY(hipMemsetAsync(n_clusters_out, 0, sizeof(int32_t), st));
+    hipLaunchKernelGGL(post_cc_kernel, dim3(node_ptr_dev ? (unsigned)n_frames : 1u), dim3(1024), 0, st, ei,
+                       (const long long*)pruned, (long long)E, N, node_ptr_dev, edge_ptr_dev, labels_out, n_clusters_out);
     HIP_TRY(hipGetLastError());
     return GNNCCA_OK;
 }

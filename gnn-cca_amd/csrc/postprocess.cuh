@@ -53,22 +53,30 @@ __global__ __launch_bounds__(256) void post_flow_kernel(const long long* __restr
     atomicAdd(&flow_in[j], 1);
 }
 
-// Connected components of the active edges by hooking + pointer jumping inside ONE workgroup (frame graphs are small;
-// a batch is processed in one launch).  labels[v] = smallest node id of v's component.
+// Connected components of the active edges by hooking + pointer jumping inside one workgroup.  labels[v] = smallest
+// node id of v's component.  Without frame ranges the whole batch is one workgroup's job; with them (node_ptr /
+// edge_ptr of a disjoint union of frame graphs, edges of a frame contiguous: Batch.from_data_list's layout) every frame
+// gets its own workgroup -- components never cross frames -- and the batch is processed frames-wide in parallel.
+// *n_clusters must be zero on entry.
 __global__ __launch_bounds__(1024) void post_cc_kernel(const long long* __restrict__ ei, const long long* __restrict__ pred,
-                                                       long long E, int N, int* labels, int* n_clusters) {
+                                                       long long E_all, int N_all, const int* __restrict__ node_ptr,
+                                                       const int* __restrict__ edge_ptr, int* labels, int* n_clusters) {
     __shared__ int s_changed;
     const int tid = threadIdx.x;
+    const int v0 = node_ptr ? node_ptr[blockIdx.x] : 0, v1 = node_ptr ? node_ptr[blockIdx.x + 1] : N_all;
+    const long long k0 = edge_ptr ? edge_ptr[blockIdx.x] : 0, k1 = edge_ptr ? edge_ptr[blockIdx.x + 1] : E_all;
+    const long long E = E_all;
+    const int N = v1 - v0;  // bound on the number of sweeps
     auto ld = [&](int v) { return __hip_atomic_load(&labels[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-    for (int v = tid; v < N; v += 1024) __hip_atomic_store(&labels[v], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int v = v0 + tid; v < v1; v += 1024) __hip_atomic_store(&labels[v], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     for (int round = 0; round <= N; ++round) {  // terminates when a sweep hooks nothing; N bounds it
         if (tid == 0) s_changed = 0;
         __syncthreads();
-        for (long long k = tid; k < E; k += 1024) {
+        for (long long k = k0 + tid; k < k1; k += 1024) {
             if (pred[k] != 1) continue;
             const long long a = ei[k], b = ei[E + k];
-            if (a < 0 || a >= N || b < 0 || b >= N) continue;
+            if (a < v0 || a >= v1 || b < v0 || b >= v1) continue;  // out of range, or an edge that leaves its frame: ignored
             int ra = (int)a, rb = (int)b;
             for (int p = ld(ra); p != ra; p = ld(ra)) ra = p;  // find roots
             for (int p = ld(rb); p != rb; p = ld(rb)) rb = p;
@@ -78,7 +86,7 @@ __global__ __launch_bounds__(1024) void post_cc_kernel(const long long* __restri
             }
         }
         __syncthreads();
-        for (int v = tid; v < N; v += 1024) {                  // pointer jumping
+        for (int v = v0 + tid; v < v1; v += 1024) {             // pointer jumping
             int r = v;
             for (int p = ld(r); p != r; p = ld(r)) r = p;
             __hip_atomic_store(&labels[v], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -87,10 +95,9 @@ __global__ __launch_bounds__(1024) void post_cc_kernel(const long long* __restri
         if (!s_changed) break;
         __syncthreads();
     }
-    if (tid == 0) *n_clusters = 0;
-    __syncthreads();
-    for (int v = tid; v < N; v += 1024)
-        if (ld(v) == v) atomicAdd(n_clusters, 1);
+    int mine = 0;
+    for (int v = v0 + tid; v < v1; v += 1024) mine += ld(v) == v;
+    if (mine) atomicAdd(n_clusters, mine);
 }
 
 }  // namespace gnncca

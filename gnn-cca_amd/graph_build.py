@@ -90,8 +90,9 @@ def build_graph_batch(xw, yw, ids, id_cam, graph_sizes, max_dist, node_embeds, r
     g = len(plan.graph_ptr) - 1
     ids64 = np.ascontiguousarray(ids, dtype=np.int64)
     f64 = np.concatenate([np.asarray(xw, np.float64), np.asarray(yw, np.float64), np.asarray(max_dist, np.float64)])
+    edge_ptr_g = plan.edge_ptr[plan.graph_ptr]  # edges are emitted graph by graph: graph g owns [edge_ptr_g[g], edge_ptr_g[g+1])
     i32 = np.concatenate([dense_ids.astype(np.int32), np.asarray(id_cam).astype(np.int32), plan.graph_of, plan.graph_ptr,
-                          plan.src_order, plan.edge_ptr])
+                          plan.src_order, plan.edge_ptr, edge_ptr_g.astype(np.int32)])
     host = np.concatenate([f64.view(np.uint8), ids64.view(np.uint8), i32.view(np.uint8)])
     staged = torch.from_numpy(host).to(dev)
     fr = nat.Frames()
@@ -112,8 +113,11 @@ def build_graph_batch(xw, yw, ids, id_cam, graph_sizes, max_dist, node_embeds, r
                                               torch.cuda.current_stream(dev).cuda_stream)
         nat.check(st, "gnncca_build_edges")
     # per-graph edge ranges: edges are emitted graph by graph, so graph g owns edge_ptr[graph_ptr[g]] .. edge_ptr[graph_ptr[g+1]]
-    edge_ptr_g = plan.edge_ptr[plan.graph_ptr].tolist()
-    batch = GraphBatch(node_embeds, edge_index, edge_attr, edge_ptr_g, plan.graph_ptr.tolist())
+    batch = GraphBatch(node_embeds, edge_index, edge_attr, edge_ptr_g.tolist(), plan.graph_ptr.tolist())
+    # device copies of the frame ranges (int32 [G + 1]) for the per-frame post-processing (postprocess.prune_and_cluster)
+    i32_dev = staged[y_off + 8 * n:].view(torch.int32)
+    batch.node_ptr_dev = i32_dev[3 * n:3 * n + g + 1]
+    batch.edge_ptr_dev = i32_dev[5 * n + g + 2:5 * n + 2 * g + 3]
     batch.edge_labels = edge_labels
     batch.y = staged[y_off:y_off + 8 * n].view(torch.int64)
     batch.reid_embeds = reid_embeds

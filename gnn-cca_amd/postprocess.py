@@ -27,9 +27,13 @@ def threshold(logits):
     return probs, preds
 
 
-def prune_and_cluster(edge_index, predictions, n_nodes):
+def prune_and_cluster(edge_index, predictions, n_nodes, node_ptr=None, edge_ptr=None):
     """-> dict(pruned int64 [E], flow_out / flow_in int32 [N], labels int32 [N] (smallest node id of the component),
-    n_clusters int32 [1] on the device)."""
+    n_clusters int32 [1] on the device).
+
+    `node_ptr` / `edge_ptr` (optional, both or neither): the frame ranges of a batch laid out like
+    Batch.from_data_list -- sequences of G + 1 ints or int32 device tensors (GraphBatch.node_ptr / .edge_ptr, or the
+    device copies build_graph_batch keeps).  With them every frame is clustered by its own workgroup."""
     if not (edge_index.is_cuda and predictions.is_cuda):
         raise RuntimeError("gnn_cca_amd.postprocess runs on MI355X only (no CPU fallback)")
     dev = edge_index.device
@@ -43,10 +47,25 @@ def prune_and_cluster(edge_index, predictions, n_nodes):
            "flow_in": torch.empty(n_nodes, dtype=torch.int32, device=dev),
            "labels": torch.empty(n_nodes, dtype=torch.int32, device=dev),
            "n_clusters": torch.zeros(1, dtype=torch.int32, device=dev)}
+    if (node_ptr is None) != (edge_ptr is None):
+        raise ValueError("node_ptr and edge_ptr go together")
+    n_frames, np_dev, ep_dev = 0, None, None
+    if node_ptr is not None:
+        def as_dev(v):
+            if torch.is_tensor(v):
+                return v.to(device=dev, dtype=torch.int32).contiguous()
+            return torch.tensor(list(v), dtype=torch.int32).to(dev)
+        np_dev, ep_dev = as_dev(node_ptr), as_dev(edge_ptr)
+        n_frames = np_dev.numel() - 1
+        if ep_dev.numel() != n_frames + 1 or n_frames < 1:
+            raise ValueError("node_ptr / edge_ptr must both have G + 1 entries")
     with torch.cuda.device(dev):
-        st = lib.gnncca_post_prune_cluster(ei.data_ptr(), pred.data_ptr(), n_nodes, e, ws.data_ptr(), ws.numel(),
-                                           out["pruned"].data_ptr(), out["flow_out"].data_ptr(), out["flow_in"].data_ptr(),
-                                           out["labels"].data_ptr(), out["n_clusters"].data_ptr(), _stream(dev))
+        st = lib.gnncca_post_prune_cluster_frames(ei.data_ptr(), pred.data_ptr(), n_nodes, e,
+                                                  np_dev.data_ptr() if np_dev is not None else None,
+                                                  ep_dev.data_ptr() if ep_dev is not None else None, n_frames,
+                                                  ws.data_ptr(), ws.numel(), out["pruned"].data_ptr(),
+                                                  out["flow_out"].data_ptr(), out["flow_in"].data_ptr(),
+                                                  out["labels"].data_ptr(), out["n_clusters"].data_ptr(), _stream(dev))
     nat.check(st, "gnncca_post_prune_cluster")
-    out["_workspace"] = ws
+    out["_workspace"] = (ws, np_dev, ep_dev)
     return out

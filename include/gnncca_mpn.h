@@ -221,6 +221,15 @@ GNNCCA_API int gnncca_post_prune_cluster(const int64_t* edge_index, const int64_
                                          int64_t n_edges, void* workspace, size_t workspace_bytes,
                                          int64_t* pruned_out, int32_t* flow_out, int32_t* flow_in,
                                          int32_t* labels_out, int32_t* n_clusters_out, gnncca_stream_t stream);
+/* The same over a batch of frame graphs laid out as Batch.from_data_list lays them out (inference.py:279): frame g owns
+ * nodes [node_ptr[g], node_ptr[g+1]) and the contiguous edges [edge_ptr[g], edge_ptr[g+1]) (int32 arrays of
+ * n_frames + 1 entries in DEVICE memory).  Components never cross frames, so each frame's clustering runs in its own
+ * workgroup, frames-wide in parallel. */
+GNNCCA_API int gnncca_post_prune_cluster_frames(const int64_t* edge_index, const int64_t* predictions, int64_t n_nodes,
+                                                int64_t n_edges, const int32_t* node_ptr_dev, const int32_t* edge_ptr_dev,
+                                                int32_t n_frames, void* workspace, size_t workspace_bytes,
+                                                int64_t* pruned_out, int32_t* flow_out, int32_t* flow_in,
+                                                int32_t* labels_out, int32_t* n_clusters_out, gnncca_stream_t stream);
 
 /* ---- backward pass (training through the HIP kernels, train.py:454-494) -----------------
  * Supported (GNNCCA_OK from gnncca_backward_supported): the MFMA family (both reattach flags, all three

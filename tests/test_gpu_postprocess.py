@@ -68,3 +68,30 @@ def test_cluster_large_batch_property():
     _, inv_ref = np.unique(ref, return_inverse=True)
     first = {}
     assert all(first.setdefault(a_, b_) == b_ for a_, b_ in zip(inv, inv_ref))
+
+
+def test_frames_mode_equals_single_workgroup():
+    """Per-frame clustering (one workgroup per frame, node_ptr / edge_ptr ranges) gives exactly the labels, pruning,
+    flows and cluster count of the whole-batch form -- on a batch built by build_graph_batch (device ranges) and with
+    host lists."""
+    import numpy as np
+    from gnn_cca_amd.graph_build import build_graph_batch
+    from gnn_cca_amd.postprocess import prune_and_cluster
+    rng = np.random.default_rng(5)
+    frames, cams, per = 37, 4, 6
+    n_g = cams * per
+    n = frames * n_g
+    id_cam = np.tile(np.repeat(np.arange(cams), per), frames)
+    ids = rng.integers(0, per, size=n).astype(np.int64)
+    xw, yw = rng.normal(size=n), rng.normal(size=n)
+    node = torch.randn(n, 64, device="cuda")
+    reid = torch.randn(n, 32, device="cuda")
+    batch = build_graph_batch(xw, yw, ids, id_cam, [n_g] * frames, [50.0] * frames, node, reid)
+    e = batch.edge_index.shape[1]
+    preds = (torch.rand(e, device="cuda") < 0.35).long()
+    ref = prune_and_cluster(batch.edge_index, preds, n)
+    for np_, ep_ in ((batch.node_ptr_dev, batch.edge_ptr_dev), (batch.node_ptr, batch.edge_ptr)):
+        out = prune_and_cluster(batch.edge_index, preds, n, node_ptr=np_, edge_ptr=ep_)
+        for k in ("pruned", "flow_out", "flow_in", "labels", "n_clusters"):
+            assert torch.equal(out[k], ref[k]), k
+    assert int(ref["n_clusters"]) >= frames

@@ -21,5 +21,5 @@ t_build, batch = T(lambda: build_graph_batch(xw, yw, ids, id_cam, [n_g]*frames, 
 with torch.no_grad():
     t_mpn, out = T(lambda: model(batch))
 t_thr, (pr, pd) = T(lambda: threshold(out['classified_edges'][-1]))
-t_post, _ = T(lambda: prune_and_cluster(batch.edge_index, pd, n))
+t_post, _ = T(lambda: prune_and_cluster(batch.edge_index, pd, n, batch.node_ptr_dev, batch.edge_ptr_dev))
 print(f"frames={frames} plan_frames(host) {t_plan:.3f}  build_graph_batch(total) {t_build:.3f}  mpn {t_mpn:.3f}  threshold {t_thr:.3f}  prune_cluster {t_post:.3f} ms")
