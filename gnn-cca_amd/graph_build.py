@@ -57,7 +57,7 @@ def normalize_columns(x):
         raise RuntimeError("gnn_cca_amd.graph_build runs on MI355X only (no CPU fallback)")
     x = x.float().contiguous()
     out = torch.empty_like(x)
-    scratch = torch.empty(((x.shape[0] + 255) // 256 + 1) * x.shape[1], dtype=torch.float32, device=x.device)
+    scratch = torch.empty(((x.shape[0] + 63) // 64 + 1) * x.shape[1], dtype=torch.float32, device=x.device)  # 64-row chunk sums + norms
     with torch.cuda.device(x.device):
         st = nat.lib().gnncca_normalize_columns(x.data_ptr(), x.shape[0], x.shape[1], scratch.data_ptr(), out.data_ptr(),
                                                 torch.cuda.current_stream(x.device).cuda_stream)

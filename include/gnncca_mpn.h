@@ -194,7 +194,7 @@ typedef struct gnncca_frames {
 enum { GNNCCA_EDGE_ATTR_FULL = 0, GNNCCA_EDGE_ATTR_ONLY_APPEARANCE = 1, GNNCCA_EDGE_ATTR_ONLY_DIST = 2 };
 
 /* out = x / max(||column||_2, 1e-12): F.normalize(x, p=2, dim=0) of inference.py:189-190.
- * scratch: (ceil(n_rows/256) + 1) * n_cols floats. */
+ * scratch: (ceil(n_rows/64) + 1) * n_cols floats. */
 GNNCCA_API int gnncca_normalize_columns(const float* x, int64_t n_rows, int64_t n_cols, float* scratch,
                                         float* out, gnncca_stream_t stream);
 
