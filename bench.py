@@ -272,10 +272,10 @@ def main():
             out = run()
         ev1.record()
         torch.cuda.synchronize()
+        wall = time.perf_counter() - t0   # this rank's K steps, drained; the MAX over ranks below is the job's time
         if dist:
-            dist.barrier()
+            dist.barrier()                # closing bracket (its own latency is not part of any rank's K steps)
         torch.cuda.synchronize()
-        wall = time.perf_counter() - t0
         dev_s = ev0.elapsed_time(ev1) / 1e3
         t = max(wall, dev_s)
         if dist:
