@@ -8,9 +8,17 @@ mode, no grad) over one batch of synthetic input already resident in HBM: `--gra
 `--nodes`-node graphs as one disjoint union (what Batch.from_data_list hands the reference, inference.py:279).
 Default = ONE 256-node dense graph (65 280 edges), L = 4: the configuration BASELINE.json's metric is quoted on.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): every rank runs the same per-GPU workload on its own
-graphs (weak scaling; independent graphs, no cross-GPU edges, no data-path collective); rank 0 packs the weights and
-broadcasts the blob over RCCL.  value = edges processed by all ranks / max-over-ranks time.
+N > 1, one rank process per GPU: either launched by torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in
+the environment) or -- when WORLD_SIZE is unset -- by this script itself: the parent touches no GPU API, starts N fresh
+children of itself with those variables set, waits for them and exits non-zero if any of them does.  Every rank runs
+the same per-GPU workload on its own graphs (weak scaling; independent graphs, no cross-GPU edges, no data-path
+collective); rank 0 packs the weights and broadcasts the blob over RCCL.  value = edges processed by all ranks /
+max-over-ranks time.  The line also carries `config4_sharded`: BASELINE config 4 (512 independent dense128 graphs)
+sharded 512/N per rank through gnn_cca_amd.sharding.forward_sharded, timed the same way (total work fixed: strong).
+
+Timing: >= 10 blocks of exactly `--steps` steps, each block bracketed by barrier + synchronize on both sides and reduced
+with MAX over ranks; the MEDIAN block is reported (ms_per_step = median block / steps), so a short `--steps` run is not
+one sub-millisecond sample.
 
 Prints ONE JSON line (rank 0) with the driver's contract plus `roofline` (dominant kernel mpn_step_kernel, per-launch
 algorithmic bytes / HIP-event duration) and `cpu_baseline` (the reference-shaped torch CPU
@@ -167,6 +175,105 @@ def cpu_baseline(params, model, n_nodes, n_graphs, budget_s=20.0):
                       f"(oracle.TorchOracle), fp32"}
 
 
+class LazyDenseGraphs:
+    """512 (or any number of) independent dense graphs as a sequence that materialises only the slice asked for, so each
+    rank builds just its own share (gnn_cca_amd.sharding.shard_batch slices it by the rank's range).  Graph g is the
+    same on every rank and for every world size: seeded by g."""
+
+    def __init__(self, n_graphs, n_nodes, device):
+        self.n_graphs, self.n_nodes, self.device = n_graphs, n_nodes, device
+        self._ei = dense_union(n_nodes, 1, device)
+
+    def __len__(self):
+        return self.n_graphs
+
+    def __getitem__(self, sl):
+        out = []
+        for g in range(*sl.indices(self.n_graphs)):
+            gen = torch.Generator(device=self.device).manual_seed(7000 + g)
+            x = torch.randn(self.n_nodes, 2048, generator=gen, device=self.device)
+            x = torch.nn.functional.normalize(x, p=2, dim=0)
+            ea = torch.rand(self._ei.shape[1], 4, generator=gen, device=self.device)
+            out.append((x, self._ei, ea))
+        return out
+
+
+def timed_blocks(run, steps, warmup, dist, device, backend, min_blocks=10, min_total_s=0.25, max_blocks=200):
+    """W untimed warm-up steps, then blocks of EXACTLY `steps` steps; every block is bracketed by barrier +
+    torch.cuda.synchronize() on both sides and its time is the MAX over ranks (of the larger of host wall clock and the
+    HIP-event span on the launch stream).  Returns the sorted block times; the caller reports the median.  The block
+    count is the same on every rank because every block time is all-reduced."""
+    for _ in range(warmup):
+        run()
+    blocks, out = [], None
+    while len(blocks) < min_blocks or (sum(blocks) < min_total_s and len(blocks) < max_blocks):
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record()
+        for _ in range(steps):
+            out = run()
+        ev1.record()
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0   # this rank's K steps, drained; the MAX over ranks below is the job's time
+        if dist:
+            dist.barrier()                # closing bracket (its own latency is not part of any rank's K steps)
+        torch.cuda.synchronize()
+        t = max(wall, ev0.elapsed_time(ev1) / 1e3)
+        if dist:
+            tt = torch.tensor([t], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            t = float(tt.item())
+        blocks.append(t)
+    return sorted(blocks), out
+
+
+def launch_ranks(args):
+    """--gpus N > 1 without WORLD_SIZE: this process becomes the launcher.  It never touches a GPU API (no
+    torch.cuda call at all); it starts N FRESH copies of this script -- one per GPU, with RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR / MASTER_PORT set -- waits for them, and exits non-zero if any of them fails.  Rank 0's stdout (the one
+    JSON line) is this process's stdout."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc, deadline = 0, time.time() + args.launch_timeout
+    alive = list(procs)
+    while alive:
+        time.sleep(0.2)
+        for p in list(alive):
+            code = p.poll()
+            if code is None:
+                continue
+            alive.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+        if alive and (rc != 0 or time.time() > deadline):   # one rank failed (or the job hung): stop the others by PID
+            for p in alive:
+                p.terminate()
+            t_kill = time.time() + 10
+            for p in alive:
+                try:
+                    p.wait(timeout=max(0.1, t_kill - time.time()))
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            rc = rc or 124
+            break
+    if rc != 0:
+        print(f"[bench] a rank process failed (exit code {rc})", file=sys.stderr)
+    sys.exit(rc if 0 <= rc < 256 else 1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -182,19 +289,33 @@ def main():
                     help="storage of the edge latents between steps (bf16: GNNCCA_OPT_EDGE_STATE_BF16; arithmetic stays fp32)")
     ap.add_argument("--no-scale-probe", action="store_true", help="skip the 64-graph batch probe of the step kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-config4", action="store_true", help="skip the sharded 512 x dense128 leg (BASELINE config 4)")
+    ap.add_argument("--config4-graphs", type=int, default=512)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--single-device", action="store_true",
                     help="rehearsal on a 1-GPU box: every rank uses cuda:0 (use with --backend gloo)")
     ap.add_argument("--profile-reps", type=int, default=20)
+    ap.add_argument("--min-blocks", type=int, default=10)
+    ap.add_argument("--launch-timeout", type=float, default=900.0, help="launcher: seconds before the rank processes are stopped")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        launch_ranks(args)   # does not return
+        return
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                         f"(or leave WORLD_SIZE unset and let bench.py start the ranks)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path is the only implementation (no CPU fallback)")
     if args.single_device:
         local_rank = 0
+    elif local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} wants cuda:{local_rank} but only {torch.cuda.device_count()} device(s) are "
+                         f"visible (rehearse on one GPU with --single-device --backend gloo)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
@@ -207,12 +328,13 @@ def main():
             dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     params = graph_net_params(L=args.L)
-    model = build_model(params, args.nodes, seed=0).to(device)
+    # ranks start from DIFFERENT random weights (seed = rank); rank 0's are the job's after the broadcast
+    model = build_model(params, args.nodes, seed=rank).to(device)
     model.edge_state_dtype = args.edge_state
-    # shared weights: rank 0 packs, everyone receives the blob over RCCL/xGMI (no other collective on the path)
+    # shared weights: ONE RCCL broadcast of rank 0's parameters over xGMI (no other collective on the path)
     if world > 1:
-        from gnn_cca_amd.sharding import broadcast_packed_weights
-        broadcast_packed_weights(model, src=0)
+        from gnn_cca_amd.sharding import broadcast_weights
+        broadcast_weights(model, src=0)
     data = make_data(args.nodes, args.graphs, 1 + rank, device)
     E = data.edge_index.shape[1]
     N = data.x.shape[0]
@@ -259,32 +381,35 @@ def main():
             if args.mode == "auto":
                 mode_used += " (auto)"
 
-        for _ in range(args.warmup):
-            run()
-        torch.cuda.synchronize()
-        if dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        t0 = time.perf_counter()
-        ev0.record()
-        for _ in range(args.steps):
-            out = run()
-        ev1.record()
-        torch.cuda.synchronize()
-        wall = time.perf_counter() - t0   # this rank's K steps, drained; the MAX over ranks below is the job's time
-        if dist:
-            dist.barrier()                # closing bracket (its own latency is not part of any rank's K steps)
-        torch.cuda.synchronize()
-        dev_s = ev0.elapsed_time(ev1) / 1e3
-        t = max(wall, dev_s)
-        if dist:
-            tt = torch.tensor([t], device=device if args.backend == "nccl" else "cpu", dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            t = float(tt.item())
+        blocks, out = timed_blocks(run, args.steps, args.warmup, dist, device, args.backend, min_blocks=args.min_blocks)
+        t = blocks[len(blocks) // 2]      # median block of K steps (max over ranks inside every block)
         if static_out is not None:
             out = static_out
         ok = all(torch.isfinite(o).all().item() for o in out["classified_edges"])
+
+        # ---- BASELINE config 4: 512 independent dense128 graphs, sharded 512/N per rank (forward_sharded) ----------
+        cfg4 = None
+        if not args.no_config4:
+            from gnn_cca_amd.sharding import forward_sharded, shard_batch
+            m4 = build_model(graph_net_params(L=4), 128, seed=rank).to(device)
+            m4.edge_state_dtype = args.edge_state
+            if world > 1:
+                broadcast_weights(m4, src=0)
+            graphs4 = LazyDenseGraphs(args.config4_graphs, 128, device)
+            lo4, hi4, batch4 = shard_batch(graphs4, rank, world)       # this rank's union, resident in HBM
+            e4_local = batch4.edge_index.shape[1] if batch4 is not None else 0
+            e4_total = args.config4_graphs * 128 * 127
+            steps4 = max(1, min(args.steps, 50))
+            blocks4, res4 = timed_blocks(lambda: forward_sharded(m4, graphs4, rank, world, batch=batch4), steps4,
+                                         min(args.warmup, 10), dist, device, args.backend, min_blocks=5, min_total_s=0.1)
+            t4 = blocks4[len(blocks4) // 2]
+            ok4 = all(torch.isfinite(o).all().item() for g in res4[2][:2] for o in g)
+            cfg4 = {"workload": f"{args.config4_graphs} x dense128 graphs (E={e4_total}), sharded {hi4 - lo4} per rank "
+                                f"through sharding.forward_sharded, L=4, 3 classified steps, fp32, eval",
+                    "value": e4_total * steps4 / t4, "unit": "edges/s", "scaling": "strong", "n_gpus": world,
+                    "graphs_per_rank": hi4 - lo4, "edges_rank0": e4_local, "steps": steps4, "blocks": len(blocks4),
+                    "ms_per_step": t4 / steps4 * 1e3, "outputs_finite": bool(ok4)}
+            del m4, graphs4, batch4, res4
 
         # per-kernel durations (HIP events attached to every dispatch; separate pass so the timed region is undisturbed)
         kernel_ms = {}
@@ -296,7 +421,8 @@ def main():
                 kernel_ms.setdefault(kind, []).append(ms)
 
     if rank == 0:
-        per_launch = step_algorithmic_bytes(E, args.L, 3, e_bytes=12 if args.edge_state == "bf16" else 24)
+        e_bytes = 12 if args.edge_state == "bf16" else 24
+        per_launch = step_algorithmic_bytes(E, args.L, 3, e_bytes=e_bytes)
         step_ms = float(np.mean(kernel_ms["step"])) if "step" in kernel_ms else float("nan")
         alg = float(np.mean(per_launch)) if per_launch else 0.0
         achieved = alg / (step_ms * 1e-3) / 1e9 if step_ms == step_ms and step_ms > 0 else 0.0
@@ -310,8 +436,12 @@ def main():
                 traffic, rocprof_us = ent["hbm_bytes_per_launch"], ent["rocprof_avg_us"]
         except OSError:
             pass
+        # the edge state of one step (read + write) against the 8 x 4 MB of L2: below that the launch is bounded by its
+        # dependent round trips after the kernel boundary, not by HBM; the HBM fraction is still reported
+        cache_resident = E * 2 * e_bytes < 32e6
+        shape = f"{args.nodes}-node dense graph" if args.graphs == 1 else f"{args.graphs} x {args.nodes}-node dense graphs"
         res = {
-            "metric": "processed edges/sec (L=4 MPN steps), 256-node dense graph",
+            "metric": f"processed edges/sec (L={args.L} MPN steps), {shape}",
             "value": world * E * args.steps / t,
             "unit": "edges/s",
             "n_gpus": world,
@@ -324,18 +454,27 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"{args.graphs} x dense{args.nodes} graph(s) per GPU per step "
-                                   f"(N={N}, E={E}), feat 2048, L={args.L}, 3 classified steps, fp32, eval",
+                                   f"(N={N}, E={E}), feat 2048, L={args.L}, 3 classified steps, fp32 arithmetic, "
+                                   f"{args.edge_state} edge state, eval",
                        "mode": mode_used, "edge_state": args.edge_state, "outputs_finite": bool(ok),
-                       "edge_steps_per_s": world * E * args.L * args.steps / t},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                       "edge_steps_per_s": world * E * args.L * args.steps / t,
+                       "timing": f"median of {len(blocks)} blocks of {args.steps} steps (each: barrier + synchronize on both "
+                                 f"sides, MAX over ranks)",
+                       "block_ms": {"min": blocks[0] * 1e3, "median": t * 1e3, "max": blocks[-1] * 1e3},
+                       "launcher": "torch.distributed.run / external" if "TORCHELASTIC_RUN_ID" in os.environ or world == 1
+                       else "bench.py (self-launched rank processes)", "backend": args.backend if world > 1 else None},
+            "roofline": {"bound": "latency" if cache_resident else "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "kernel": "mpn_step_fast_kernel<FIRST|CLS,MSG> (message-passing step, L-1 launches/forward)",
                          "avg_launch_us": step_ms * 1e3, "rocprof_avg_launch_us": rocprof_us,
                          "algorithmic_bytes_per_launch": alg,
-                         "note": "working set is L2/Infinity-Cache resident at this size: latency-bound, not HBM-bound"
-                         if E * 48 < 200e6 else ""},
+                         "note": "edge state is L2/Infinity-Cache resident at this size: the launch is bounded by its dependent "
+                                 "round trips (latency), `frac` is still algorithmic bytes / time / HBM peak; "
+                                 "`roofline_at_scale` is the same kernel where HBM is the bound" if cache_resident else ""},
             "kernels_us": {k: float(np.mean(v)) * 1e3 for k, v in kernel_ms.items()},
         }
+        if cfg4 is not None:
+            res["config4_sharded"] = cfg4
         if world == 1 and args.graphs == 1 and not args.no_scale_probe:
             res["roofline_at_scale"] = scale_probe(params, device, args)
         if world == 1 and not args.no_cpu_baseline:

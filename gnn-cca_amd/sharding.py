@@ -5,8 +5,9 @@ weights are shared and read-only in eval mode, so the path shards by GRAPH with 
 
   * rank r of W owns graphs [lo, hi) of the batch (`shard_range`), builds its own disjoint union with local node
     numbering (`union_graphs`) and runs the ordinary single-GPU forward on it;
-  * the only collective is a one-time broadcast of the packed weight blob (2.66 MB for the shipped configs) from rank 0
-    over RCCL/xGMI (`broadcast_packed_weights`; backend "nccl" is RCCL on ROCm, "gloo" in the CPU tests).
+  * the only collective is a one-time broadcast of the shared MLP weights (the state_dict as one flat 1.07 MB buffer)
+    from rank 0 over RCCL/xGMI (`broadcast_weights`; backend "nccl" is RCCL on ROCm, "gloo" in the CPU tests); every
+    rank then packs its own kernel blob from them (byte-identical everywhere).
 
 The reference has no distributed code at all (single GPU, main_training.py:7).
 """
@@ -55,46 +56,68 @@ def split_logits(outputs, batch):
     return per_graph
 
 
-def broadcast_packed_weights(model, src=0, group=None):
-    """Rank `src` packs its state_dict into the kernel blob; every rank receives it and installs it.  One collective,
-    (2.66 MB for the shipped configs: fp32 weights plus the three bf16 planes of the first encoder layer), issued once
-    at start-up or after load_state_dict."""
+def broadcast_weights(model, src=0, group=None):
+    """Every rank receives rank `src`'s parameters and buffers: the whole state_dict travels as one flat buffer per
+    dtype (268 145 fp32 values = 1.07 MB for the shipped configs, plus BatchNorm's int64 counter) -- ONE RCCL broadcast
+    over xGMI on the "nccl" backend -- and is copied INTO this rank's own tensors.  After it `state_dict()` is rank
+    `src`'s on every rank and the packed kernel blob is rebuilt from it by the ordinary packer (host and device packers
+    are byte-identical, tests/test_gpu_parity.py), so a later `.eval()` / `.train()` / `.to()` that drops the packed
+    cache cannot resurrect rank-local weights.  Issued once at start-up or after load_state_dict on `src`."""
     import torch.distributed as dist
+    sd = model.state_dict()
     dev = next(model.parameters()).device
-    if dist.get_backend(group) != "nccl" and dev.type == "cuda":
-        # rehearsal backends (gloo) move host tensors: broadcast the host blob, then upload
-        import ctypes as C
-        from . import _native as nat
-        if dist.get_rank(group) == src:
-            host = model.pack_weights_host()
-        else:
-            host = torch.empty(nat.lib().gnncca_packed_weights_bytes(C.byref(model.native_dims())), dtype=torch.uint8)
-        dist.broadcast(host, src=src, group=group)
-        blob = host.to(dev)
-        model.set_packed_weights(blob)
-        return blob
-    if dist.get_rank(group) == src:
-        blob = model._pack_weights_device(dev) if dev.type == "cuda" else None  # packed by one kernel, no host copy
-        if blob is None:
-            blob = model.pack_weights_host().to(dev)
-    else:
-        import ctypes as C
-        from . import _native as nat
-        nbytes = nat.lib().gnncca_packed_weights_bytes(C.byref(model.native_dims()))
-        if nbytes == 0:
-            nat.check(nat.lib().gnncca_supported(C.byref(model.native_dims())), "MOTMPNet configuration")
-        blob = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-    dist.broadcast(blob, src=src, group=group)
-    model.set_packed_weights(blob)
-    return blob
+    via_host = dist.get_backend(group) != "nccl" and dev.type == "cuda"  # rehearsal backends (gloo) move host tensors
+    by_dtype = {}
+    for name, t in sd.items():
+        by_dtype.setdefault(t.dtype, []).append(t)
+    with torch.no_grad():
+        for dtype in sorted(by_dtype, key=str):
+            tensors = by_dtype[dtype]
+            flat = torch.cat([t.reshape(-1) for t in tensors])
+            if via_host:
+                flat = flat.cpu()
+            dist.broadcast(flat, src=src, group=group)
+            if dist.get_rank(group) != src:
+                flat = flat.to(dev)
+                off = 0
+                for t in tensors:
+                    t.copy_(flat[off:off + t.numel()].view(t.shape))
+                    off += t.numel()
+    model.invalidate_packed_weights()
 
 
-def forward_sharded(model, graphs, rank, world):
-    """Run this rank's share of `graphs` (a list as for union_graphs, identical on every rank or at least indexable
-    by this rank's range).  Returns (lo, hi, per-graph logits)."""
+def broadcast_packed_weights(model, src=0, group=None):
+    """broadcast_weights, then pack on this rank; returns the packed blob (on the module's device, or on the host for
+    a CPU module, where only the packer -- no kernel -- can run)."""
+    broadcast_weights(model, src=src, group=group)
+    dev = next(model.parameters()).device
+    if dev.type == "cuda":
+        return model._packed_weights(dev)
+    return model.pack_weights_host()
+
+
+def shard_batch(graphs, rank, world):
+    """This rank's share of `graphs` as ONE disjoint union, built once (inputs then stay resident in HBM; the reference
+    builds its union in the DataLoader, outside the model call, inference.py:279).  `graphs` is any sequence that can be
+    sliced by this rank's range -- a list that is identical on every rank, or a lazy sequence that only materialises
+    the graphs asked for.  Returns (lo, hi, GraphBatch or None for an empty share)."""
     lo, hi = shard_range(len(graphs), rank, world)
     if hi == lo:
+        return lo, hi, None
+    return lo, hi, union_graphs(graphs[lo:hi])
+
+
+def forward_sharded(model, graphs, rank, world, batch=None):
+    """Run this rank's share of `graphs` (see shard_batch; pass the `batch` it returned to reuse a union that is already
+    resident instead of concatenating again).  No collective: every rank runs the ordinary single-GPU forward on its own
+    union.  Returns (lo, hi, per-graph logits: list over this rank's graphs of list over classified steps)."""
+    if batch is None:
+        lo, hi, batch = shard_batch(graphs, rank, world)
+    else:
+        lo, hi = shard_range(len(graphs), rank, world)
+        if len(batch.node_ptr) - 1 != hi - lo:
+            raise ValueError(f"batch holds {len(batch.node_ptr) - 1} graphs, this rank's share is [{lo}, {hi})")
+    if batch is None:
         return lo, hi, []
-    batch = union_graphs(graphs[lo:hi])
     out = model(batch)
     return lo, hi, split_logits(out, batch)

@@ -1,0 +1,97 @@
+"""SURVEY.md 8(e) on hardware: two FRESH rank processes (RCCL when the box has two GPUs, gloo with both ranks on
+cuda:0 otherwise) broadcast rank 0's weights and run sharding.forward_sharded over 7 unequal graphs; every graph's
+logits must be BITWISE equal to the unsharded single-process forward over the union of all 7.  (All three launches
+-- the 7-graph union and the 4- and 3-graph shares -- fall into the same dispatch regime: N < 992 keeps the encoder's
+split-K factor, out-degree < 64 keeps one wave per segment; a graph's result then does not depend on its neighbours
+in the batch.)  Also: `bench.py --gpus 2` with WORLD_SIZE unset starts its own rank processes and reports n_gpus 2."""
+import copy
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN_DIR, ROOT
+from oracle.mpn_oracle import load_case
+
+pytestmark = pytest.mark.gpu
+
+WORKER = os.path.join(ROOT, "tests", "helpers", "sharded_worker.py")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _clean_env():
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    return env
+
+
+def test_forward_sharded_two_ranks_bitwise_equals_unsharded(tmp_path):
+    world, port = 2, _free_port()
+    procs = [subprocess.Popen([sys.executable, WORKER, str(r), str(world), str(port), str(tmp_path)], env=_clean_env())
+             for r in range(world)]
+    try:
+        for p in procs:
+            assert p.wait(timeout=300) == 0
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    sys.path.insert(0, os.path.join(ROOT, "tests", "helpers"))
+    from sharded_worker import SIZES, make_graphs
+    from gnn_cca_amd import MOTMPNet
+    from gnn_cca_amd.sharding import split_logits, union_graphs
+    params, arch, sd, _ = load_case(os.path.join(GOLDEN_DIR, "terrace32.npz"))
+    m = MOTMPNet(copy.deepcopy(params), None, arch)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    m = m.cuda().eval()
+    batch = union_graphs(make_graphs("cuda"))
+    with torch.no_grad():
+        ref = split_logits(m(batch), batch)
+    torch.cuda.synchronize()
+    got = [np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(world)]
+    covered = []
+    for r, z in enumerate(got):
+        lo, hi = int(z["lo"]), int(z["hi"])
+        covered += list(range(lo, hi))
+        for k, v in sd.items():   # the broadcast put rank 0's state_dict into every rank's own tensors
+            assert np.array_equal(z["sd::" + k], np.asarray(v)), (r, k)
+        for g in range(lo, hi):
+            assert len(ref[g]) == 3
+            for s, t in enumerate(ref[g]):
+                a = z[f"g{g}_s{s}"]
+                assert a.shape == (SIZES[g] * (SIZES[g] - 1), 1)
+                assert np.array_equal(a, t.cpu().numpy()), (r, g, s, float(np.abs(a - t.cpu().numpy()).max()))
+    assert covered == list(range(len(SIZES)))
+    assert str(got[0]["backend"]) == ("nccl" if torch.cuda.device_count() >= world else "gloo")
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` (WORLD_SIZE unset): the parent starts two rank processes; rank 0 prints ONE JSON line
+    with n_gpus = 2 and the sharded config-4 leg."""
+    multi = torch.cuda.device_count() >= 2
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--min-blocks", "3",
+           "--no-cpu-baseline", "--no-scale-probe", "--profile-reps", "1", "--config4-graphs", "6", "--mode", "eager"]
+    if not multi:
+        cmd += ["--single-device", "--backend", "gloo"]
+    r = subprocess.run(cmd, env=_clean_env(), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["steps"] == 5 and res["config"]["outputs_finite"]
+    assert res["value"] > 0 and res["scaling"] == "weak"
+    c4 = res["config4_sharded"]
+    assert c4["n_gpus"] == 2 and c4["graphs_per_rank"] == 3 and c4["outputs_finite"] and c4["value"] > 0

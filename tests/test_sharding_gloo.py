@@ -35,7 +35,13 @@ def _worker(rank, world, port, q):
             m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
         blob = broadcast_packed_weights(m, src=0)
         covered = list(range(*shard_range(7, rank, world)))
-        q.put((rank, blob.numpy().tobytes(), covered))
+        # the broadcast lands in this rank's OWN tensors: dropping the packed cache (.train() / .eval()) and packing again
+        # must give rank 0's blob, not this rank's initial weights
+        m.train()
+        m.eval()
+        again = m.pack_weights_host().numpy().tobytes()
+        sd_bytes = b"".join(v.numpy().tobytes() for v in m.state_dict().values())
+        q.put((rank, blob.numpy().tobytes(), covered, again, sd_bytes))
     finally:
         dist.destroy_process_group()
 
@@ -53,6 +59,8 @@ def test_weight_broadcast_and_sharding_world2():
         assert p.exitcode == 0
     assert res[0][1] == res[1][1], "every rank must hold rank 0's packed weights after the broadcast"
     assert res[0][2] + res[1][2] == list(range(7))
+    assert res[1][3] == res[0][1], "repacking after .train()/.eval() on rank 1 must still give rank 0's weights"
+    assert res[1][4] == res[0][4], "state_dict of rank 1 must be rank 0's after the broadcast"
     # and the blob is rank 0's: equal to packing the golden state_dict locally
     from gnn_cca_amd import MOTMPNet
     params, arch, sd, _ = load_case(os.path.join(GOLDEN_DIR, "terrace32.npz"))
@@ -82,3 +90,43 @@ def test_union_graphs_layout():
     assert b.edge_ptr == [0, 3, 5] and b.node_ptr == [0, 3, 5]
     parts = split_logits({'classified_edges': [torch.arange(5.).view(5, 1)]}, b)
     assert [p[0].view(-1).tolist() for p in parts] == [[0., 1., 2.], [3., 4.]]
+
+
+def test_forward_sharded_host_logic():
+    """forward_sharded / shard_batch with a stand-in model (the real forward is HIP-only): every graph is covered once
+    over the ranks, a prebuilt union is reused, a lazy sequence is only sliced by the rank's range."""
+    from gnn_cca_amd.sharding import forward_sharded, shard_batch
+
+    class Echo:  # 'logit' of an edge = its global source node id inside the rank's union
+        def __call__(self, batch):
+            return {'classified_edges': [batch.edge_index[0].float().view(-1, 1)]}
+
+    class Lazy:
+        def __init__(self, graphs):
+            self.graphs, self.asked = graphs, []
+
+        def __len__(self):
+            return len(self.graphs)
+
+        def __getitem__(self, sl):
+            self.asked.append((sl.start, sl.stop))
+            return self.graphs[sl]
+
+    graphs = [(torch.zeros(n, 3), torch.tensor([[i for i in range(n)], [(i + 1) % n for i in range(n)]]), torch.zeros(n, 4))
+              for n in (2, 3, 4, 5, 6)]
+    seen = []
+    for rank in range(3):
+        lazy = Lazy(graphs)
+        lo, hi, batch = shard_batch(lazy, rank, 3)
+        assert lazy.asked == [(lo, hi)]
+        lo2, hi2, per_graph = forward_sharded(Echo(), lazy, rank, 3, batch=batch)
+        assert (lo, hi) == (lo2, hi2) and lazy.asked == [(lo, hi)]  # the union was not rebuilt
+        assert len(per_graph) == hi - lo
+        for g, steps in zip(range(lo, hi), per_graph):
+            n = graphs[g][0].shape[0]
+            assert steps[0].shape == (n, 1)
+            seen.append(g)
+    assert seen == list(range(5))
+    assert forward_sharded(Echo(), graphs[:1], 1, 2) == (1, 1, [])
+    with pytest.raises(ValueError):
+        forward_sharded(Echo(), graphs, 0, 3, batch=shard_batch(graphs[:1], 0, 1)[2])  # rank 0 of 3 owns two graphs
