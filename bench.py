@@ -461,7 +461,7 @@ def main():
                        "timing": f"median of {len(blocks)} blocks of {args.steps} steps (each: barrier + synchronize on both "
                                  f"sides, MAX over ranks)",
                        "block_ms": {"min": blocks[0] * 1e3, "median": t * 1e3, "max": blocks[-1] * 1e3},
-                       "launcher": "torch.distributed.run / external" if "TORCHELASTIC_RUN_ID" in os.environ or world == 1
+                       "launcher": "single process" if world == 1 else "torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ
                        else "bench.py (self-launched rank processes)", "backend": args.backend if world > 1 else None},
             "roofline": {"bound": "latency" if cache_resident else "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,

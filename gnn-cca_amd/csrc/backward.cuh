@@ -104,12 +104,14 @@ struct BwdEdgeParams {
 template <bool COUNT>
 __global__ __launch_bounds__(256) void bwd_max_kernel(const long long* __restrict__ ei, const float* __restrict__ e_cur,
                                                       const float* __restrict__ Q, const float* __restrict__ Wn_, long long E,
-                                                      int HI, int* __restrict__ hmax, int* __restrict__ hcnt) {
+                                                      int N, int HI, int* __restrict__ hmax, int* __restrict__ hcnt) {
     const long long k = (long long)blockIdx.x * 256 + threadIdx.x;
     if (k >= E) return;
     typedef const float __attribute__((address_space(4))) cfloat;
     cfloat* Wn = (cfloat*)(unsigned long long)Wn_;
-    const int i = (int)ei[k];
+    const long long ri = ei[k];
+    if ((unsigned long long)ri >= (unsigned long long)N) return;  // bad index: the forward flagged it and poisoned the logits
+    const int i = (int)ri;
     float es[kEF];
 #pragma unroll
     for (int f = 0; f < kEF; ++f) es[f] = e_cur[k * kEF + f];
@@ -179,11 +181,17 @@ __global__ __launch_bounds__(256) void bwd_edge_kernel(const BwdEdgeParams p) {
 
     for (long long chunk = blockIdx.x; chunk * 256 < p.E; chunk += gridDim.x) {
         const long long k0 = chunk * 256 + threadIdx.x;
-        const bool valid = k0 < p.E;
-        const long long k = valid ? k0 : p.E - 1;  // every lane takes part in the wave reductions; invalid lanes add zeros
+        const bool has = k0 < p.E;
+        const long long k = has ? k0 : p.E - 1;  // every lane takes part in the wave reductions; invalid lanes add zeros
+        // An edge with an index outside [0, N) is DEAD here (no read or atomic at a wild address): the forward has flagged
+        // it (GNNCCA_GRAPH_BAD_INDEX) and poisoned the logits with NaN, so the loss and every gradient are NaN anyway --
+        // the reference raises an IndexError at this point (models/mpn.py:48).
+        const long long ri = p.ei[k], rj = p.ei[p.E + k], rf = p.ei[chunk * 256];
+        const bool inb = (unsigned long long)ri < (unsigned long long)p.N && (unsigned long long)rj < (unsigned long long)p.N;
+        const bool valid = has && inb;
         const float live = valid ? 1.f : 0.f;
-        const int i = (int)p.ei[k], j = (int)p.ei[p.E + k];
-        const int i_first = (int)p.ei[chunk * 256];
+        const int i = inb ? (int)ri : 0, j = inb ? (int)rj : 0;
+        const int i_first = (unsigned long long)rf < (unsigned long long)p.N ? (int)rf : 0;
         for (int t = threadIdx.x; t < kBwdLdsRows * 44; t += 256) s_dp[t] = 0.f;
         __syncthreads();
         const unsigned li = (unsigned)(i - i_first);
@@ -377,8 +385,9 @@ __global__ __launch_bounds__(256) void bwd_edge_kernel(const BwdEdgeParams p) {
                 wave_lds_add16(v, s_acc, [&](int idx) { return idx == 0 ? kSlotBe + f : (idx <= 12 ? kSlotWe + f * 12 + idx - 1 : -1); });
             }
         }
-        if (valid) {
-            // gradient of the edge part of the input: W_ee^T g_a; with reattach the first six columns belong to e0
+        if (has) {
+            // gradient of the edge part of the input: W_ee^T g_a (zeros for a dead edge); with reattach the first six
+            // columns belong to e0
             const int off_prev = p.e0 ? kEF : 0;
 #pragma unroll
             for (int g = 0; g < kEF; ++g) {

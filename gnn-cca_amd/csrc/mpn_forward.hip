@@ -643,9 +643,9 @@ int gnncca_mpn_backward_ex(const gnncca_mpn_dims* d, const float* const* params_
         if (g_h && d->agg == GNNCCA_AGG_MAX) {  // which edge attained each node's maximum
             HIP_TRY(hipMemsetAsync(hmax, 0, (size_t)2 * N * kH * 4, st));
             hipLaunchKernelGGL(bwd_max_kernel<false>, grid1((size_t)E, 256), dim3(256), 0, st, ei, e_cur, (const float*)Q, Wn,
-                               (long long)E, HI, hmax, hcnt);
+                               (long long)E, N, HI, hmax, hcnt);
             hipLaunchKernelGGL(bwd_max_kernel<true>, grid1((size_t)E, 256), dim3(256), 0, st, ei, e_cur, (const float*)Q, Wn,
-                               (long long)E, HI, hmax, hcnt);
+                               (long long)E, N, HI, hmax, hcnt);
             HIP_TRY(hipGetLastError());
             bp.hmax = hmax;
             bp.hcnt = hcnt;

@@ -47,13 +47,37 @@ def union_graphs(graphs):
     return GraphBatch(torch.cat(xs), torch.cat(eis, dim=1), torch.cat(eas), edge_ptr, node_ptr)
 
 
+class PerGraphLogits:
+    """Sequence over the graphs of a GraphBatch; item g = list over classified steps of Tensor[e_g, 1] (views of the
+    batch's logits, made when asked for: slicing 512 graphs x 3 steps eagerly costs more host time than the whole GPU
+    forward of that batch)."""
+
+    def __init__(self, outputs, batch):
+        self._steps, self._edge_ptr = outputs['classified_edges'], batch.edge_ptr
+
+    def __len__(self):
+        return len(self._edge_ptr) - 1
+
+    def __getitem__(self, g):
+        if isinstance(g, slice):
+            return [self[i] for i in range(*g.indices(len(self)))]
+        if g < 0:
+            g += len(self)
+        if not 0 <= g < len(self):
+            raise IndexError(g)
+        lo, hi = self._edge_ptr[g], self._edge_ptr[g + 1]
+        return [t[lo:hi] for t in self._steps]
+
+    def __iter__(self):
+        return (self[g] for g in range(len(self)))
+
+    def __eq__(self, other):
+        return list(self) == other if isinstance(other, list) else NotImplemented
+
+
 def split_logits(outputs, batch):
-    """Per-graph views of each classified step: list over graphs of list over steps of Tensor[e_g, 1]."""
-    per_graph = []
-    for g in range(len(batch.edge_ptr) - 1):
-        lo, hi = batch.edge_ptr[g], batch.edge_ptr[g + 1]
-        per_graph.append([t[lo:hi] for t in outputs['classified_edges']])
-    return per_graph
+    """Per-graph views of each classified step: sequence over graphs of list over steps of Tensor[e_g, 1]."""
+    return PerGraphLogits(outputs, batch)
 
 
 def broadcast_weights(model, src=0, group=None):

@@ -89,3 +89,15 @@ def test_packed_blob_header_is_validated_on_load():
     m2 = MOTMPNet(copy.deepcopy(other), None, "tiny64")
     with pytest.raises(RuntimeError):
         m2.load_packed_blob(good)                        # a different GRAPH_NET_PARAMS: different size
+
+
+def test_plan_load_is_pure_and_explains():
+    from gnn_cca_amd.checkpoint import plan_load
+    shapes = {"a.weight": (2, 3), "a.bias": (2,), "b": ()}
+    ck = {"module.a.weight": torch.zeros(2, 3), "a.bias": torch.zeros(3), "zzz": torch.zeros(1), "module.module.b": torch.zeros(())}
+    accepted, rep = plan_load(shapes, ck)
+    assert list(accepted) == ["a.weight"] and rep.matched == ["a.weight"]
+    assert rep.discarded == ["a.bias", "zzz", "module.b"]      # only ONE DataParallel prefix is removed
+    assert "shape (3,)" in rep.reasons["a.bias"] and rep.reasons["zzz"] == "not a tensor of this model"
+    assert rep.missing == ["a.bias", "b"]
+    assert "skipped a.bias" in rep.summary()

@@ -198,3 +198,29 @@ def test_random_graphs_gradients_vs_oracle(agg):
                 assert float(np.abs(p.grad.cpu().numpy()).max()) <= 5e-4 and float(np.abs(r).max()) <= 5e-4, (it, k)
                 continue
             assert err <= 3e-5 * scale, (it, n, ei.shape, k, err)
+
+
+@pytest.mark.parametrize("name", ["terrace32", "terrace32_max", "terrace32_mean"])
+@pytest.mark.parametrize("which,bad", [(0, 10 ** 6), (1, -3), (0, 2 ** 40 + 1)])
+def test_out_of_range_index_in_train_mode_is_contained(name, which, bad):
+    """An index outside [0, N) in train mode (the reference raises IndexError at models/mpn.py:48): the forward flags it
+    and poisons the logits; the backward must treat the edge as dead -- no read, write or atomic at a wild address.  A
+    canary tensor allocated right around the call stays intact, the flag word says BAD_INDEX, loss and gradients are
+    NaN (never silently plausible numbers)."""
+    params, arch, sd, _, _, a = load_bwd(name)
+    m = build(params, arch, sd)
+    ei = torch.from_numpy(a["edge_index"]).clone()
+    ei[which, ei.shape[1] // 2] = bad
+    canary_lo = torch.full((1 << 18,), 7.0, device="cuda")
+    d = Data(torch.from_numpy(a["x"]).cuda(), ei.cuda(), torch.from_numpy(a["edge_attr"]).cuda())
+    canary_hi = torch.full((1 << 18,), 7.0, device="cuda")
+    out = m(d)
+    loss = loss_of(out, torch.from_numpy(a["labels"]).cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    assert m.graph_flags() & 2
+    assert not np.isfinite(float(loss))
+    assert all(torch.isnan(t).all().item() for t in out["classified_edges"])
+    for k, p in m.named_parameters():
+        assert p.grad is not None and p.grad.shape == p.shape, k
+    assert bool((canary_lo == 7.0).all()) and bool((canary_hi == 7.0).all())
