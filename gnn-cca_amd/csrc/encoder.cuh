@@ -72,6 +72,7 @@ struct EncPlanParams {
     int* col32;
     unsigned* blockflags;
     int M, K, O, kslice, vec_ok, nrt, nks, gemm_blocks, E, N;
+    int ell_S;  // slots per node of the padded step layout to validate the degrees against (0: none)
 };
 
 __global__ __launch_bounds__(256) void enc_gemm_plan_kernel(const EncPlanParams p) {
@@ -82,7 +83,7 @@ __global__ __launch_bounds__(256) void enc_gemm_plan_kernel(const EncPlanParams 
         const int rt = b % p.nrt, t = b / p.nrt;
         gemm_tile(rt, t % p.nks, t / p.nks, p.in, p.W, p.part, p.M, p.K, p.O, p.kslice, p.vec_ok);
     } else {
-        plan_block(b - p.gemm_blocks, p.ei, p.E, p.N, p.seg_ptr, p.col32, p.blockflags, &s_fl);
+        plan_block(b - p.gemm_blocks, p.ei, p.E, p.N, p.seg_ptr, p.col32, p.blockflags, &s_fl, p.ell_S);
     }
     GNNCCA_STAMP(1, 1);
 }

@@ -117,7 +117,11 @@ struct Workspace {
     size_t flags, blockflags, seg_ptr, col32, perm, cursor, h0, act, partial, pd[2], psq[2], e, e0, total;
     int ksplit;        // split-K factor of the first encoder GEMM
     int64_t e_stride;  // floats between two feature planes of the edge state
+    int ell_S;         // padded edge-state layout: slots per node (multiple of 32), 0 = compact CSR order only
 };
+// Padded edge-state stride for big, nearly regular batches: a pure function of (dims, N, E) -- the host never reads the
+// graph back; the plan kernel validates the degrees against it on the device (GNNCCA_GRAPH_IRREGULAR).
+int ell_stride(const gnncca_mpn_dims* d, int64_t n, int64_t e);
 Workspace carve(const gnncca_mpn_dims* d, int64_t n, int64_t e);
 
 }  // namespace gnncca

@@ -92,6 +92,10 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
     float* ebuf = reinterpret_cast<float*>(base + ws.e);
     float* e0buf = reinterpret_cast<float*>(base + ws.e0);
 
+    // big, nearly regular batches keep the edge state in the padded layout (StepParams::ell_S); the decision is a pure
+    // function of (dims, N, E) made in carve(); the plan validates the degrees against it on the device
+    const bool use_ell = ws.ell_S > 0 && hdr.fast_consts != 0 && d->edge_in == 4 && !trace && d->agg != GNNCCA_AGG_MAX &&
+                         (reinterpret_cast<uintptr_t>(edge_attr) & 15) == 0 && E > 0;
     // ---- node encoder -------------------------------------------------------------------------------------
     const int nl = d->enc_node.n_layers;
     const int n_gemm = nl == 1 ? 1 : nl - 1;
@@ -152,6 +156,7 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
             ep.blockflags = blockflags;
             ep.E = E;
             ep.N = N;
+            ep.ell_S = use_ell ? ws.ell_S : 0;
             plan_blocks = plan_num_blocks(E);
         }
         if (ep.gemm_blocks + plan_blocks > 0) {
@@ -268,6 +273,7 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
     sp.hin = hin;
     sp.pd_lds = (N <= 1024) && d->num_enc_steps > 0;
     sp.e_bf16 = (options & GNNCCA_OPT_EDGE_STATE_BF16) != 0;  // honoured by the specialised kernels only
+    sp.ell_S = use_ell ? ws.ell_S : 0;
     const bool re = d->reattach_edges != 0;
     int out_idx = 0;
     if (L == 0) {  // models/mpn.py:295-297: classify the encoded edge features once

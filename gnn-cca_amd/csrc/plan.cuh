@@ -71,7 +71,7 @@ __host__ __device__ inline int plan_num_blocks(int E) { return (E + plan_edges_p
 // written, so there is no state to clear between forwards); the tail launch ORs them into flags[0].
 __device__ __forceinline__ void plan_block(int pb, const long long* __restrict__ ei, int E, int N,
                                            int* __restrict__ seg_ptr, int* __restrict__ col32,
-                                           unsigned* __restrict__ blockflags, unsigned* s_fl) {
+                                           unsigned* __restrict__ blockflags, unsigned* s_fl, int ell_S = 0) {
     if (threadIdx.x == 0) *s_fl = 0u;
     __syncthreads();
     const int per = plan_edges_per_block(E) / 256;
@@ -101,6 +101,10 @@ __device__ __forceinline__ void plan_block(int pb, const long long* __restrict__
                 fl |= GNNCCA_GRAPH_UNSORTED;
             } else {
                 for (long long n = rp[u] + 1; n <= r[u]; ++n) seg_ptr[n] = k;
+                // padded layout of the step kernels (ell_S slots per node, chosen from E/N): a row that still continues
+                // ell_S edges after its start does not fit (rows are sorted here, or UNSORTED is raised elsewhere)
+                if (ell_S > 0 && r[u] > rp[u] && (long long)k + ell_S < E && ei[(size_t)k + ell_S] == r[u])
+                    fl |= GNNCCA_GRAPH_IRREGULAR;
             }
             if (k == E - 1)
                 for (long long n = r[u] + 1; n <= N; ++n) seg_ptr[n] = E;

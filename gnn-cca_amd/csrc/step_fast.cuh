@@ -9,8 +9,18 @@ namespace gnncca {
 // time, so the body is straight-line code whose loads issue back to back.  mpn_step_kernel stays as the
 // general / traced variant.
 // ------------------------------------------------------------------------------------------------------------
+// ReLU of an MFMA result as a signed-integer max: negative floats (sign bit set) are negative integers, -0 included.  One
+// VALU op; fmaxf first canonicalises the (not provably canonical) MFMA output with a second v_max per element -- 32 extra
+// VALU instructions per 64-edge chunk.  NaN inputs: a positive NaN stays, a negative one becomes 0 (fmaxf gives 0 for both).
+__device__ __forceinline__ float relu_bits(float x) { return __int_as_float(max(__float_as_int(x), 0)); }
+
+#ifdef GNNCCA_FAST_WAVES   // diagnostic builds: force the register budget of N waves per SIMD
+#define GNNCCA_FAST_ATTR __attribute__((amdgpu_waves_per_eu(GNNCCA_FAST_WAVES, GNNCCA_FAST_WAVES)))
+#else
+#define GNNCCA_FAST_ATTR
+#endif
 template <bool FIRST, bool CLS, bool MSG, bool PD_LDS, bool EBF16>
-__global__ __launch_bounds__(256) void mpn_step_fast_kernel(const StepParams p) {
+__global__ __launch_bounds__(256) GNNCCA_FAST_ATTR void mpn_step_fast_kernel(const StepParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_proj = smem;                                   // [32][48]   (MSG)
     float* s_part = s_proj + (MSG ? kH * kProjOut : 0);     // [4][32]
@@ -80,6 +90,13 @@ __global__ __launch_bounds__(256) void mpn_step_fast_kernel(const StepParams p) 
     if (MSG || PD_LDS) __syncthreads();
     GNNCCA_STAMP(p.stamp_slot, 2);
     if (!active) seg_s = seg_t = 0;
+    // Edge-state slot of sorted edge kk: kk + eoff.  Padded layout (big, nearly regular batches): the node's segment starts at
+    // node * ell_S, a multiple of 128 B in every feature plane, so no line of the state is shared by two segments (with the
+    // compact order a wave's 256-B accesses straddle three lines and every boundary line crosses the fabric twice: 12-27 %
+    // more bytes than the algorithm needs).  The plan has checked every degree against ell_S; if one did not fit
+    // (GNNCCA_GRAPH_IRREGULAR) or the rows were not sorted, every step of this forward uses the compact order.
+    const long long eoff = (p.ell_S > 0 && !(gflags & (GNNCCA_GRAPH_UNSORTED | GNNCCA_GRAPH_IRREGULAR)))
+                               ? (long long)node * p.ell_S - seg_s : 0ll;
 
     f32x16 acc;  // 'sum' / 'mean' only: 'max' takes the general kernel
 #pragma unroll
@@ -107,13 +124,13 @@ __global__ __launch_bounds__(256) void mpn_step_fast_kernel(const StepParams p) 
             const unsigned* __restrict__ e2 = reinterpret_cast<const unsigned*>(p.e);
 #pragma unroll
             for (int f = 0; f < kEF / 2; ++f) {
-                const unsigned w = e2[(size_t)f * p.e_stride + kk];
+                const unsigned w = e2[(size_t)f * p.e_stride + kk + eoff];
                 c.raw[2 * f] = __uint_as_float(w << 16);
                 c.raw[2 * f + 1] = __uint_as_float(w & 0xFFFF0000u);
             }
         } else {
 #pragma unroll
-            for (int f = 0; f < kEF; ++f) c.raw[f] = p.e[(size_t)f * p.e_stride + kk];
+            for (int f = 0; f < kEF; ++f) c.raw[f] = p.e[(size_t)f * p.e_stride + kk + eoff];
         }
     };
     // phase B: the gather that depends on the target id
@@ -175,11 +192,11 @@ __global__ __launch_bounds__(256) void mpn_step_fast_kernel(const StepParams p) 
                     bf16x2_t pk;  // round to nearest even (v_cvt_pk_bf16_f32)
                     pk[0] = (__bf16)en[2 * f];
                     pk[1] = (__bf16)en[2 * f + 1];
-                    e2[(size_t)f * p.e_stride + k] = __builtin_bit_cast(unsigned, pk);
+                    e2[(size_t)f * p.e_stride + k + eoff] = __builtin_bit_cast(unsigned, pk);
                 }
             } else {
 #pragma unroll
-                for (int f = 0; f < kEF; ++f) p.e[(size_t)f * p.e_stride + k] = en[f];
+                for (int f = 0; f < kEF; ++f) p.e[(size_t)f * p.e_stride + k + eoff] = en[f];
             }
         }
         if (CLS) {
@@ -211,14 +228,14 @@ __global__ __launch_bounds__(256) void mpn_step_fast_kernel(const StepParams p) 
             }
             if (base + 64 <= seg_t) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) acc[i] += fmaxf(d0[i], 0.f) + fmaxf(d1[i], 0.f);
+                for (int i = 0; i < 16; ++i) acc[i] += relu_bits(d0[i]) + relu_bits(d1[i]);
             } else {
                 const int rem = seg_t - base - 4 * half;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const int eo = (i & 3) + 8 * (i >> 2);
-                    const float m0 = (eo < rem) ? fmaxf(d0[i], 0.f) : 0.f;
-                    const float m1 = (eo + 32 < rem) ? fmaxf(d1[i], 0.f) : 0.f;
+                    const float m0 = (eo < rem) ? relu_bits(d0[i]) : 0.f;
+                    const float m1 = (eo + 32 < rem) ? relu_bits(d1[i]) : 0.f;
                     acc[i] += m0 + m1;
                 }
             }

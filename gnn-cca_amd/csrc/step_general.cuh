@@ -41,6 +41,11 @@ struct StepParams {
     int off_fast;
     int cls_layers, cls_hidden;  // cls_layers == 0: this step does not classify
     int N, E, edge_in, attr_vec, first, update, agg, reatt_n, wps, store_e, hin, pd_lds, stamp_slot, e_bf16;
+    // padded edge-state layout of big, nearly regular batches: node i owns the slots [i * ell_S, (i + 1) * ell_S) of every
+    // feature plane (ell_S a multiple of 32 floats = one 128-B line), so no line is shared by two segments; 0: compact
+    // CSR order.  Chosen by the host from E/N alone; the plan raises GNNCCA_GRAPH_IRREGULAR when a degree exceeds it and
+    // the kernels then use the compact order for this forward.
+    int ell_S;
 };
 
 template <bool REATT_E, bool MSG, bool AGG_MAX>

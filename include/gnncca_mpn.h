@@ -92,6 +92,8 @@ typedef struct gnncca_trace {
 /* Bits of the per-call graph flag word (device side, read back with gnncca_read_graph_flags). */
 #define GNNCCA_GRAPH_UNSORTED 1u   /* `row` was not non-decreasing: the stable device sort ran     */
 #define GNNCCA_GRAPH_BAD_INDEX 2u  /* an index outside [0,N): kernels skipped, logits set to NaN   */
+#define GNNCCA_GRAPH_IRREGULAR 4u  /* informational: a big batch with a degree above the padded edge-state
+                                      stride chosen from E/N; the step kernels used the compact layout */
 
 GNNCCA_API int gnncca_abi_version(void);
 GNNCCA_API const char* gnncca_status_string(int status);

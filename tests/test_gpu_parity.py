@@ -321,3 +321,78 @@ def test_concurrent_streams_one_module():
     for s in range(3):
         for o, r in zip(outs[s], alone[s]):
             assert torch.equal(o, r), s
+
+
+# ---- padded edge-state layout of big, nearly regular batches (StepParams::ell_S, csrc/step_fast.cuh) -------------------
+def _union(sizes, rng, extra=None):
+    """Disjoint union of dense graphs of the given sizes (+ optional extra (x-rows, edge list) appended at the end)."""
+    xs, eis, off = [], [], 0
+    for n in sizes:
+        eis.append(_dense_graph(n, off))
+        off += n
+    n_extra = 0
+    if extra is not None:
+        n_extra, e_extra = extra
+        eis.append(e_extra + off)
+        off += n_extra
+    x = rng.standard_normal((off, 2048)).astype(np.float32)
+    x /= np.linalg.norm(x, axis=0, keepdims=True)
+    ei = np.concatenate(eis, axis=1).astype(np.int64)
+    ea = rng.random((ei.shape[1], 4)).astype(np.float32)
+    return x, ei, ea
+
+
+@pytest.mark.parametrize("agg,edge_state", [("sum", "fp32"), ("mean", "fp32"), ("sum", "bf16")])
+def test_padded_layout_ragged_batch_vs_oracle(agg, edge_state):
+    """45 dense graphs of 120..129 nodes (E ~ 0.69 M >= 2^19, degrees 119..128, 97 % fill): the step kernels keep the edge
+    state in the padded layout (128 slots per node).  Degrees differ from node to node, every segment ends in padding."""
+    params, arch, sd = _default_model(1.0 / 124, node_agg_fn=agg)
+    rng = np.random.default_rng(5)
+    sizes = [120 + (7 * g) % 10 for g in range(45)]
+    x, ei, ea = _union(sizes, rng)
+    assert ei.shape[1] >= 1 << 19
+    ref = NumpyOracle(params, arch, sd, np.float32).forward(x, ei, ea)
+    m = build(params, arch, sd)
+    m.edge_state_dtype = edge_state
+    with torch.no_grad():
+        out = m(Data(torch.from_numpy(x).cuda(), torch.from_numpy(ei).cuda(), torch.from_numpy(ea).cuda()))["classified_edges"]
+    torch.cuda.synchronize()
+    assert m.graph_flags() == 0
+    tol = TOL if edge_state == "bf16" else TOL_TIGHT * 2
+    for o, r in zip(out, ref):
+        assert np.abs(o.cpu().numpy() - r).max() <= tol
+
+
+def test_padded_layout_overflow_falls_back_to_compact_order():
+    """60 dense128 graphs + one hub with 400 out-edges to 400 leaves (which have none): E/N still says 128 slots per node,
+    the hub does not fit.  The plan raises GNNCCA_GRAPH_IRREGULAR (bit 2 of the flag word, informational) and every step
+    uses the compact order -- same logits as the oracle; zero-degree nodes included."""
+    params, arch, sd = _default_model(1.0 / 127)
+    rng = np.random.default_rng(6)
+    hub = np.stack([np.zeros(400, dtype=np.int64), np.arange(1, 401, dtype=np.int64)])
+    x, ei, ea = _union([128] * 60, rng, extra=(401, hub))
+    ref = NumpyOracle(params, arch, sd, np.float32).forward(x, ei, ea)
+    m = build(params, arch, sd)
+    with torch.no_grad():
+        out = m(Data(torch.from_numpy(x).cuda(), torch.from_numpy(ei).cuda(), torch.from_numpy(ea).cuda()))["classified_edges"]
+    torch.cuda.synchronize()
+    assert m.graph_flags() == 4
+    for o, r in zip(out, ref):
+        assert np.abs(o.cpu().numpy() - r).max() <= TOL_TIGHT * 2
+
+
+def test_padded_layout_unsorted_rows_fall_back():
+    """The same kind of batch with its edge list shuffled: UNSORTED -> the stable device sort + compact order."""
+    params, arch, sd = _default_model(1.0 / 127)
+    rng = np.random.default_rng(7)
+    x, ei, ea = _union([128] * 36, rng)
+    perm = rng.permutation(ei.shape[1])
+    ei, ea = np.ascontiguousarray(ei[:, perm]), np.ascontiguousarray(ea[perm])
+    ref = NumpyOracle(params, arch, sd, np.float32).forward(x, ei, ea)
+    m = build(params, arch, sd)
+    with torch.no_grad():
+        out = m(Data(torch.from_numpy(x).cuda(), torch.from_numpy(ei).cuda(), torch.from_numpy(ea).cuda()))["classified_edges"]
+    torch.cuda.synchronize()
+    assert m.graph_flags() & 1
+    for o, r in zip(out, ref):
+        assert np.abs(o.cpu().numpy() - r).max() <= TOL_TIGHT * 4

@@ -29,7 +29,7 @@ def run(tag, sub, extra, bench_args):
 
 def main():
     tag = sys.argv[1]
-    bench_args = sys.argv[sys.argv.index("--") + 1:] + ["--no-cpu-baseline", "--no-scale-probe", "--profile-reps", "0"]
+    bench_args = sys.argv[sys.argv.index("--") + 1:] + ["--no-cpu-baseline", "--no-scale-probe", "--no-config4", "--profile-reps", "0"]
     summary = {"command": "python3 bench.py " + " ".join(bench_args), "kernels": {}}
     d = run(tag, "trace", ["--kernel-trace", "--stats"], bench_args)
     stats = glob.glob(os.path.join(d, "*", "*kernel_stats.csv"))

@@ -8,6 +8,7 @@ import csv
 import glob
 import json
 import os
+import shutil
 import signal
 import subprocess
 import sys
@@ -17,11 +18,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def main():
     kern, groups = sys.argv[1], [g.split(",") for g in sys.argv[2].split(";")]
-    bench_args = sys.argv[sys.argv.index("--") + 1:] + ["--no-cpu-baseline", "--no-scale-probe", "--profile-reps", "0", "--mode", "eager",
+    bench_args = sys.argv[sys.argv.index("--") + 1:] + ["--no-cpu-baseline", "--no-scale-probe", "--no-config4", "--profile-reps", "0", "--mode", "eager",
                                                          "--steps", "30", "--warmup", "5"]
     res = {}
     for gi, grp in enumerate(groups):
         out = os.path.join(ROOT, "gpurun_out", "pmc_kernel", f"g{gi}")
+        shutil.rmtree(out, ignore_errors=True)   # a previous run's CSVs must not be averaged in
         os.makedirs(out, exist_ok=True)
         cmd = ["rocprofv3", "--pmc"] + grp + ["--output-format", "csv", "-d", out, "--", "python3", os.path.join(ROOT, "bench.py")] + bench_args
         with open(os.path.join(out, "run.log"), "w") as log:
