@@ -228,14 +228,57 @@ __global__ __launch_bounds__(256) void enc_gemm_split_direct_kernel(const float*
 // ------------------------------------------------------------------------------------------------------------
 constexpr int kLdsGemmRows = 256;
 constexpr size_t kLdsGemmBytes = (size_t)2 * 3 * (kLdsGemmRows + 128) * 32 * 2;  // 147 456
+
+// What the fused epilogue of the un-split launch needs (enc_gemm_split_lds_kernel<true>): the rest of encoder.node_mlp and the
+// step-1 projections, applied to the 256 x 128 tile while it is still on chip -- no [N][128] partial goes to HBM and comes
+// back, and the wave-per-node tail kernel (63 us at N = 65 536, 0.11 of HBM peak) disappears from that regime.
+struct EncFuseParams {
+    const float* b1;       // [128]      bias of the first encoder layer
+    const float* W2;       // [32][128]  last encoder layer, row-major [out][in]
+    const float* b2;       // [32]
+    const float* projwT;   // [32][48]   per-node projection, k-major (BlobHeader::proj_wT)
+    const float* projb;    // [48]
+    float* h0;             // [N][32]
+    float* trace_h;        // [N][32] or null
+    float* pd_out;         // [N][8]
+    float* psq_out;        // [N][40]
+    int relu_prev;
+    // second half of the graph plan (plan_finish), run by the LAST workgroup of the launch -- the plan blocks were launched before
+    const long long* ei;
+    int* seg_ptr;
+    int* col32;
+    int* perm;
+    int* cursor;
+    unsigned* flags;
+    const unsigned* blockflags;
+    int E;
+};
+
+// Main loop: top of iteration kt = global loads of chunk kt + 1 (x: 4 x 16 B per thread, W pieces: 3 x 16 B), middle = the
+// MFMAs of chunk kt from LDS stage kt & 1, bottom = conversion + LDS store of chunk kt + 1, one barrier.  Measured and NOT
+// kept (round 2, N = 65 536, same box): waves 4-7 running [convert][MFMA] against waves 0-3 [MFMA][convert] (the stagger of
+// MI355X_MICROARCH's "two waves that run the same program") 202 -> 220 us; x two chunks ahead in a second register set
+// 202 -> 216 us.  Ablations of the same build: no MFMAs and no LDS reads at all 160 us; x re-read from L2 instead of HBM 183 us;
+// no conversion / LDS stores 183 us -- the kernel is bound by its x stream, not by the matrix pipe: walking a 256-row tile in
+// 128-B-per-row chunks with one workgroup per CU streams at 4.4 TB/s even in a bare copy loop (tools/ubench_rowtile.hip:
+// 122 us for these 537 MB; a linear sweep of the same bytes 86 us).
+template <bool FUSE>
 __global__ __launch_bounds__(512) void enc_gemm_split_lds_kernel(const float* __restrict__ x, const unsigned short* __restrict__ w3,
-                                                                 float* __restrict__ out, int M, int K, int O, int kslice) {
+                                                                 float* __restrict__ out, int M, int K, int O, int kslice,
+                                                                 const EncFuseParams fp) {
     constexpr int BK = 32, RA = kLdsGemmRows, RB = 128;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     __bf16* sa = reinterpret_cast<__bf16*>(lds_raw);                 // [2][3][RA][32]
     __bf16* sb = sa + (size_t)2 * 3 * RA * BK;                       // [2][3][RB][32]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1, h = lane >> 5, l32 = lane & 31;
+    if (FUSE && blockIdx.x == gridDim.x - 1) {   // the plan workgroup (its first four waves: plan_finish is written for 256 threads)
+        if (tid < 256)
+            plan_finish(fp.ei, fp.E, M, fp.seg_ptr, fp.col32, fp.perm, fp.cursor, fp.flags, fp.blockflags,
+                        reinterpret_cast<unsigned*>(lds_raw));
+        return;
+    }
     const int row0 = blockIdx.x * RA;
     const int kbeg = blockIdx.y * kslice;
     const int nk = min(kslice, K - kbeg) / BK;
@@ -255,11 +298,13 @@ __global__ __launch_bounds__(512) void enc_gemm_split_lds_kernel(const float* __
         wdst[u] = (p * RB + col) * BK + ((kc ^ ((col >> 2) & 3)) << 3);
     }
     const size_t wchunk = (size_t)3 * O * BK;  // bf16 elements per k-chunk of w3
-    f32x4 xreg[4];
+    f32x4 xr[4];
     bf16x8 wreg[3];
-    auto load_next = [&](int kt) {
+    auto load_x = [&](int kt) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) xreg[u] = *reinterpret_cast<const f32x4*>(xsrc[u] + kt * BK);
+        for (int u = 0; u < 4; ++u) xr[u] = *reinterpret_cast<const f32x4*>(xsrc[u] + kt * BK);
+    };
+    auto load_w = [&](int kt) {
 #pragma unroll
         for (int u = 0; u < 3; ++u)
             wreg[u] = *reinterpret_cast<const bf16x8*>(w3 + (size_t)(kbeg / BK + kt) * wchunk + (size_t)(tid + 512 * u) * 8);
@@ -272,7 +317,7 @@ __global__ __launch_bounds__(512) void enc_gemm_split_lds_kernel(const float* __
             bf16x4 p0, p1, p2;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const float v = xreg[u][q];
+                const float v = xr[u][q];
                 const __bf16 h0 = (__bf16)v;
                 const float r1 = v - (float)h0;
                 const __bf16 h1 = (__bf16)r1;
@@ -301,12 +346,7 @@ __global__ __launch_bounds__(512) void enc_gemm_split_lds_kernel(const float* __
         arow[t] = ra * BK, aswz[t] = (ra >> 2) & 3;
         brow[t] = cb * BK, bswz[t] = (cb >> 2) & 3;
     }
-    load_next(0);
-    store_stage(0);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int stage = kt & 1;
-        if (kt + 1 < nk) load_next(kt + 1);
+    auto mfma_chunk = [&](int stage) {
         const __bf16* a = sa + (size_t)stage * 3 * RA * BK;
         const __bf16* b = sb + (size_t)stage * 3 * RB * BK;
 #pragma unroll
@@ -333,21 +373,125 @@ __global__ __launch_bounds__(512) void enc_gemm_split_lds_kernel(const float* __
                     acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[rt][0], bf[ct][0], acc[rt][ct], 0, 0, 0);
                 }
         }
-        if (kt + 1 < nk) store_stage(stage ^ 1);
+    };
+    load_w(0);
+    load_x(0);
+    store_stage(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) {
+            load_w(kt + 1);
+            load_x(kt + 1);
+        }
+        mfma_chunk(kt & 1);
+        if (kt + 1 < nk) store_stage((kt + 1) & 1);
         __syncthreads();
     }
-    float* __restrict__ dst = out + (size_t)blockIdx.y * M * O;
+    if (!FUSE) {
+        float* __restrict__ dst = out + (size_t)blockIdx.y * M * O;
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                const int col = wc * 64 + ct * 32 + l32;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int row = row0 + wr * 64 + rt * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    if (row < M) dst[(size_t)row * O + col] = acc[rt][ct][i];
+                }
+            }
+        return;
+    }
+    // ---- fused epilogue (O == 128, un-split): h1 = [ReLU](acc + b1) -> LDS -> h0 = ReLU(h1 W2^T + b2) -> projections ----------
+    // every MFMA below is v_mfma_f32_32x32x2_f32: exact fp32 FMA chains, as in the tail kernels
+    constexpr int LD1 = 132, LD0 = 36;   // row strides (floats): ds_read_b128 of 16 consecutive rows hits 64 distinct banks
+    float* H1 = reinterpret_cast<float*>(lds_raw);   // [256][132] = 135 KB, over the (dead) stages: the loop ended with a barrier
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {
             const int col = wc * 64 + ct * 32 + l32;
+            const float bias = fp.b1[col];
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const int row = row0 + wr * 64 + rt * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                if (row < M) dst[(size_t)row * O + col] = acc[rt][ct][i];
+                const int rl = wr * 64 + rt * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                const float v = acc[rt][ct][i] + bias;
+                H1[rl * LD1 + col] = fp.relu_prev ? fmaxf(v, 0.f) : v;
             }
         }
+    __syncthreads();
+    // layer 2: wave w owns rows [32 w, 32 w + 32); lane (m, h) feeds k = 64 c + 32 h + s at step s of chunk c to BOTH operands
+    float* hblk = H1 + (size_t)wave * 32 * LD1;
+    f32x16 d;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) d[i] = 0.f;
+    {
+        const float* hrow = hblk + l32 * LD1 + 32 * h;
+        const float* w2row = fp.W2 + (size_t)l32 * 128 + 32 * h;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            float av[32], bv[32];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const f32x4 a4 = *reinterpret_cast<const f32x4*>(hrow + 64 * c + 4 * j);
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(w2row + 64 * c + 4 * j);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) av[4 * j + q] = a4[q], bv[4 * j + q] = b4[q];
+            }
+#pragma unroll
+            for (int s = 0; s < 32; ++s) d = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[s], d, 0, 0, 0);
+        }
+    }
+    // h0 in accumulator layout: lane = channel n, register i = row (i & 3) + 8 (i >> 2) + 4 h of the wave's 32
+    const float bias2 = fp.b2[l32];
+    float* H0 = hblk;   // [32][36], over this wave's own (consumed) rows of H1
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int rl = (i & 3) + 8 * (i >> 2) + 4 * h;
+        const float v = fmaxf(d[i] + bias2, 0.f);
+        H0[rl * LD0 + l32] = v;
+        const int row = row0 + wave * 32 + rl;
+        if (row < M) {
+            fp.h0[(size_t)row * kH + l32] = v;
+            if (fp.trace_h) fp.trace_h[(size_t)row * kH + l32] = v;
+        }
+    }
+    // projections: P[row][slot] = sum_k h0[row][k] Wp[slot][k]; lane (m, h) feeds k = 16 h + s at step s
+    float a2[16];
+    {
+        const float* hr = H0 + l32 * LD0 + 16 * h;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 a4 = *reinterpret_cast<const f32x4*>(hr + 4 * j);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a2[4 * j + q] = a4[q];
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int slot = 32 * t + l32;
+        const bool on = slot < kProjOut;
+        float b2v[16];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) b2v[s] = on ? fp.projwT[(16 * h + s) * kProjOut + slot] : 0.f;
+        f32x16 pacc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) pacc[i] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[s], b2v[s], pacc, 0, 0, 0);
+        const float pb = on ? fp.projb[slot] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = row0 + wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+            if (row < M && on) {
+                const float v = pacc[i] + pb;
+                if (slot < kPdStride)
+                    fp.pd_out[(size_t)row * kPdStride + slot] = v;
+                else
+                    fp.psq_out[(size_t)row * kPsQStride + slot - kPdStride] = v;
+            }
+        }
+    }
 }
 
 // act[M][O] = [ReLU](bias + sum_ks part[ks][M][O]) -- only for encoders deeper than two layers.
@@ -613,6 +757,141 @@ __global__ __launch_bounds__(256) void enc_tail_fast_kernel(const TailParams p) 
     }
 }
 
+
+
+// ------------------------------------------------------------------------------------------------------------
+// Encoder tail on the matrix pipe, for batches whose first GEMM ran split-K (4096 <= N, partial slabs in HBM): a
+// 256-thread workgroup finishes 32 nodes.
+//   1. every thread sums its 16 columns of one node over the ks slabs (whole 512-B rows, four 16-B loads per slab, all
+//      slabs in flight), adds the bias, applies ReLU and parks h1 [32][128] in LDS;
+//   2. layer 2 (128 -> 32) as v_mfma_f32_32x32x2_f32 (exact fp32 FMA chains): wave w takes k in [32 w, 32 w + 32) -- the
+//      A operand straight from LDS (row stride 132 floats: ds_read_b128 of 16 rows hits 64 distinct banks), the B operand
+//      straight from the row-major W2 in the blob -- and the four partial tiles are summed in fixed order;
+//   3. the step-1 projections (32 -> 48) the same way by waves 0 and 1.
+// The wave-per-node VALU + LDS form it replaces took 15 us at N = 8 192 and 22 us at N = 16 384 (63 us at 65 536, where the
+// GEMM's fused epilogue now does this work).  Same plan workgroup as the other tails.
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void enc_tail_mfma_kernel(const TailParams p, const float* __restrict__ W2rm) {
+    constexpr int F = 128, LD1 = 132, LDP = 33, LD0 = 36;
+    __shared__ __attribute__((aligned(16))) float s_h1[32 * LD1];
+    __shared__ __attribute__((aligned(16))) float s_dp[4 * 32 * LDP];
+    __shared__ __attribute__((aligned(16))) float s_h0[32 * LD0];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const float* __restrict__ blob = p.blob;
+    if (blockIdx.x == gridDim.x - 1) {  // the plan workgroup: fold the per-block findings, repair if needed
+        __shared__ unsigned smem[1024];
+        plan_finish(p.ei, p.E, p.N, p.seg_ptr, p.col32, p.perm, p.cursor, p.flags, p.blockflags, smem);
+        return;
+    }
+    const int node0 = blockIdx.x * 32;
+    const int l32 = lane & 31, h = lane >> 5;
+    // ---- 1. slab sum + bias + ReLU -> LDS -------------------------------------------------------------------------------------
+    {
+        // thread (node nl, t = tid & 7) owns the columns 32 j + 4 t .. + 3, j = 0..3: for a fixed j the eight threads of a row read
+        // one whole 128-B line (16 columns in a row per thread would touch every line of the row in every instruction)
+        const int nl = tid >> 3, c0 = (tid & 7) * 4;
+        const int node = min(node0 + nl, p.N - 1);
+        const float* __restrict__ src = p.part + (size_t)node * F + c0;
+        const size_t sstride = (size_t)p.N * F;
+        f32x4 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const f32x4*>(blob + p.off_prev_b + c0 + 32 * j);
+        for (int s0 = 0; s0 < p.ks; s0 += 8) {   // eight slabs (32 loads) in flight, summed in slab order
+            f32x4 t[8][4];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    t[u][j] = (s0 + u < p.ks) ? *reinterpret_cast<const f32x4*>(src + (size_t)(s0 + u) * sstride + 32 * j)
+                                              : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] += t[u][j];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (p.relu_prev) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[j][q] = fmaxf(v[j][q], 0.f);
+            }
+            *reinterpret_cast<f32x4*>(s_h1 + nl * LD1 + c0 + 32 * j) = v[j];
+        }
+    }
+    __syncthreads();
+    // ---- 2. layer 2, k split over the four waves: lane (m, h) feeds k = 32 w + 16 h + s at step s to both operands -----------
+    {
+        const float* hr = s_h1 + l32 * LD1 + 32 * wave + 16 * h;
+        const float* wr = W2rm + (size_t)l32 * F + 32 * wave + 16 * h;
+        float av[16], bv[16];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 a4 = *reinterpret_cast<const f32x4*>(hr + 4 * j);
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(wr + 4 * j);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) av[4 * j + q] = a4[q], bv[4 * j + q] = b4[q];
+        }
+        f32x16 d;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) d[i] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) d = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[s], d, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s_dp[(wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * h) * LDP + l32] = d[i];
+    }
+    __syncthreads();
+    {
+        const int r = tid >> 3, c4 = (tid & 7) * 4;
+        const int node = node0 + r;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c = c4 + q;
+            float v = s_dp[r * LDP + c];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) v += s_dp[(w * 32 + r) * LDP + c];
+            v = fmaxf(v + blob[p.off_last_b + c], 0.f);
+            s_h0[r * LD0 + c] = v;
+            if (node < p.N) {
+                p.h0[(size_t)node * kH + c] = v;
+                if (p.trace_h) p.trace_h[(size_t)node * kH + c] = v;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- 3. projections: column tile t = wave (slots 32 t .. 32 t + 31), lane (m, h) feeds k = 16 h + s ---------------------------
+    if (wave < 2) {
+        const int slot = 32 * wave + l32;
+        const bool on = slot < kProjOut;
+        float a2[16], b2[16];
+        const float* hr = s_h0 + l32 * LD0 + 16 * h;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 a4 = *reinterpret_cast<const f32x4*>(hr + 4 * j);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a2[4 * j + q] = a4[q];
+        }
+#pragma unroll
+        for (int s = 0; s < 16; ++s) b2[s] = on ? blob[p.off_projwT + (16 * h + s) * kProjOut + slot] : 0.f;
+        f32x16 pacc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) pacc[i] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[s], b2[s], pacc, 0, 0, 0);
+        const float pb = on ? blob[p.off_projb + slot] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int node = node0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+            if (node < p.N && on) {
+                const float v = pacc[i] + pb;
+                if (slot < kPdStride)
+                    p.pd_out[(size_t)node * kPdStride + slot] = v;
+                else
+                    p.psq_out[(size_t)node * kPsQStride + slot - kPdStride] = v;
+            }
+        }
+    }
+}
 
 
 }  // namespace gnncca

@@ -122,6 +122,9 @@ struct Workspace {
 // Padded edge-state stride for big, nearly regular batches: a pure function of (dims, N, E) -- the host never reads the
 // graph back; the plan kernel validates the degrees against it on the device (GNNCCA_GRAPH_IRREGULAR).
 int ell_stride(const gnncca_mpn_dims* d, int64_t n, int64_t e);
+// Split-K factor of the 256-row split-bf16 encoder GEMM (N >= 16 384): 1 = un-split with the fused epilogue, else 2 / 4 / 8
+// partial slabs for the tail kernel.  One workgroup per CU (144 KB of LDS), so the cost is counted in ROUNDS of 256 workgroups.
+int enc_lds_ksplit(int64_t n_nodes, int K);
 Workspace carve(const gnncca_mpn_dims* d, int64_t n, int64_t e);
 
 }  // namespace gnncca

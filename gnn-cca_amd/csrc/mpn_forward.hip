@@ -101,6 +101,7 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
     const int n_gemm = nl == 1 ? 1 : nl - 1;
     const float* cur_in = x;
     int ks_last = 1;
+    bool fused_tail = false;   // the GEMM launch already produced h0 and the step-1 projections
     for (int g = 0; g < n_gemm; ++g) {
         const gnncca_layer& l = d->enc_node.layers[g];
         const int K = l.in_dim, O = l.out_dim;
@@ -121,35 +122,9 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
         ep.nrt = (N + 31) / 32;
         ep.nks = ks;
         ep.gemm_blocks = split ? 0 : ep.nrt * ks * ((O + 127) / 128);
-        int ks_split = 1;
-        if (split) {  // big batches: split-bf16 MFMA GEMM; the plan gets its own launch
-            const unsigned short* w3 = reinterpret_cast<const unsigned short*>(blob + hdr.enc_w3);
-            static const bool force_direct = std::getenv("GNNCCA_GEMM_DIRECT") != nullptr;  // diagnostics: A/B the two GEMMs
-            if (N >= 16384 && O == 128 && !force_direct) {
-                // 256-row workgroups, both operands through LDS (144 KB: one workgroup per CU, 8 waves); split-K until every
-                // CU has one
-                while (ks_split < ws.ksplit && ((N + 255) / 256) * ks_split < 256 && (K / (ks_split * 2)) % 32 == 0) ks_split *= 2;
-                static thread_local int attr_dev = -1;  // once per device and thread: the attribute is per device
-                int dev = 0;
-                HIP_TRY(hipGetDevice(&dev));
-                if (attr_dev != dev) {
-                    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(enc_gemm_split_lds_kernel),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsGemmBytes));
-                    attr_dev = dev;
-                }
-                GNNCCA_LAUNCH(enc_gemm_split_lds_kernel, dim3((N + 255) / 256, ks_split), dim3(512), kLdsGemmBytes, st, cur_in,
-                                   w3, part, N, K, O, K / ks_split);
-            } else {
-                // 128-row workgroups (a wave = 32 rows x 128 columns); split-K until >= 512 workgroups are in flight
-                while (ks_split < ws.ksplit && ((N + 127) / 128) * ks_split < 512 && (K / (ks_split * 2)) % 32 == 0) ks_split *= 2;
-                GNNCCA_LAUNCH(enc_gemm_split_direct_kernel, dim3((N + 127) / 128, ks_split), dim3(256), 0, st, cur_in, w3, part,
-                                   N, K, O, K / ks_split);
-            }
-            HIP_TRY(hipGetLastError());
-            PROF_MARK(GNNCCA_K_ENC_GEMM);
-        }
         int plan_blocks = 0;
-        if (g == 0 && E > 0) {  // the graph plan rides in the first GEMM launch
+        bool plan_launched = false;
+        if (g == 0 && E > 0) {  // the graph plan rides in the first GEMM launch (small graphs) or gets its own (batches)
             ep.ei = reinterpret_cast<const long long*>(edge_index);
             ep.seg_ptr = seg_ptr;
             ep.col32 = col32;
@@ -159,7 +134,75 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
             ep.ell_S = use_ell ? ws.ell_S : 0;
             plan_blocks = plan_num_blocks(E);
         }
-        if (ep.gemm_blocks + plan_blocks > 0) {
+        int ks_split = 1;
+        if (split) {  // big batches: split-bf16 MFMA GEMM; the plan gets its own launch
+            const unsigned short* w3 = reinterpret_cast<const unsigned short*>(blob + hdr.enc_w3);
+            static const bool force_direct = std::getenv("GNNCCA_GEMM_DIRECT") != nullptr;  // diagnostics: A/B the two GEMMs
+            if (N >= 16384 && O == 128 && !force_direct) {
+                // 256-row workgroups, both operands through LDS (144 KB: one workgroup per CU, 8 waves); split-K by whole
+                // rounds of 256 workgroups (internal.h: enc_lds_ksplit)
+                ks_split = std::min(enc_lds_ksplit(N, K), ws.ksplit);
+                // un-split and the shipped encoder shape (2048 -> 128 -> 32, no reattach): the rest of the encoder and the step-1
+                // projections run in the GEMM's epilogue, on the tile while it is on chip
+                static const bool no_fuse = std::getenv("GNNCCA_NO_FUSE") != nullptr;  // diagnostics: A/B against GEMM + tail launch
+                fused_tail = !no_fuse && ks_split == 1 && nl == 2 && d->enc_node.layers[1].in_dim == 128 && d->enc_node.layers[1].out_dim == kH &&
+                             !d->reattach_nodes && hdr.proj_wT != 0;
+                EncFuseParams fp;
+                std::memset(&fp, 0, sizeof(fp));
+                if (fused_tail) {
+                    fp.b1 = blob + hdr.enc_node_b[0];
+                    fp.W2 = blob + hdr.enc_node_w[1];
+                    fp.b2 = blob + hdr.enc_node_b[1];
+                    fp.projwT = blob + hdr.proj_wT;
+                    fp.projb = blob + hdr.proj_b;
+                    fp.h0 = h0;
+                    fp.trace_h = trace ? trace->h_enc : nullptr;
+                    fp.pd_out = pd[0];
+                    fp.psq_out = psq[0];
+                    fp.relu_prev = l.relu;
+                    // the plan goes FIRST here, so that one extra workgroup of the GEMM launch can fold its findings (and repair
+                    // an unsorted graph): no tail launch is left in this regime
+                    fp.ei = reinterpret_cast<const long long*>(edge_index);
+                    fp.seg_ptr = seg_ptr;
+                    fp.col32 = col32;
+                    fp.perm = perm;
+                    fp.cursor = cursor;
+                    fp.flags = flags;
+                    fp.blockflags = blockflags;
+                    fp.E = E;
+                    if (plan_blocks > 0) {
+                        GNNCCA_LAUNCH(enc_gemm_plan_kernel, dim3(plan_blocks), dim3(256), 0, st, ep);
+                        HIP_TRY(hipGetLastError());
+                        PROF_MARK(GNNCCA_K_PLAN_ROWS);
+                    }
+                    plan_launched = true;
+                }
+                static thread_local int attr_dev = -1;  // once per device and thread: the attribute is per device
+                int dev = 0;
+                HIP_TRY(hipGetDevice(&dev));
+                if (attr_dev != dev) {
+                    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(enc_gemm_split_lds_kernel<false>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsGemmBytes));
+                    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(enc_gemm_split_lds_kernel<true>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsGemmBytes));
+                    attr_dev = dev;
+                }
+                if (fused_tail)
+                    GNNCCA_LAUNCH(enc_gemm_split_lds_kernel<true>, dim3((N + 255) / 256 + 1, 1), dim3(512), kLdsGemmBytes, st, cur_in, w3,
+                                  part, N, K, O, K, fp);
+                else
+                    GNNCCA_LAUNCH(enc_gemm_split_lds_kernel<false>, dim3((N + 255) / 256, ks_split), dim3(512), kLdsGemmBytes, st,
+                                  cur_in, w3, part, N, K, O, K / ks_split, fp);
+            } else {
+                // 128-row workgroups (a wave = 32 rows x 128 columns); split-K until >= 512 workgroups are in flight
+                while (ks_split < ws.ksplit && ((N + 127) / 128) * ks_split < 512 && (K / (ks_split * 2)) % 32 == 0) ks_split *= 2;
+                GNNCCA_LAUNCH(enc_gemm_split_direct_kernel, dim3((N + 127) / 128, ks_split), dim3(256), 0, st, cur_in, w3, part,
+                                   N, K, O, K / ks_split);
+            }
+            HIP_TRY(hipGetLastError());
+            PROF_MARK(GNNCCA_K_ENC_GEMM);
+        }
+        if (ep.gemm_blocks + plan_blocks > 0 && !plan_launched) {
             GNNCCA_LAUNCH(enc_gemm_plan_kernel, dim3(ep.gemm_blocks + plan_blocks), dim3(256), 0, st, ep);
             HIP_TRY(hipGetLastError());
             PROF_MARK(split ? GNNCCA_K_PLAN_ROWS : GNNCCA_K_ENC_GEMM);
@@ -217,12 +260,21 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
         // measured 15 % slower than the LDS form (72 vs 62 us at N = 65 536)
         const bool tail_fast = N < 4096 && tp.F == 128 && tp.has_last && !tp.reatt_n && tp.trace_h == nullptr && tp.vec_reduce &&
                                (reinterpret_cast<uintptr_t>(part) & 15) == 0;
-        if (tail_fast)
+        // batches whose GEMM ran split-K: the tail on the matrix pipe, 32 nodes per workgroup
+        static const bool no_mfma_tail = std::getenv("GNNCCA_NO_MFMA_TAIL") != nullptr;  // diagnostics: A/B the two tails
+        const bool tail_mfma = !fused_tail && !no_mfma_tail && N >= 8192 && tp.F == 128 && tp.has_last && nl == 2 && !tp.reatt_n &&
+                               (reinterpret_cast<uintptr_t>(part) & 15) == 0;
+        if (fused_tail) {
+            // nothing: h0, the projections and the plan's flag word all came out of the GEMM launch
+        } else if (tail_fast)
             GNNCCA_LAUNCH(enc_tail_fast_kernel, dim3(blocks), dim3(256), 0, st, tp);
+        else if (tail_mfma)
+            GNNCCA_LAUNCH(enc_tail_mfma_kernel, dim3((unsigned)((N + 31) / 32) + 1), dim3(256), 0, st, tp,
+                          blob + hdr.enc_node_w[nl - 1]);
         else
             GNNCCA_LAUNCH(enc_tail_kernel, dim3(blocks), dim3(256), std::max<size_t>(lds, 4096), st, tp);
         HIP_TRY(hipGetLastError());
-        PROF_MARK(GNNCCA_K_ENC_TAIL);
+        if (!fused_tail) PROF_MARK(GNNCCA_K_ENC_TAIL);
     }
     if (E == 0) return GNNCCA_OK;
 

@@ -561,6 +561,22 @@ int ell_stride(const gnncca_mpn_dims* d, int64_t n, int64_t e) {
     return (int)S;
 }
 
+int enc_lds_ksplit(int64_t n_nodes, int K) {
+    const int64_t b = (n_nodes + 255) / 256;               // row blocks
+    // time in units of one un-split workgroup's run (~237 us): rounds of 256 workgroups / k, + the fused epilogue (un-split) or
+    // the tail kernel's pass over the k slabs (measured: 14 us at N = 16 384 / k = 4, 76 us at 66 048 / k = 4).
+    // N = 65 536 -> 1 (256 blocks, one round); 66 048 -> 4 (258 blocks would take two rounds un-split: 2.07 vs 1.25 + 0.33);
+    // 51 200 -> 1 (200 blocks: 1.07 vs 2 / 2 + 0.15); 16 384 -> 4.
+    int best = 1;
+    double best_cost = (double)((b + 255) / 256) + 0.07;
+    for (int k = 2; k <= 8; k *= 2) {
+        if ((K / k) % 32 != 0) break;
+        const double cost = (double)((b * k + 255) / 256) / k + (0.05 + 0.07 * k) * (double)b / 256.0;
+        if (cost < best_cost - 1e-9) best = k, best_cost = cost;
+    }
+    return best;
+}
+
 Workspace carve(const gnncca_mpn_dims* d, int64_t n, int64_t e) {
     Workspace w;
     std::memset(&w, 0, sizeof(w));
@@ -578,6 +594,7 @@ Workspace carve(const gnncca_mpn_dims* d, int64_t n, int64_t e) {
     // batches run the split-bf16 GEMM with 128-row workgroups: room for its split-K factor too
     if (N >= 4096)
         while (ks < 8 && ((N + 127) / 128) * (size_t)ks < 512 && k0 / (ks * 2) >= 64) ks *= 2;
+    if (N >= 16384) ks = std::max(ks, enc_lds_ksplit((int64_t)N, k0));  // room for the slabs of the 256-row GEMM's choice
     w.ksplit = ks;
     size_t fmax = 0;
     for (int i = 0; i < d->enc_node.n_layers; ++i)

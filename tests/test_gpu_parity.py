@@ -218,11 +218,14 @@ def test_big_batch_split_bf16_encoder_vs_oracle():
         assert np.abs(o.cpu().numpy() - r).max() <= TOL_TIGHT * 2
 
 
-@pytest.mark.parametrize("n_nodes", [16384, 16384 + 77, 40000])
+@pytest.mark.parametrize("n_nodes", [8192 + 5, 16384, 16384 + 77, 40000, 51200 + 33])
 def test_lds_staged_split_gemm_vs_fp64_oracle(n_nodes):
     """N >= 16 384 nodes: the first encoder layer runs on the 256-row, both-operands-through-LDS split-bf16 GEMM
-    (ragged N exercises the clamped loads / masked stores, 40 000 the un-split k range).  A sparse ring graph keeps the
-    oracle cheap; the encoder output is judged against an fp64 evaluation, the logits against the fp32 oracle."""
+    (ragged N exercises the clamped loads / masked stores; 16 384 / 40 000 split K four ways and finish in the MFMA tail
+    kernel, 51 233 runs un-split -- 201 row blocks, one round of workgroups -- with the rest of the encoder and the step-1
+    projections in the GEMM's fused epilogue; 8 197 takes the 128-row GEMM + the MFMA tail over eight slabs).  A sparse ring
+    graph keeps the oracle cheap; the encoder output is judged against an fp64 evaluation, the logits against the fp32
+    oracle."""
     params, arch, sd = _default_model(1.0)
     rng = np.random.default_rng(n_nodes)
     x = rng.standard_normal((n_nodes, 2048)).astype(np.float32)
@@ -396,3 +399,26 @@ def test_padded_layout_unsorted_rows_fall_back():
     assert m.graph_flags() & 1
     for o, r in zip(out, ref):
         assert np.abs(o.cpu().numpy() - r).max() <= TOL_TIGHT * 4
+
+
+def test_fused_encoder_launch_repairs_unsorted_plan():
+    """N = 51 233 with a SHUFFLED sparse edge list: the fused GEMM launch's extra workgroup folds the plan's findings and
+    runs the stable sort itself (there is no tail launch in this regime); logits in the caller's edge order."""
+    params, arch, sd = _default_model(1.0)
+    n_nodes = 51200 + 33
+    rng = np.random.default_rng(99)
+    x = rng.standard_normal((n_nodes, 2048)).astype(np.float32)
+    x /= np.linalg.norm(x, axis=0, keepdims=True)
+    src = np.repeat(np.arange(n_nodes), 2)
+    dst = (src + np.tile([1, 5], n_nodes)) % n_nodes
+    perm = rng.permutation(src.shape[0])
+    ei = np.ascontiguousarray(np.stack([src, dst])[:, perm]).astype(np.int64)
+    ea = rng.random((ei.shape[1], 4)).astype(np.float32)
+    ref = NumpyOracle(params, arch, sd, np.float32).forward(x, ei, ea)
+    m = build(params, arch, sd)
+    with torch.no_grad():
+        out = m(Data(torch.from_numpy(x).cuda(), torch.from_numpy(ei).cuda(), torch.from_numpy(ea).cuda()))["classified_edges"]
+    torch.cuda.synchronize()
+    assert m.graph_flags() & 1
+    for o, r in zip(out, ref):
+        assert np.abs(o.cpu().numpy() - r).max() <= TOL_TIGHT * 2
