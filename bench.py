@@ -287,6 +287,9 @@ def main():
                          "auto: time 50 steps of each after warm-up and keep the faster (reported in config.mode)")
     ap.add_argument("--edge-state", choices=["fp32", "bf16"], default="fp32",
                     help="storage of the edge latents between steps (bf16: GNNCCA_OPT_EDGE_STATE_BF16; arithmetic stays fp32)")
+    ap.add_argument("--enc-products", type=int, choices=[6, 3], default=6,
+                    help="split-bf16 products of the first encoder layer on batches of >= 4096 nodes (3: GNNCCA_OPT_ENC_SPLIT3, "
+                         "an accuracy/speed option; the default 6 keeps fp32-level accuracy)")
     ap.add_argument("--no-scale-probe", action="store_true", help="skip the 64-graph batch probe of the step kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-config4", action="store_true", help="skip the sharded 512 x dense128 leg (BASELINE config 4)")
@@ -331,6 +334,7 @@ def main():
     # ranks start from DIFFERENT random weights (seed = rank); rank 0's are the job's after the broadcast
     model = build_model(params, args.nodes, seed=rank).to(device)
     model.edge_state_dtype = args.edge_state
+    model.encoder_products = args.enc_products
     # shared weights: ONE RCCL broadcast of rank 0's parameters over xGMI (no other collective on the path)
     if world > 1:
         from gnn_cca_amd.sharding import broadcast_weights
@@ -393,6 +397,7 @@ def main():
             from gnn_cca_amd.sharding import forward_sharded, shard_batch
             m4 = build_model(graph_net_params(L=4), 128, seed=rank).to(device)
             m4.edge_state_dtype = args.edge_state
+            m4.encoder_products = args.enc_products
             if world > 1:
                 broadcast_weights(m4, src=0)
             graphs4 = LazyDenseGraphs(args.config4_graphs, 128, device)
@@ -456,7 +461,8 @@ def main():
             "config": {"workload": f"{args.graphs} x dense{args.nodes} graph(s) per GPU per step "
                                    f"(N={N}, E={E}), feat 2048, L={args.L}, 3 classified steps, fp32 arithmetic, "
                                    f"{args.edge_state} edge state, eval",
-                       "mode": mode_used, "edge_state": args.edge_state, "outputs_finite": bool(ok),
+                       "mode": mode_used, "edge_state": args.edge_state, "encoder_products": args.enc_products,
+                       "outputs_finite": bool(ok),
                        "edge_steps_per_s": world * E * args.L * args.steps / t,
                        "timing": f"median of {len(blocks)} blocks of {args.steps} steps (each: barrier + synchronize on both "
                                  f"sides, MAX over ranks)",

@@ -47,6 +47,7 @@ class Profile(C.Structure):
 
 
 OPT_EDGE_STATE_BF16 = 1
+OPT_ENC_SPLIT3 = 2
 BWD_GRADS_ZEROED = 1
 
 

@@ -95,7 +95,10 @@ __global__ __launch_bounds__(256) void enc_gemm_plan_kernel(const EncPlanParams 
 // Every product of two bf16 values is exact in fp32 and the MFMA accumulates in fp32: measured against fp64 the
 // result is MORE accurate than an fp32 GEMM (1.9e-9 vs 1.4e-7 on the N=64 golden case), while the six
 // v_mfma_f32_32x32x16_bf16 cost 6/16 of the v_mfma_f32_32x32x2_f32 time.  (Keeping only x0w0 + x0w1 + x1w0 would
-// halve the MFMA work again at 1.2e-6 absolute error on the pre-activations -- not taken: accuracy first.)
+// halve the MFMA work again -- GNNCCA_OPT_ENC_SPLIT3, off by default.  Measured (tools/exp_enc_products.py, x ~ N(0,1),
+// N = 8 192 / 51 233): encoder output 5.0e-6 / 5.5e-6 from an fp64 evaluation instead of 3.0e-7 / 9.9e-7 (an fp32 GEMM:
+// 4.9e-7 / 5.7e-7), logits 0.9e-7 / 1.5e-7 from the fp32 oracle instead of 0.6e-7 (tolerance 1e-4); GEMM 30.8 -> 22.3 us at
+// N = 8 192, 57.7 -> 44.7 at 16 384, 225 -> 183 at 65 536.)
 // ------------------------------------------------------------------------------------------------------------
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -109,6 +112,7 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 //   bottom           : next W -> the other LDS stage, next x -> A fragments (loads had the whole middle to land)
 // Workgroup = 4 waves = 128 rows.  Split-K over blockIdx.y for mid-size batches.
 // ------------------------------------------------------------------------------------------------------------
+template <bool P3>
 __global__ __launch_bounds__(256) void enc_gemm_split_direct_kernel(const float* __restrict__ x,
                                                                     const unsigned short* __restrict__ w3,
                                                                     float* __restrict__ out, int M, int K, int O, int kslice) {
@@ -183,9 +187,11 @@ __global__ __launch_bounds__(256) void enc_gemm_split_direct_kernel(const float*
                 for (int p = 0; p < 3; ++p)
                     b[p] = *reinterpret_cast<const bf16x8*>(&wsm[stage][p][c * 32 + (lane & 31)][ks * 16 + k8]);
                 // smallest terms first
-                acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[ks][2], b[0], acc[c], 0, 0, 0);
-                acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[ks][1], b[1], acc[c], 0, 0, 0);
-                acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[ks][0], b[2], acc[c], 0, 0, 0);
+                if (!P3) {   // the three 2^-16-order terms (GNNCCA_OPT_ENC_SPLIT3 drops them)
+                    acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[ks][2], b[0], acc[c], 0, 0, 0);
+                    acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[ks][1], b[1], acc[c], 0, 0, 0);
+                    acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[ks][0], b[2], acc[c], 0, 0, 0);
+                }
                 acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[ks][1], b[0], acc[c], 0, 0, 0);
                 acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[ks][0], b[1], acc[c], 0, 0, 0);
                 acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[ks][0], b[0], acc[c], 0, 0, 0);
@@ -262,7 +268,7 @@ struct EncFuseParams {
 // no conversion / LDS stores 183 us -- the kernel is bound by its x stream, not by the matrix pipe: walking a 256-row tile in
 // 128-B-per-row chunks with one workgroup per CU streams at 4.4 TB/s even in a bare copy loop (tools/ubench_rowtile.hip:
 // 122 us for these 537 MB; a linear sweep of the same bytes 86 us).
-template <bool FUSE>
+template <bool FUSE, bool P3>
 __global__ __launch_bounds__(512) void enc_gemm_split_lds_kernel(const float* __restrict__ x, const unsigned short* __restrict__ w3,
                                                                  float* __restrict__ out, int M, int K, int O, int kslice,
                                                                  const EncFuseParams fp) {
@@ -365,9 +371,11 @@ __global__ __launch_bounds__(512) void enc_gemm_split_lds_kernel(const float* __
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct) {
                     // smallest terms first
-                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[rt][2], bf[ct][0], acc[rt][ct], 0, 0, 0);
-                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[rt][1], bf[ct][1], acc[rt][ct], 0, 0, 0);
-                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[rt][0], bf[ct][2], acc[rt][ct], 0, 0, 0);
+                    if (!P3) {   // the three 2^-16-order terms (GNNCCA_OPT_ENC_SPLIT3 drops them)
+                        acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[rt][2], bf[ct][0], acc[rt][ct], 0, 0, 0);
+                        acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[rt][1], bf[ct][1], acc[rt][ct], 0, 0, 0);
+                        acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[rt][0], bf[ct][2], acc[rt][ct], 0, 0, 0);
+                    }
                     acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[rt][1], bf[ct][0], acc[rt][ct], 0, 0, 0);
                     acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[rt][0], bf[ct][1], acc[rt][ct], 0, 0, 0);
                     acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[rt][0], bf[ct][0], acc[rt][ct], 0, 0, 0);

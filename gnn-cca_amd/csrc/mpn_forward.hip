@@ -102,6 +102,7 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
     const float* cur_in = x;
     int ks_last = 1;
     bool fused_tail = false;   // the GEMM launch already produced h0 and the step-1 projections
+    const bool split3 = (options & GNNCCA_OPT_ENC_SPLIT3) != 0;
     for (int g = 0; g < n_gemm; ++g) {
         const gnncca_layer& l = d->enc_node.layers[g];
         const int K = l.in_dim, O = l.out_dim;
@@ -181,23 +182,34 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
                 int dev = 0;
                 HIP_TRY(hipGetDevice(&dev));
                 if (attr_dev != dev) {
-                    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(enc_gemm_split_lds_kernel<false>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsGemmBytes));
-                    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(enc_gemm_split_lds_kernel<true>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsGemmBytes));
+                    const void* fns[4] = {reinterpret_cast<const void*>(enc_gemm_split_lds_kernel<false, false>),
+                                          reinterpret_cast<const void*>(enc_gemm_split_lds_kernel<true, false>),
+                                          reinterpret_cast<const void*>(enc_gemm_split_lds_kernel<false, true>),
+                                          reinterpret_cast<const void*>(enc_gemm_split_lds_kernel<true, true>)};
+                    for (const void* fn : fns)
+                        HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsGemmBytes));
                     attr_dev = dev;
                 }
-                if (fused_tail)
-                    GNNCCA_LAUNCH(enc_gemm_split_lds_kernel<true>, dim3((N + 255) / 256 + 1, 1), dim3(512), kLdsGemmBytes, st, cur_in, w3,
-                                  part, N, K, O, K, fp);
+                const dim3 fgrid((N + 255) / 256 + 1, 1), sgrid((N + 255) / 256, ks_split);
+                if (fused_tail && split3)
+                    GNNCCA_LAUNCH((enc_gemm_split_lds_kernel<true, true>), fgrid, dim3(512), kLdsGemmBytes, st, cur_in, w3, part, N, K, O, K, fp);
+                else if (fused_tail)
+                    GNNCCA_LAUNCH((enc_gemm_split_lds_kernel<true, false>), fgrid, dim3(512), kLdsGemmBytes, st, cur_in, w3, part, N, K, O, K, fp);
+                else if (split3)
+                    GNNCCA_LAUNCH((enc_gemm_split_lds_kernel<false, true>), sgrid, dim3(512), kLdsGemmBytes, st, cur_in, w3, part, N, K, O,
+                                  K / ks_split, fp);
                 else
-                    GNNCCA_LAUNCH(enc_gemm_split_lds_kernel<false>, dim3((N + 255) / 256, ks_split), dim3(512), kLdsGemmBytes, st,
-                                  cur_in, w3, part, N, K, O, K / ks_split, fp);
+                    GNNCCA_LAUNCH((enc_gemm_split_lds_kernel<false, false>), sgrid, dim3(512), kLdsGemmBytes, st, cur_in, w3, part, N, K, O,
+                                  K / ks_split, fp);
             } else {
                 // 128-row workgroups (a wave = 32 rows x 128 columns); split-K until >= 512 workgroups are in flight
                 while (ks_split < ws.ksplit && ((N + 127) / 128) * ks_split < 512 && (K / (ks_split * 2)) % 32 == 0) ks_split *= 2;
-                GNNCCA_LAUNCH(enc_gemm_split_direct_kernel, dim3((N + 127) / 128, ks_split), dim3(256), 0, st, cur_in, w3, part,
-                                   N, K, O, K / ks_split);
+                if (split3)
+                    GNNCCA_LAUNCH(enc_gemm_split_direct_kernel<true>, dim3((N + 127) / 128, ks_split), dim3(256), 0, st, cur_in, w3, part,
+                                  N, K, O, K / ks_split);
+                else
+                    GNNCCA_LAUNCH(enc_gemm_split_direct_kernel<false>, dim3((N + 127) / 128, ks_split), dim3(256), 0, st, cur_in, w3, part,
+                                  N, K, O, K / ks_split);
             }
             HIP_TRY(hipGetLastError());
             PROF_MARK(GNNCCA_K_ENC_GEMM);

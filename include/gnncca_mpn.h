@@ -171,6 +171,11 @@ GNNCCA_API int gnncca_mpn_forward_profiled(const gnncca_mpn_dims* dims, const vo
  * dominant traffic of the step kernels; honoured by the specialised kernels (shipped config shape), ignored elsewhere.
  * Measured effect on the logits: DESIGN.md section 5. */
 #define GNNCCA_OPT_EDGE_STATE_BF16 1u
+/* GNNCCA_OPT_ENC_SPLIT3: on batches of >= 4096 nodes the first encoder layer (models/mpn.py:131, 2048 -> 128) runs as a
+ * split-bf16 MFMA GEMM; by default with the six products that give fp32-level accuracy, with this option with the three
+ * leading ones (x0 w0 + x0 w1 + x1 w0): ~2^-17 relative on that layer's pre-activations (encoder output 5e-6 from fp64
+ * instead of 3e-7 .. 1e-6), measured logit deviation 1.5e-7 (tolerance 1e-4), GEMM 19-28 % faster.  Off by default. */
+#define GNNCCA_OPT_ENC_SPLIT3 2u
 GNNCCA_API int gnncca_mpn_forward_ex(const gnncca_mpn_dims* dims, const void* packed_dev, const float* x,
                                      const int64_t* edge_index, const float* edge_attr, int64_t n_nodes,
                                      int64_t n_edges, void* workspace, size_t workspace_bytes, float* logits_out,
