@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""profiles/r01_*_pmc_summary.json -> profiles/pmc_index.json, the table bench.py reads `roofline.traffic` and
+"""profiles/r<NN>_*_pmc_summary.json (the newest round that has the workload) -> profiles/pmc_index.json, the table bench.py reads `roofline.traffic` and
 `rocprof_avg_launch_us` from (keyed "<graphs>x<nodes>_L<L>[_bf16]").  The dominant kernel is the middle message-passing
 step, mpn_step_fast_kernel<FIRST=false, CLS=true, MSG=true, ...>."""
 import glob
@@ -9,7 +9,7 @@ import re
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 index = {}
-for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r01_*_pmc_summary.json"))):
+for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_*_pmc_summary.json"))):  # later rounds overwrite
     s = json.load(open(path))
     cmd = s["command"]
     def arg(name, default):
@@ -24,5 +24,8 @@ for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r01_*_pmc_summary.j
     if best:
         index[key] = {"kernel": best[0], "hbm_bytes_per_launch": best[1]["hbm_bytes_per_launch"],
                       "rocprof_avg_us": best[1]["avg_ns"] / 1e3, "source": os.path.relpath(path, ROOT)}
+        for extra in ("mfma_util", "valu_util", "wave_share_issuing", "wave_share_issue_stalled", "wave_share_waiting"):
+            if extra in best[1]:
+                index[key][extra] = best[1][extra]
 json.dump(index, open(os.path.join(ROOT, "profiles", "pmc_index.json"), "w"), indent=1)
 print(json.dumps(index, indent=1))
