@@ -139,7 +139,9 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
         if (split) {  // big batches: split-bf16 MFMA GEMM; the plan gets its own launch
             const unsigned short* w3 = reinterpret_cast<const unsigned short*>(blob + hdr.enc_w3);
             static const bool force_direct = std::getenv("GNNCCA_GEMM_DIRECT") != nullptr;  // diagnostics: A/B the two GEMMs
-            if (N >= 16384 && O == 128 && !force_direct) {
+            // measured crossover of the two GEMMs (+ their tails): N = 8 192 equal (32 us), 12 288: 51 vs 59 us, 4 096: 27 vs 21 us
+            static const int lds_min = std::getenv("GNNCCA_GEMM_LDS_MIN") ? std::atoi(std::getenv("GNNCCA_GEMM_LDS_MIN")) : 12288;
+            if (N >= lds_min && O == 128 && !force_direct) {
                 // 256-row workgroups, both operands through LDS (144 KB: one workgroup per CU, 8 waves); split-K by whole
                 // rounds of 256 workgroups (internal.h: enc_lds_ksplit)
                 ks_split = std::min(enc_lds_ksplit(N, K), ws.ksplit);

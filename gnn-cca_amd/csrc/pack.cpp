@@ -594,7 +594,7 @@ Workspace carve(const gnncca_mpn_dims* d, int64_t n, int64_t e) {
     // batches run the split-bf16 GEMM with 128-row workgroups: room for its split-K factor too
     if (N >= 4096)
         while (ks < 8 && ((N + 127) / 128) * (size_t)ks < 512 && k0 / (ks * 2) >= 64) ks *= 2;
-    if (N >= 16384) ks = std::max(ks, enc_lds_ksplit((int64_t)N, k0));  // room for the slabs of the 256-row GEMM's choice
+    if (N >= 4096) ks = std::max(ks, enc_lds_ksplit((int64_t)N, k0));  // room for the slabs of the 256-row GEMM's choice
     w.ksplit = ks;
     size_t fmax = 0;
     for (int i = 0; i < d->enc_node.n_layers; ++i)

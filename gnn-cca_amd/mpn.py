@@ -18,7 +18,24 @@ from . import _native as nat
 from .mlp import MLP
 
 
-class MetaLayer(nn.Module):
+class _Replayed(nn.Module):
+    """Base of the three top-level containers (encoder, MPNet, classifier).  They hold parameters; the arithmetic of a
+    forward runs fused inside libgnncca_mpn.so.  When a caller has registered forward hooks on one of them (the way
+    per-step latents are usually tapped from the reference), MOTMPNet.forward runs the traced native forward and then
+    REPLAYS the reference's call sequence (models/mpn.py:266-297) through ``__call__`` of these containers: each call returns
+    the tensors the fused kernels produced for it, so hooks see the same inputs and outputs as on the reference.  A
+    container called on its own, outside MOTMPNet.forward, raises."""
+
+    def _take_replayed(self, what):
+        queue = getattr(self, '_replay_queue', None)
+        if not queue:
+            raise RuntimeError(f"{what} is a parameter container here: its arithmetic runs fused inside "
+                               "MOTMPNet.forward (libgnncca_mpn.so); register forward hooks on it and call the whole "
+                               "model to observe its inputs and outputs")
+        return queue.pop(0)
+
+
+class MetaLayer(_Replayed):
     """Container mirroring models/mpn.py:10-57 (``edge_model`` / ``node_model`` children)."""
 
     def __init__(self, edge_model=None, node_model=None):
@@ -27,7 +44,7 @@ class MetaLayer(nn.Module):
         self.node_model = node_model
 
     def forward(self, x, edge_index, edge_attr):
-        raise RuntimeError("MetaLayer is a parameter container here; call MOTMPNet.forward")
+        return self._take_replayed("MetaLayer")   # (x, edge_attr), models/mpn.py:54
 
 
 class EdgeModel(nn.Module):
@@ -48,7 +65,7 @@ class NodeModel(nn.Module):
         self.node_agg_fn = node_agg_fn
 
 
-class MLPGraphIndependent(nn.Module):
+class MLPGraphIndependent(_Replayed):
     """Container mirroring models/mpn.py:103-142: an optional node MLP and an optional edge MLP."""
 
     def __init__(self, edge_in_dim=None, node_in_dim=None, edge_out_dim=None, node_out_dim=None,
@@ -60,6 +77,9 @@ class MLPGraphIndependent(nn.Module):
             self.node_mlp = MLP(node_in_dim, list(node_fc_dims) + [node_out_dim], dropout_p, use_batchnorm)
         if edge_in_dim is not None:
             self.edge_mlp = MLP(edge_in_dim, list(edge_fc_dims) + [edge_out_dim], dropout_p, use_batchnorm)
+
+    def forward(self, edge_feats=None, nodes_feats=None):
+        return self._take_replayed("MLPGraphIndependent")   # (edge_out, node_out): edge first, models/mpn.py:142
 
 
 def _raw_stream(device):
@@ -367,18 +387,26 @@ class MOTMPNet(nn.Module):
         return self._hot.workspaces
 
     # -- forward -----------------------------------------------------------------------------------------------
+    @staticmethod
+    def _check_inputs(x, edge_index, edge_attr):
+        """dtype contract of the reference: its fp32 Linear layers raise a RuntimeError on any other floating type
+        (models/mlp.py:13 via models/mpn.py:131,137) and tensor indexing wants int64 (models/mpn.py:48).  A wrong dtype is a
+        caller bug and is raised here as well instead of being converted silently; a non-contiguous VIEW of the right dtype
+        is only a layout and is copied."""
+        if x.dtype != torch.float32 or edge_attr.dtype != torch.float32:
+            raise RuntimeError(f"expected float32 node / edge features, got x {x.dtype}, edge_attr {edge_attr.dtype} "
+                               "(the module's Linear layers are float32, as in the reference)")
+        if edge_index.dtype != torch.int64:
+            raise RuntimeError(f"edge_index must be int64 (torch.long), got {edge_index.dtype}")
+        return x.contiguous(), edge_index.contiguous(), edge_attr.contiguous()
+
     def _prepare(self, x, edge_index, edge_attr):
         if not (x.is_cuda and edge_index.is_cuda and edge_attr.is_cuda):
             raise RuntimeError("gnn_cca_amd.MOTMPNet runs on MI355X only: move the module and `data` to the GPU "
                                "(there is no CPU fallback)")
         lib, d = nat.lib(), self.native_dims()
         dev = x.device
-        if x.dtype != torch.float32 or not x.is_contiguous():
-            x = x.float().contiguous()
-        if edge_attr.dtype != torch.float32 or not edge_attr.is_contiguous():
-            edge_attr = edge_attr.float().contiguous()
-        if edge_index.dtype != torch.int64 or not edge_index.is_contiguous():
-            edge_index = edge_index.long().contiguous()
+        x, edge_index, edge_attr = self._check_inputs(x, edge_index, edge_attr)
         n, e = x.shape[0], edge_index.shape[1]
         if x.dim() != 2 or x.shape[1] != d.node_in or edge_index.dim() != 2 or edge_index.shape[0] != 2 \
                 or edge_attr.dim() != 2 or edge_attr.shape[0] != e or edge_attr.shape[1] != d.edge_in:
@@ -404,8 +432,52 @@ class MOTMPNet(nn.Module):
         In train mode the outputs carry an autograd graph to the parameters (row N3)."""
         if self.training:
             return self._forward_train(data)
+        if trace is None and self._containers_hooked():
+            return self._forward_replayed(data)
         logits = self._forward_native(data.x, data.edge_index, data.edge_attr, trace)
         return {'classified_edges': list(logits.unbind(0))}
+
+    def _containers_hooked(self):
+        for m in (self.encoder, self.MPNet, self.classifier):
+            if m._forward_hooks or m._forward_pre_hooks:
+                return True
+        return False
+
+    def _forward_replayed(self, data):
+        """Forward with forward hooks registered on encoder / MPNet / classifier: the traced native forward, then the
+        reference's own call sequence (models/mpn.py:266-297) through the containers, each call handing back what the fused
+        kernels computed for it.  Hooks on deeper modules (edge_model, node_model, the MLPs) do not fire: those calls do not
+        exist as separate steps on this path."""
+        x, edge_index, edge_attr = data.x, data.edge_index, data.edge_attr
+        trace = {}
+        logits = self._forward_native(x, edge_index, edge_attr, trace)
+        L, n_cls = int(self.num_enc_steps), int(self.num_class_steps)
+        enc_q, mp_q, cls_q = [(trace['e_enc'], trace['h_enc'])], [], []
+        first_class_step = L - n_cls + 1
+        for step in range(1, L + 1):
+            mp_q.append((trace['h_steps'][step - 1], trace['e_steps'][step - 1]))
+        for i in range(logits.shape[0]):
+            cls_q.append((logits[i], None))
+        self.encoder._replay_queue, self.MPNet._replay_queue, self.classifier._replay_queue = enc_q, mp_q, cls_q
+        try:
+            latent_edge, latent_node = self.encoder(edge_attr, x)
+            initial_edge, initial_node = latent_edge, latent_node
+            out = []
+            for step in range(1, L + 1):
+                if self.reattach_initial_nodes:
+                    latent_node = torch.cat((initial_node, latent_node), dim=1)
+                if self.reattach_initial_edges:
+                    latent_edge = torch.cat((initial_edge, latent_edge), dim=1)
+                latent_node, latent_edge = self.MPNet(latent_node, edge_index, latent_edge)
+                if step >= first_class_step:
+                    dec_edge, _ = self.classifier(latent_edge)
+                    out.append(dec_edge)
+            if L == 0:
+                dec_edge, _ = self.classifier(latent_edge)
+                out.append(dec_edge)
+        finally:
+            self.encoder._replay_queue = self.MPNet._replay_queue = self.classifier._replay_queue = None
+        return {'classified_edges': out}
 
     def _classifier_batchnorm(self):
         mlp = self.classifier.edge_mlp
@@ -431,13 +503,10 @@ class MOTMPNet(nn.Module):
     def _forward_train(self, data):
         self._check_trainable()
         params = self.native_param_tensors()
-        x, edge_index, edge_attr = data.x, data.edge_index, data.edge_attr
-        if x.dtype != torch.float32 or not x.is_contiguous():
-            x = x.float().contiguous()
-        if edge_attr.dtype != torch.float32 or not edge_attr.is_contiguous():
-            edge_attr = edge_attr.float().contiguous()
-        if edge_index.dtype != torch.int64 or not edge_index.is_contiguous():
-            edge_index = edge_index.long().contiguous()
+        if not (data.x.is_cuda and data.edge_index.is_cuda and data.edge_attr.is_cuda):
+            raise RuntimeError("gnn_cca_amd.MOTMPNet runs on MI355X only: move the module and `data` to the GPU "
+                               "(there is no CPU fallback)")
+        x, edge_index, edge_attr = self._check_inputs(data.x, data.edge_index, data.edge_attr)
         logits = _MPNTrainFunction.apply(self, x.detach(), edge_index, edge_attr.detach(), *params)
         return {'classified_edges': list(logits.unbind(0))}
 

@@ -478,3 +478,61 @@ def test_bf16_edge_state_at_named_sizes(n, L):
           f"bf16 state {worst['bf16'][0]:.2e} (rel {worst['bf16'][1]:.2e})")
     assert worst["fp32"][0] <= TOL_TIGHT * 4
     assert worst["bf16"][0] <= TOL
+
+
+@pytest.mark.parametrize("name", ["terrace32", "reattach_n1e1", "steps_L0", "generic_dims"])
+def test_forward_hooks_on_containers_see_reference_tensors(name):
+    """Forward hooks on model.encoder / model.MPNet / model.classifier -- how per-step latents are tapped from the reference
+    (tests/golden/make_golden.py does exactly that) -- fire with the reference's inputs and outputs: the module replays the
+    call sequence of models/mpn.py:266-297 over the traced native forward.  Hooked and un-hooked logits are identical."""
+    params, arch, sd, a = load_case(os.path.join(GOLDEN_DIR, name + ".npz"))
+    m = build(params, arch, sd)
+    d = to_data(a)
+    with torch.no_grad():
+        plain = [t.clone() for t in m(d)["classified_edges"]]
+    seen = {"enc": [], "mp_in": [], "mp_out": [], "cls": []}
+    hooks = [m.encoder.register_forward_hook(lambda mod, i, o: seen["enc"].append(o)),
+             m.MPNet.register_forward_pre_hook(lambda mod, i: seen["mp_in"].append(i)),
+             m.MPNet.register_forward_hook(lambda mod, i, o: seen["mp_out"].append(o)),
+             m.classifier.register_forward_hook(lambda mod, i, o: seen["cls"].append(o))]
+    with torch.no_grad():
+        out = m(d)["classified_edges"]
+    for h in hooks:
+        h.remove()
+    L = int(params["num_enc_steps"])
+    assert len(seen["enc"]) == 1 and len(seen["mp_out"]) == L and len(seen["cls"]) == len(out) == int(a["n_logits"])
+    e_enc, h_enc = seen["enc"][0]                      # (edge_out, node_out): edge first (models/mpn.py:142)
+    assert np.abs(e_enc.cpu().numpy() - a["e_enc"]).max() <= TOL_TIGHT
+    assert np.abs(h_enc.cpu().numpy() - a["h_enc"]).max() <= TOL_TIGHT
+    for s in range(1, L + 1):
+        x_in, ei_in, e_in = seen["mp_in"][s - 1]
+        nf = 2 if params["reattach_initial_nodes"] else 1
+        ef = 2 if params["reattach_initial_edges"] else 1
+        assert x_in.shape[1] == nf * h_enc.shape[1] and e_in.shape[1] == ef * e_enc.shape[1] and ei_in is d.edge_index
+        h_s, e_s = seen["mp_out"][s - 1]               # (x, edge_attr) (models/mpn.py:54)
+        assert np.abs(h_s.cpu().numpy() - a[f"h_step_{s}"]).max() <= TOL_TIGHT
+        assert np.abs(e_s.cpu().numpy() - a[f"e_step_{s}"]).max() <= TOL_TIGHT
+    for (dec, none), o, p in zip(seen["cls"], out, plain):
+        assert none is None and dec is o
+        assert np.abs(o.cpu().numpy() - p.cpu().numpy()).max() <= TOL_TIGHT
+    with pytest.raises(RuntimeError):                  # a container on its own has nothing to replay
+        m.MPNet(h_enc, d.edge_index, e_enc)
+
+
+def test_wrong_input_dtypes_raise_like_the_reference():
+    params, arch, sd, a = load_case(os.path.join(GOLDEN_DIR, "terrace32.npz"))
+    m = build(params, arch, sd)
+    d = to_data(a)
+    for bad in (Data(d.x.double(), d.edge_index, d.edge_attr), Data(d.x, d.edge_index, d.edge_attr.half()),
+                Data(d.x, d.edge_index.int(), d.edge_attr)):
+        with pytest.raises(RuntimeError):
+            m(bad)
+        m.train()
+        with pytest.raises(RuntimeError):
+            m(bad)
+        m.eval()
+    with torch.no_grad():                              # a non-contiguous view of the right dtype is only a layout
+        xt = d.x.t().contiguous().t()
+        assert not xt.is_contiguous()
+        out = m(Data(xt, d.edge_index, d.edge_attr))["classified_edges"]
+    assert np.abs(out[-1].cpu().numpy() - a[f"logits_{int(a['n_logits']) - 1}"]).max() <= TOL_TIGHT
