@@ -70,7 +70,7 @@ struct BwdEdgeParams {
     const float* g_h;      // [N][32] d loss / d h_s, or null on the last step (its node update is dead)
     const int* deg;        // [N] (mean) or null
     const int* hmax;       // [N][32] ('max'): bit pattern of the largest positive message per node and channel, or null
-    const int* hcnt;       // [N][32] ('max'): how many of the node's edges attain it (ties share the gradient)
+    const int* hcnt;       // [N][32] ('max'): E - id of the FIRST edge that attains it (it alone receives the gradient), 0: none
     const float* g_logit;  // [E] or null
     const float* ge_in;    // [E][6] from step s+1, or null
     float* ge_out;         // [E][6] d loss / d e_{s-1}
@@ -100,7 +100,8 @@ struct BwdEdgeParams {
 // 'max' aggregation, pass 1: hmax[i][c] = bit pattern of max over the edges of node i of the (positive) message
 // pre-activation b = Q[i][c] + W_ne[c] . e', recomputed with exactly the arithmetic bwd_edge_kernel uses, so that its
 // equality test selects the same edge.  Positive floats order like their bit patterns: atomicMax on int.
-// Pass 2 (COUNT): hcnt[i][c] = number of edges that attain it.
+// Pass 2 (COUNT): hcnt[i][c] = E - (id of the first edge that attains it): torch_scatter's scatter_max hands the whole gradient to
+// its `arg`, the first source row with the maximum (its CPU reducer updates on a strict `>`).
 template <bool COUNT>
 __global__ __launch_bounds__(256) void bwd_max_kernel(const long long* __restrict__ ei, const float* __restrict__ e_cur,
                                                       const float* __restrict__ Q, const float* __restrict__ Wn_, long long E,
@@ -120,8 +121,8 @@ __global__ __launch_bounds__(256) void bwd_max_kernel(const long long* __restric
 #pragma unroll
         for (int f = 0; f < kEF; ++f) b = fmaf(Wn[c * (HI + kEF) + HI + f], es[f], b);
         if (b > 0.f) {
-            if (COUNT) {
-                if (__float_as_int(b) == hmax[(size_t)i * kH + c]) atomicAdd(&hcnt[(size_t)i * kH + c], 1);
+            if (COUNT) {  // pass 2: the FIRST edge (lowest id k) that attains the maximum, kept as E - k so that 0 means "none"
+                if (__float_as_int(b) == hmax[(size_t)i * kH + c]) atomicMax(&hcnt[(size_t)i * kH + c], (int)(E - k));
             } else {
                 atomicMax(&hmax[(size_t)i * kH + c], __float_as_int(b));
             }
@@ -316,17 +317,16 @@ __global__ __launch_bounds__(256) void bwd_edge_kernel(const BwdEdgeParams p) {
                     float b = q_row[c];
 #pragma unroll
                     for (int f = 0; f < kEF; ++f) b = fmaf(Wn[c * WnLd + HI + f], es[f], b);
-                    // 'max': only the edge(s) that attain the node's maximum pass the gradient on (a maximum of 0, i.e. no
-                    // positive message, passes nothing: ReLU' = 0 there anyway)
-                    // Ties are real: an edge whose six features are all dead (e' = 0) has b = Q[row][c], the same for every such
-                    // edge of the node.  They share the gradient equally (torch's amax backward; torch_scatter hands it to one
-                    // of them -- the same total, and tied edges are indistinguishable downstream).
+                    // 'max': only the edge torch_scatter's `arg` names -- the first one that attains the node's maximum -- passes the
+                    // gradient on (a maximum of 0, i.e. no positive message, passes nothing: ReLU' = 0 there anyway).  Ties are real
+                    // (every edge whose six features are dead has b = Q[row][c]), which edge of a tie gets the gradient only
+                    // matters for the per-edge terms: the parameter gradients of tied DEAD or DUPLICATE edges are the same either way.
                     float gb = 0.f;
                     if (b > 0.f) {
                         if (p.hmax == nullptr)
                             gb = gh_row[c] * inv * live;
-                        else if (__float_as_int(b) == hm_row[c])
-                            gb = gh_row[c] * live / (float)max(p.hcnt[(size_t)i * kH + c], 1);
+                        else if (__float_as_int(b) == hm_row[c] && p.hcnt[(size_t)i * kH + c] == (int)(p.E - k))
+                            gb = gh_row[c] * live;
                     }
                     v[8 * u] = gb;
                     v[8 * u + 7] = 0.f;

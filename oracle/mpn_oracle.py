@@ -190,8 +190,7 @@ class TorchOracle:
         torch = self.torch
         agg = self.lay["agg"]
         if agg == "max":
-            idx = row.view(-1, 1).expand_as(flow)
-            return torch.zeros(n, flow.shape[1]).scatter_reduce(0, idx, flow, reduce="amax", include_self=False)
+            return _scatter_max_first(torch, flow, row, n)
         out = torch.zeros(n, flow.shape[1]).index_add_(0, row, flow)
         if agg == "mean":
             cnt = torch.zeros(n).index_add_(0, row, torch.ones(row.numel())).clamp_(min=1)
@@ -248,6 +247,40 @@ def load_case(path):
 # --------------------------------------------------------------------------------------------------
 # train-mode flavour with autograd (row N3): the reference's forward under torch autograd
 # --------------------------------------------------------------------------------------------------
+_SCATTER_MAX_FN = None
+
+
+def _scatter_max_first(torch, src, index, dim_size):
+    """torch_scatter 2.0.8's scatter_max(...)[0] with ITS backward (models/mpn.py:199; package pinned at env_gnn.yml:97, absent
+    here, restated from its CPU kernel): per-segment maximum, 0 for empty segments; the gradient goes, whole, to the FIRST
+    source row that attains the maximum (the reducer updates on a strict `>` walking the rows in order; backward is
+    grad_in.scatter_(0, arg, grad_out)).  torch's amax backward would split it evenly among tied rows instead."""
+    global _SCATTER_MAX_FN
+    if _SCATTER_MAX_FN is None:
+        class ScatterMaxFirst(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, src, index, dim_size):
+                idx = index.view(-1, 1).expand_as(src)
+                out = torch.zeros(dim_size, src.shape[1], dtype=src.dtype).scatter_reduce(0, idx, src, reduce="amax", include_self=False)
+                e = src.shape[0]
+                rows = torch.arange(e).view(-1, 1).expand_as(src)
+                cand = torch.where(src == out[index], rows, torch.full_like(rows, e))
+                arg = torch.full(out.shape, e, dtype=torch.long).scatter_reduce(0, idx, cand, reduce="amin", include_self=True)
+                ctx.save_for_backward(arg)
+                ctx.e = e
+                return out
+
+            @staticmethod
+            def backward(ctx, grad_out):
+                (arg,) = ctx.saved_tensors
+                grad_src = torch.zeros(ctx.e + 1, grad_out.shape[1], dtype=grad_out.dtype)
+                grad_src.scatter_(0, arg, grad_out)   # empty segments carry arg == e: the extra row swallows them
+                return grad_src[:ctx.e], None, None
+
+        _SCATTER_MAX_FN = ScatterMaxFirst
+    return _SCATTER_MAX_FN.apply(src, index, dim_size)
+
+
 class TorchTrainOracle(TorchOracle):
     """TorchOracle with gradients: parameters are autograd leaves, BatchNorm1d runs in TRAIN mode (batch statistics,
     running buffers updated with momentum 0.1 as torch.nn.BatchNorm1d does, models/mlp.py:15), Dropout must be 0.

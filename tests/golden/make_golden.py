@@ -66,12 +66,35 @@ def _install_torch_scatter_standin():
         cnt = cnt.clamp_(min=1)
         return out / cnt.view(-1, *([1] * (src.dim() - 1)))
 
+    class _ScatterMaxFirst(torch.autograd.Function):
+        """torch_scatter 2.0.8 (env_gnn.yml:97) semantics of scatter_max restated from its CPU kernel: the output is the
+        per-segment maximum (0 for segments that receive nothing), `arg` the FIRST source row that attains it (the reducer
+        updates on a strict `>`, walking the rows in order), and the backward hands the whole gradient to that one row
+        (grad_in.scatter_(dim, arg, grad_out)) -- torch's own amax backward would split it evenly among tied rows."""
+
+        @staticmethod
+        def forward(ctx, src, index, dim_size):
+            idx = index.view(-1, *([1] * (src.dim() - 1))).expand_as(src)
+            out = torch.zeros((dim_size,) + tuple(src.shape[1:]), dtype=src.dtype)
+            out = out.scatter_reduce(0, idx, src, reduce="amax", include_self=False)
+            e = src.shape[0]
+            rows = torch.arange(e).view(-1, *([1] * (src.dim() - 1))).expand_as(src)
+            cand = torch.where(src == out[index], rows, torch.full_like(rows, e))
+            arg = torch.full(out.shape, e, dtype=torch.long).scatter_reduce(0, idx, cand, reduce="amin", include_self=True)
+            ctx.save_for_backward(arg)
+            ctx.e = e
+            return out, arg
+
+        @staticmethod
+        def backward(ctx, grad_out, _grad_arg):
+            (arg,) = ctx.saved_tensors
+            grad_src = torch.zeros((ctx.e + 1,) + tuple(grad_out.shape[1:]), dtype=grad_out.dtype)
+            grad_src.scatter_(0, arg, grad_out)          # empty segments carry arg == e: the extra row swallows them
+            return grad_src[:ctx.e], None, None
+
     def scatter_max(src, index, dim=0, dim_size=None):
         assert dim == 0
-        idx = index.view(-1, *([1] * (src.dim() - 1))).expand_as(src)
-        out = torch.zeros((dim_size,) + tuple(src.shape[1:]), dtype=src.dtype)
-        out = out.scatter_reduce(0, idx, src, reduce="amax", include_self=False)
-        return out, None
+        return _ScatterMaxFirst.apply(src, index, dim_size)
 
     ts.scatter_add, ts.scatter_mean, ts.scatter_max = scatter_add, scatter_mean, scatter_max
     sys.modules["torch_scatter"] = ts

@@ -224,3 +224,53 @@ def test_out_of_range_index_in_train_mode_is_contained(name, which, bad):
     for k, p in m.named_parameters():
         assert p.grad is not None and p.grad.shape == p.shape, k
     assert bool((canary_lo == 7.0).all()) and bool((canary_hi == 7.0).all())
+
+
+def test_max_aggregation_gradient_goes_to_the_first_arg_max():
+    """torch_scatter's scatter_max hands the whole gradient to its `arg`, the FIRST edge that attains a node's maximum
+    (torch's own amax backward would split it among tied edges).  Constructed exact ties that make the two rules differ in
+    a PARAMETER gradient: eight channels of the node MLP get a zero edge-feature block, so every edge of a node has the
+    same message Q[row][c] in those channels while its edge features differ -- d W_ne[c] is gh * e'(first edge) under the
+    reference's rule and gh * mean(e') under the other.  Checked against autograd over the oracle's first-arg scatter_max."""
+    from oracle.mpn_oracle import load_case
+    from test_gpu_fuzz import random_graph
+    params, arch, sd, _ = load_case(os.path.join(GOLDEN_DIR, "n8_sum.npz"))
+    params = copy.deepcopy(params)
+    params.update(node_agg_fn="max")
+    params["classifier_feats_dict"]["use_batchnorm"] = False
+    sd = {k: np.array(v) for k, v in sd.items() if "classifier" not in k}
+    torch.manual_seed(5)
+    from gnn_cca_amd import MOTMPNet
+    fresh = MOTMPNet(copy.deepcopy(params), None, arch).state_dict()
+    for k, v in fresh.items():
+        if k not in sd:
+            sd[k] = v.numpy().copy()
+    w = sd["MPNet.node_model.node_mlp.fc_layers.0.weight"] * np.float32(4.0)
+    b = sd["MPNet.node_model.node_mlp.fc_layers.0.bias"] * np.float32(4.0)
+    w[:8, 32:] = 0.0                    # channels 0..7 ignore the edge features: exact ties among all edges of a node
+    b[:8] = np.abs(b[:8]) + 0.05        # ... at a positive value, so the tie carries gradient
+    sd["MPNet.node_model.node_mlp.fc_layers.0.weight"], sd["MPNet.node_model.node_mlp.fc_layers.0.bias"] = w, b
+    m = build(params, arch, sd)
+    orc = TorchTrainOracle(params, arch, sd)
+    rng = np.random.default_rng(77)
+    for it in range(6):
+        n, ei = random_graph(rng, "frames")
+        if it % 2:
+            ei = ei[:, rng.permutation(ei.shape[1])]          # the first edge by ID, not by sorted position
+        x = (rng.standard_normal((n, 64)) * 0.3).astype(np.float32)
+        ea = rng.random((ei.shape[1], 4)).astype(np.float32)
+        labels = (rng.random(ei.shape[1]) < 0.3).astype(np.float32)
+        ref_loss, _, ref = orc.loss_and_grads(x, ei, ea, labels)
+        m.zero_grad(set_to_none=True)
+        out = m(Data(torch.from_numpy(x).cuda(), torch.from_numpy(ei).cuda(), torch.from_numpy(ea).cuda()))
+        loss = loss_of(out, torch.from_numpy(labels).cuda())
+        loss.backward()
+        assert abs(float(loss) - ref_loss) <= 1e-5
+        gw = m.MPNet.node_model.node_mlp.fc_layers[0].weight.grad.cpu().numpy()
+        rw = ref["MPNet.node_model.node_mlp.fc_layers.0.weight"].numpy()
+        assert float(np.abs(rw[:8, 32:]).max()) > 1e-4, "the constructed ties must carry gradient"
+        for k, p in m.named_parameters():
+            r = ref[k].numpy()
+            scale = max(1.0, float(np.abs(r).max()))
+            assert float(np.abs(p.grad.cpu().numpy() - r).max()) <= 3e-5 * scale, (it, k)
+        assert float(np.abs(gw[:8, 32:] - rw[:8, 32:]).max()) <= 3e-5
