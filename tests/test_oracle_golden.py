@@ -34,6 +34,25 @@ def test_torch_oracle_matches_reference(name):
         assert np.abs(o.numpy() - a[f"logits_{i}"]).max() <= TOL32, (name, i)
 
 
+@pytest.mark.parametrize("name", golden_cases())
+def test_c_oracle_matches_reference(name):
+    """oracle/mpn_oracle_c.c (the fused split-weight C / OpenMP restatement, SURVEY.md 8d's CPU-baseline flavour (ii)) against
+    the reference's golden logits; the two goldens with multi-layer MPN MLPs are outside its scope and must say so."""
+    from oracle.c_oracle import COracle
+    params, arch, sd, a = load_case(os.path.join(GOLDEN_DIR, name + ".npz"))
+    orc = COracle(params, arch, sd)
+    if not orc.supported():
+        assert name in ("generic_dims", "generic_reattach_max")
+        with pytest.raises(RuntimeError):
+            orc.forward(a["x"], a["edge_index"], a["edge_attr"])
+        return
+    out = orc.forward(a["x"], a["edge_index"], a["edge_attr"])
+    assert len(out) == int(a["n_logits"])
+    for i, o in enumerate(out):
+        assert o.shape == a[f"logits_{i}"].shape and o.dtype == np.float32
+        assert np.abs(o - a[f"logits_{i}"]).max() <= TOL32, (name, i)
+
+
 @pytest.mark.parametrize("name", ["dense64", "terrace32", "ragged_max", "generic_dims"])
 def test_fp64_oracle_brackets_reference(name):
     params, arch, sd, a = load_case(os.path.join(GOLDEN_DIR, name + ".npz"))
