@@ -340,6 +340,12 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
     sp.pd_lds = (N <= 1024) && d->num_enc_steps > 0;
     sp.e_bf16 = (options & GNNCCA_OPT_EDGE_STATE_BF16) != 0;  // honoured by the specialised kernels only
     sp.ell_S = use_ell ? ws.ell_S : 0;
+    {
+        static const bool no_nt = std::getenv("GNNCCA_NO_NT") != nullptr;  // diagnostics: A/B the cache policy
+        const double state_bytes = (double)(sp.e_bf16 ? kEF / 2 : kEF) * (double)ws.e_stride * 4.0;
+        sp.nt_store = !no_nt && state_bytes > 150e6;
+        sp.nt_load = !no_nt && state_bytes > 256e6;
+    }
     const bool re = d->reattach_edges != 0;
     int out_idx = 0;
     if (L == 0) {  // models/mpn.py:295-297: classify the encoded edge features once

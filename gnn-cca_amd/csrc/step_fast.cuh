@@ -19,7 +19,7 @@ __device__ __forceinline__ float relu_bits(float x) { return __int_as_float(max(
 #else
 #define GNNCCA_FAST_ATTR
 #endif
-template <bool FIRST, bool CLS, bool MSG, bool PD_LDS, bool EBF16>
+template <bool FIRST, bool CLS, bool MSG, bool PD_LDS, bool EBF16, int NT>
 __global__ __launch_bounds__(256) GNNCCA_FAST_ATTR void mpn_step_fast_kernel(const StepParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_proj = smem;                                   // [32][48]   (MSG)
@@ -98,6 +98,13 @@ __global__ __launch_bounds__(256) GNNCCA_FAST_ATTR void mpn_step_fast_kernel(con
     const long long eoff = (p.ell_S > 0 && !(gflags & (GNNCCA_GRAPH_UNSORTED | GNNCCA_GRAPH_IRREGULAR)))
                                ? (long long)node * p.ell_S - seg_s : 0ll;
 
+    // Cache policy of the streams (template NT: 0 none, 1 stores + edge_attr, 2 + loads of e; chosen by the host from the size of the
+    // edge state; a RUN-TIME flag does not work: the compiler merges the two arms of the branch into one plain access): while the
+    // state of a step fits the 256 MB Infinity Cache next to everything else the step touches, the next step finds it there and
+    // default-policy accesses are best (64 x dense256, 100 MB: non-temporal loads cost +20 %).  Beyond that the streams only evict
+    // each other: non-temporal stores of e' / logits and loads of edge_attr -7 % at 512 x dense128 (200 MB of state), non-temporal
+    // loads of e on top -6 % at 200 x dense256 (313 MB).
+    constexpr bool nt_store = NT >= 1, nt_load = NT >= 2;
     f32x16 acc;  // 'sum' / 'mean' only: 'max' takes the general kernel
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
@@ -117,20 +124,27 @@ __global__ __launch_bounds__(256) GNNCCA_FAST_ATTR void mpn_step_fast_kernel(con
     auto load_state = [&](int base, Chunk& c) {
         const int kk = min(base + lane, last);
         if (FIRST) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(p.edge_attr + (size_t)c.ko * 4);
+            const f32x4* __restrict__ ap = reinterpret_cast<const f32x4*>(p.edge_attr + (size_t)c.ko * 4);
+            const f32x4 a = nt_store ? __builtin_nontemporal_load(ap) : *ap;   // read once per forward
             c.raw[0] = a[0], c.raw[1] = a[1], c.raw[2] = a[2], c.raw[3] = a[3], c.raw[4] = 0.f, c.raw[5] = 0.f;
         } else if (EBF16) {
             // edge state stored as three planes of packed bf16 pairs: one dword load = two features
             const unsigned* __restrict__ e2 = reinterpret_cast<const unsigned*>(p.e);
 #pragma unroll
             for (int f = 0; f < kEF / 2; ++f) {
-                const unsigned w = e2[(size_t)f * p.e_stride + kk + eoff];
+                const unsigned w = nt_load ? __builtin_nontemporal_load(e2 + (size_t)f * p.e_stride + kk + eoff)
+                                           : e2[(size_t)f * p.e_stride + kk + eoff];
                 c.raw[2 * f] = __uint_as_float(w << 16);
                 c.raw[2 * f + 1] = __uint_as_float(w & 0xFFFF0000u);
             }
         } else {
+            if (nt_load) {
 #pragma unroll
-            for (int f = 0; f < kEF; ++f) c.raw[f] = p.e[(size_t)f * p.e_stride + kk + eoff];
+                for (int f = 0; f < kEF; ++f) c.raw[f] = __builtin_nontemporal_load(p.e + (size_t)f * p.e_stride + kk + eoff);
+            } else {
+#pragma unroll
+                for (int f = 0; f < kEF; ++f) c.raw[f] = p.e[(size_t)f * p.e_stride + kk + eoff];
+            }
         }
     };
     // phase B: the gather that depends on the target id
@@ -192,11 +206,19 @@ __global__ __launch_bounds__(256) GNNCCA_FAST_ATTR void mpn_step_fast_kernel(con
                     bf16x2_t pk;  // round to nearest even (v_cvt_pk_bf16_f32)
                     pk[0] = (__bf16)en[2 * f];
                     pk[1] = (__bf16)en[2 * f + 1];
-                    e2[(size_t)f * p.e_stride + k + eoff] = __builtin_bit_cast(unsigned, pk);
+                    if (nt_store)
+                        __builtin_nontemporal_store(__builtin_bit_cast(unsigned, pk), e2 + (size_t)f * p.e_stride + k + eoff);
+                    else
+                        e2[(size_t)f * p.e_stride + k + eoff] = __builtin_bit_cast(unsigned, pk);
                 }
             } else {
 #pragma unroll
-                for (int f = 0; f < kEF; ++f) p.e[(size_t)f * p.e_stride + k + eoff] = en[f];
+                for (int f = 0; f < kEF; ++f) {
+                    if (nt_store)
+                        __builtin_nontemporal_store(en[f], p.e + (size_t)f * p.e_stride + k + eoff);
+                    else
+                        p.e[(size_t)f * p.e_stride + k + eoff] = en[f];
+                }
             }
         }
         if (CLS) {
@@ -213,7 +235,12 @@ __global__ __launch_bounds__(256) GNNCCA_FAST_ATTR void mpn_step_fast_kernel(con
             float logit = cw[kFcCb2];
 #pragma unroll
             for (int q = 0; q < 4; ++q) logit = fmaf(cw[kFcCw2 + q], fmaxf(z[q >> 1][q & 1], 0.f), logit);
-            if (valid) p.logits[c.ko] = logit;
+            if (valid) {
+                if (nt_store)
+                    __builtin_nontemporal_store(logit, p.logits + c.ko);   // written once, read by the caller much later
+                else
+                    p.logits[c.ko] = logit;
+            }
         }
         if (MSG) {
             f32x16 d0, d1;
@@ -298,18 +325,23 @@ __global__ __launch_bounds__(256) GNNCCA_FAST_ATTR void mpn_step_fast_kernel(con
     GNNCCA_STAMP(p.stamp_slot, 7);
 }
 
-template <bool FIRST, bool CLS, bool MSG, bool PDL, bool EB>
+template <bool FIRST, bool CLS, bool MSG, bool PDL, bool EB, int NT>
 static hipError_t launch_fast_t(const StepParams& sp, hipStream_t st) {
     const int npg = 4 / sp.wps;
     const unsigned blocks = (unsigned)((sp.N + npg - 1) / npg);
     const size_t lds = ((MSG ? (size_t)kH * kProjOut : 0) + 4 * kH + (PDL ? (size_t)sp.N * kPdStride : 0)) * sizeof(float);
-    GNNCCA_LAUNCH((mpn_step_fast_kernel<FIRST, CLS, MSG, PDL, EB>), dim3(blocks), dim3(256), lds, st, sp);
+    GNNCCA_LAUNCH((mpn_step_fast_kernel<FIRST, CLS, MSG, PDL, EB, NT>), dim3(blocks), dim3(256), lds, st, sp);
     return hipGetLastError();
 }
 
 template <bool FIRST, bool CLS, bool MSG, bool PDL>
 static hipError_t launch_fast(const StepParams& sp, hipStream_t st) {
-    return sp.e_bf16 ? launch_fast_t<FIRST, CLS, MSG, PDL, true>(sp, st) : launch_fast_t<FIRST, CLS, MSG, PDL, false>(sp, st);
+    if (!PDL) {   // the non-temporal variants only exist beyond the LDS-resident gather table (N > 1024): big batches
+        const int nt = sp.nt_load ? 2 : (sp.nt_store ? 1 : 0);
+        if (nt == 2) return sp.e_bf16 ? launch_fast_t<FIRST, CLS, MSG, false, true, 2>(sp, st) : launch_fast_t<FIRST, CLS, MSG, false, false, 2>(sp, st);
+        if (nt == 1) return sp.e_bf16 ? launch_fast_t<FIRST, CLS, MSG, false, true, 1>(sp, st) : launch_fast_t<FIRST, CLS, MSG, false, false, 1>(sp, st);
+    }
+    return sp.e_bf16 ? launch_fast_t<FIRST, CLS, MSG, PDL, true, 0>(sp, st) : launch_fast_t<FIRST, CLS, MSG, PDL, false, 0>(sp, st);
 }
 
 static hipError_t launch_fast_dispatch(const StepParams& sp, bool msg, hipStream_t st) {

@@ -46,6 +46,7 @@ struct StepParams {
     // CSR order.  Chosen by the host from E/N alone; the plan raises GNNCCA_GRAPH_IRREGULAR when a degree exceeds it and
     // the kernels then use the compact order for this forward.
     int ell_S;
+    int nt_store, nt_load;   // non-temporal policy of the specialised step kernel's streams (see step_fast.cuh)
 };
 
 template <bool REATT_E, bool MSG, bool AGG_MAX>
