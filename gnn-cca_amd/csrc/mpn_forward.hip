@@ -138,60 +138,61 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
         int ks_split = 1;
         if (split) {  // big batches: split-bf16 MFMA GEMM; the plan gets its own launch
             const unsigned short* w3 = reinterpret_cast<const unsigned short*>(blob + hdr.enc_w3);
-            static const bool force_direct = std::getenv("GNNCCA_GEMM_DIRECT") != nullptr;  // diagnostics: A/B the two GEMMs
-            // measured crossover of the two GEMMs (+ their tails): N = 8 192 equal (32 us), 12 288: 51 vs 59 us, 4 096: 27 vs 21 us
+            static const bool force_direct = std::getenv("GNNCCA_GEMM_DIRECT") != nullptr;  // diagnostics: A/B the GEMMs
+            static const bool no_fuse = std::getenv("GNNCCA_NO_FUSE") != nullptr;             // A/B against GEMM + tail launch
             static const int lds_min = std::getenv("GNNCCA_GEMM_LDS_MIN") ? std::atoi(std::getenv("GNNCCA_GEMM_LDS_MIN")) : 12288;
-            if (N >= lds_min && O == 128 && !force_direct) {
+            const bool fusable = !no_fuse && nl == 2 && d->enc_node.layers[1].in_dim == 128 && d->enc_node.layers[1].out_dim == kH &&
+                                 !d->reattach_nodes && hdr.proj_wT != 0;
+            const bool use_lds = N >= lds_min && O == 128 && !force_direct;
+            if (use_lds) ks_split = std::min(enc_lds_ksplit(N, K), ws.ksplit);
+            // un-split and the shipped encoder shape (2048 -> 128 -> 32, no reattach): the rest of the encoder, the step-1
+            // projections and the plan fold run in the GEMM's epilogue, on the tile while it is on chip
+            fused_tail = use_lds && fusable && ks_split == 1;
+            EncFuseParams fp;
+            std::memset(&fp, 0, sizeof(fp));
+            if (fused_tail) {
+                fp.b1 = blob + hdr.enc_node_b[0];
+                fp.W2 = blob + hdr.enc_node_w[1];
+                fp.b2 = blob + hdr.enc_node_b[1];
+                fp.projwT = blob + hdr.proj_wT;
+                fp.projb = blob + hdr.proj_b;
+                fp.h0 = h0;
+                fp.trace_h = trace ? trace->h_enc : nullptr;
+                fp.pd_out = pd[0];
+                fp.psq_out = psq[0];
+                fp.relu_prev = l.relu;
+                // the plan goes FIRST here, so that one extra workgroup of the GEMM launch can fold its findings (and repair
+                // an unsorted graph): no tail launch is left in this regime
+                fp.ei = reinterpret_cast<const long long*>(edge_index);
+                fp.seg_ptr = seg_ptr;
+                fp.col32 = col32;
+                fp.perm = perm;
+                fp.cursor = cursor;
+                fp.flags = flags;
+                fp.blockflags = blockflags;
+                fp.E = E;
+                if (plan_blocks > 0) {
+                    GNNCCA_LAUNCH(enc_gemm_plan_kernel, dim3(plan_blocks), dim3(256), 0, st, ep);
+                    HIP_TRY(hipGetLastError());
+                    PROF_MARK(GNNCCA_K_PLAN_ROWS);
+                }
+                plan_launched = true;
+            }
+            static thread_local int attr_dev = -1;  // once per device and thread: the attribute is per device
+            int dev = 0;
+            HIP_TRY(hipGetDevice(&dev));
+            if (attr_dev != dev) {
+                const void* fns[4] = {reinterpret_cast<const void*>(enc_gemm_split_lds_kernel<false, false>),
+                                      reinterpret_cast<const void*>(enc_gemm_split_lds_kernel<true, false>),
+                                      reinterpret_cast<const void*>(enc_gemm_split_lds_kernel<false, true>),
+                                      reinterpret_cast<const void*>(enc_gemm_split_lds_kernel<true, true>)};
+                for (const void* fn : fns)
+                    HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsGemmBytes));
+                attr_dev = dev;
+            }
+            if (use_lds) {
                 // 256-row workgroups, both operands through LDS (144 KB: one workgroup per CU, 8 waves); split-K by whole
                 // rounds of 256 workgroups (internal.h: enc_lds_ksplit)
-                ks_split = std::min(enc_lds_ksplit(N, K), ws.ksplit);
-                // un-split and the shipped encoder shape (2048 -> 128 -> 32, no reattach): the rest of the encoder and the step-1
-                // projections run in the GEMM's epilogue, on the tile while it is on chip
-                static const bool no_fuse = std::getenv("GNNCCA_NO_FUSE") != nullptr;  // diagnostics: A/B against GEMM + tail launch
-                fused_tail = !no_fuse && ks_split == 1 && nl == 2 && d->enc_node.layers[1].in_dim == 128 && d->enc_node.layers[1].out_dim == kH &&
-                             !d->reattach_nodes && hdr.proj_wT != 0;
-                EncFuseParams fp;
-                std::memset(&fp, 0, sizeof(fp));
-                if (fused_tail) {
-                    fp.b1 = blob + hdr.enc_node_b[0];
-                    fp.W2 = blob + hdr.enc_node_w[1];
-                    fp.b2 = blob + hdr.enc_node_b[1];
-                    fp.projwT = blob + hdr.proj_wT;
-                    fp.projb = blob + hdr.proj_b;
-                    fp.h0 = h0;
-                    fp.trace_h = trace ? trace->h_enc : nullptr;
-                    fp.pd_out = pd[0];
-                    fp.psq_out = psq[0];
-                    fp.relu_prev = l.relu;
-                    // the plan goes FIRST here, so that one extra workgroup of the GEMM launch can fold its findings (and repair
-                    // an unsorted graph): no tail launch is left in this regime
-                    fp.ei = reinterpret_cast<const long long*>(edge_index);
-                    fp.seg_ptr = seg_ptr;
-                    fp.col32 = col32;
-                    fp.perm = perm;
-                    fp.cursor = cursor;
-                    fp.flags = flags;
-                    fp.blockflags = blockflags;
-                    fp.E = E;
-                    if (plan_blocks > 0) {
-                        GNNCCA_LAUNCH(enc_gemm_plan_kernel, dim3(plan_blocks), dim3(256), 0, st, ep);
-                        HIP_TRY(hipGetLastError());
-                        PROF_MARK(GNNCCA_K_PLAN_ROWS);
-                    }
-                    plan_launched = true;
-                }
-                static thread_local int attr_dev = -1;  // once per device and thread: the attribute is per device
-                int dev = 0;
-                HIP_TRY(hipGetDevice(&dev));
-                if (attr_dev != dev) {
-                    const void* fns[4] = {reinterpret_cast<const void*>(enc_gemm_split_lds_kernel<false, false>),
-                                          reinterpret_cast<const void*>(enc_gemm_split_lds_kernel<true, false>),
-                                          reinterpret_cast<const void*>(enc_gemm_split_lds_kernel<false, true>),
-                                          reinterpret_cast<const void*>(enc_gemm_split_lds_kernel<true, true>)};
-                    for (const void* fn : fns)
-                        HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsGemmBytes));
-                    attr_dev = dev;
-                }
                 const dim3 fgrid((N + 255) / 256 + 1, 1), sgrid((N + 255) / 256, ks_split);
                 if (fused_tail && split3)
                     GNNCCA_LAUNCH((enc_gemm_split_lds_kernel<true, true>), fgrid, dim3(512), kLdsGemmBytes, st, cur_in, w3, part, N, K, O, K, fp);

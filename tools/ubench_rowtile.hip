@@ -11,9 +11,11 @@ template <int CB, int ROWS = 256, int THREADS = 512>   // bytes per row per chun
 __global__ __launch_bounds__(THREADS) void k_tile(const float* __restrict__ x, float* __restrict__ sink, int K, int deep) {
     constexpr int F4 = CB / 16;            // float4 per row per chunk
     constexpr int PER = ROWS * F4 / THREADS;    // float4 per thread per chunk
+    extern __shared__ float dyn_lds[];   // only to limit residency (launch with e.g. 96 KB -> one workgroup per CU)
     const int tid = threadIdx.x;
     const float* base = x + (size_t)blockIdx.x * ROWS * K;
     f4 acc = {0, 0, 0, 0};
+    if (deep == 12345) dyn_lds[tid] = 1.f;
     const int nchunk = K * 4 / CB;
     f4 r[2][PER];
     auto load = [&](int kt, f4 (&dst)[PER]) {
@@ -77,5 +79,16 @@ int main() {
     time("64 rows x 256 B, 256 thr", [&] { hipLaunchKernelGGL((k_tile<256, 64, 256>), dim3(N / 64), dim3(256), 0, 0, x, sink, K, 0); });
     time("32 rows x 512 B, 256 thr", [&] { hipLaunchKernelGGL((k_tile<512, 32, 256>), dim3(N / 32), dim3(256), 0, 0, x, sink, K, 0); });
     time("128 rows x 256 B, 512 thr", [&] { hipLaunchKernelGGL((k_tile<256, 128, 512>), dim3(N / 128), dim3(512), 0, 0, x, sink, K, 0); });
+    // the same shapes with ONE workgroup per CU (96 KB of dynamic LDS requested), as a GEMM whose stages fill the LDS would run
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile<512, 64, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile<256, 128, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile<512, 128, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile<512, 32, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
+    time("64 rows x 512 B, 256 thr, 1 WG/CU", [&] { hipLaunchKernelGGL((k_tile<512, 64, 256>), dim3(N / 64), dim3(256), 98304, 0, x, sink, K, 0); });
+    time("128 rows x 256 B, 512 thr, 1 WG/CU", [&] { hipLaunchKernelGGL((k_tile<256, 128, 512>), dim3(N / 128), dim3(512), 98304, 0, x, sink, K, 0); });
+    time("128 rows x 512 B, 512 thr, 1 WG/CU", [&] { hipLaunchKernelGGL((k_tile<512, 128, 512>), dim3(N / 128), dim3(512), 98304, 0, x, sink, K, 0); });
+    time("32 rows x 512 B, 256 thr, 1 WG/CU", [&] { hipLaunchKernelGGL((k_tile<512, 32, 256>), dim3(N / 32), dim3(256), 98304, 0, x, sink, K, 0); });
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile<512, 64, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    time("64 rows x 512 B, 256 thr, 2 WG/CU", [&] { hipLaunchKernelGGL((k_tile<512, 64, 256>), dim3(N / 64), dim3(256), 65536, 0, x, sink, K, 0); });
     return 0;
 }
