@@ -46,6 +46,11 @@ class Profile(C.Structure):
     _fields_ = [("options", C.c_uint32), ("count", C.c_int32), ("kind", C.c_int32 * PROFILE_MAX), ("ms", C.c_float * PROFILE_MAX)]
 
 
+class Dropout(C.Structure):
+    """gnncca_dropout (include/gnncca_mpn.h): Dropout probabilities per MLP group + a DEVICE seed word."""
+    _fields_ = [("p_enc", C.c_float), ("p_edge", C.c_float), ("p_node", C.c_float), ("p_cls", C.c_float), ("seed_dev", C.c_void_p)]
+
+
 OPT_EDGE_STATE_BF16 = 1
 OPT_ENC_SPLIT3 = 2
 BWD_GRADS_ZEROED = 1
@@ -92,6 +97,14 @@ _SIGNATURES = {
                                          C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p]),
     "gnncca_classifier_train": (C.c_int, [C.POINTER(MpnDims), C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_int64, C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gnncca_mpn_forward_train": (C.c_int, [C.POINTER(MpnDims), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                           C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(Trace), C.POINTER(Dropout),
+                                           C.c_void_p]),
+    "gnncca_classifier_train_dropout": (C.c_int, [C.POINTER(MpnDims), C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_int64,
+                                                  C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Dropout), C.c_void_p]),
+    "gnncca_mpn_backward_train": (C.c_int, [C.POINTER(MpnDims), C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_int64, C.c_int64, C.POINTER(Trace), C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p),
+                                            C.c_void_p, C.c_size_t, C.c_uint32, C.POINTER(Dropout), C.c_void_p]),
     "gnncca_read_graph_flags": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.c_void_p]),
 }
 

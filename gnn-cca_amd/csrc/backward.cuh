@@ -95,6 +95,8 @@ struct BwdEdgeParams {
     const float* bn_beta;
     long long E;
     int N, cls_hidden;     // cls_hidden == 0: single Linear(6,1)
+    DropCfg drop;          // train-mode Dropout of this iteration (p == 0: off); masks are re-derived, never loaded
+    int step_no, cls_no;   // 1-based step / 0-based classified-step index: the dropout streams of this launch
 };
 
 // 'max' aggregation, pass 1: hmax[i][c] = bit pattern of max over the edges of node i of the (positive) message
@@ -105,7 +107,8 @@ struct BwdEdgeParams {
 template <bool COUNT>
 __global__ __launch_bounds__(256) void bwd_max_kernel(const long long* __restrict__ ei, const float* __restrict__ e_cur,
                                                       const float* __restrict__ Q, const float* __restrict__ Wn_, long long E,
-                                                      int N, int HI, int* __restrict__ hmax, int* __restrict__ hcnt) {
+                                                      int N, int HI, int* __restrict__ hmax, int* __restrict__ hcnt,
+                                                      DropCfg drop, int step_no) {
     const long long k = (long long)blockIdx.x * 256 + threadIdx.x;
     if (k >= E) return;
     typedef const float __attribute__((address_space(4))) cfloat;
@@ -120,6 +123,8 @@ __global__ __launch_bounds__(256) void bwd_max_kernel(const long long* __restric
         float b = Q[(size_t)i * kH + c];
 #pragma unroll
         for (int f = 0; f < kEF; ++f) b = fmaf(Wn[c * (HI + kEF) + HI + f], es[f], b);
+        if (drop.p_node > 0.f)   // the maximum is taken over the messages AFTER Dropout (0 for a dropped one)
+            b = fmaxf(b, 0.f) * drop_scale(*drop.seed, kDropNodeStep + step_no, (unsigned long long)k * kH + c, drop.p_node);
         if (b > 0.f) {
             if (COUNT) {  // pass 2: the FIRST edge (lowest id k) that attains the maximum, kept as E - k so that 0 means "none"
                 if (__float_as_int(b) == hmax[(size_t)i * kH + c]) atomicMax(&hcnt[(size_t)i * kH + c], (int)(E - k));
@@ -244,7 +249,9 @@ __global__ __launch_bounds__(256) void bwd_edge_kernel(const BwdEdgeParams p) {
                         for (int f = 0; f < kEF; ++f) z1 = fmaf(Wc1[q * kEF + f], es[f], z1);
                         const float zh = (z1 - bn_stat[2 * q]) * bn_stat[2 * q + 1];
                         const float y = fmaf(bn_gamma[q], zh, bn_beta[q]);
-                        const float gy = y > 0.f ? Wc2[q] * dz : 0.f;
+                        const float sc = p.drop.p_cls > 0.f ? drop_scale(*p.drop.seed, kDropCls + p.cls_no, (unsigned long long)k * p.cls_hidden + q,
+                                                                         p.drop.p_cls) : 1.f;
+                        const float gy = y > 0.f ? Wc2[q] * dz * sc : 0.f;
                         float gz1 = live * bn_gamma[q] * bn_stat[2 * q + 1] * (gy - bn_red[2 * q] - zh * bn_red[2 * q + 1]);
                         if (q0 + u >= p.cls_hidden) gz1 = 0.f;
                         v[8 * u] = gz1;
@@ -276,8 +283,10 @@ __global__ __launch_bounds__(256) void bwd_edge_kernel(const BwdEdgeParams p) {
                         float z1 = bc1[q];
 #pragma unroll
                         for (int f = 0; f < kEF; ++f) z1 = fmaf(Wc1[q * kEF + f], es[f], z1);
-                        const float gz1 = (on && z1 > 0.f) ? Wc2[q] * dz : 0.f;
-                        v[8 * u] = on ? dz * fmaxf(z1, 0.f) : 0.f;
+                        const float sc = p.drop.p_cls > 0.f ? drop_scale(*p.drop.seed, kDropCls + p.cls_no, (unsigned long long)k * p.cls_hidden + q,
+                                                                         p.drop.p_cls) : 1.f;
+                        const float gz1 = (on && z1 > 0.f) ? Wc2[q] * dz * sc : 0.f;
+                        v[8 * u] = on ? dz * fmaxf(z1, 0.f) * sc : 0.f;
                         v[8 * u + 1] = gz1;
 #pragma unroll
                         for (int f = 0; f < kEF; ++f) {
@@ -322,11 +331,14 @@ __global__ __launch_bounds__(256) void bwd_edge_kernel(const BwdEdgeParams p) {
                     // (every edge whose six features are dead has b = Q[row][c]), which edge of a tie gets the gradient only
                     // matters for the per-edge terms: the parameter gradients of tied DEAD or DUPLICATE edges are the same either way.
                     float gb = 0.f;
+                    const float scn = p.drop.p_node > 0.f ? drop_scale(*p.drop.seed, kDropNodeStep + p.step_no, (unsigned long long)k * kH + c,
+                                                                       p.drop.p_node) : 1.f;
+                    if (p.drop.p_node > 0.f) b = fmaxf(b, 0.f) * scn;   // the message as aggregated: after ReLU and Dropout
                     if (b > 0.f) {
                         if (p.hmax == nullptr)
-                            gb = gh_row[c] * inv * live;
+                            gb = gh_row[c] * inv * live * scn;
                         else if (__float_as_int(b) == hm_row[c] && p.hcnt[(size_t)i * kH + c] == (int)(p.E - k))
-                            gb = gh_row[c] * live;
+                            gb = gh_row[c] * live * scn;
                     }
                     v[8 * u] = gb;
                     v[8 * u + 7] = 0.f;
@@ -345,10 +357,11 @@ __global__ __launch_bounds__(256) void bwd_edge_kernel(const BwdEdgeParams p) {
             }
         }
         // ---- edge update -----------------------------------------------------------------------------------------
+        const float inv_keep_edge = 1.f / (1.f - p.drop.p_edge);
         float ga[kEF];
 #pragma unroll
         for (int f = 0; f < kEF; ++f) {
-            ga[f] = es[f] > 0.f ? ge[f] : 0.f;
+            ga[f] = es[f] > 0.f ? ge[f] * inv_keep_edge : 0.f;   // es > 0 <=> positive AND kept (the saved latent is post-Dropout)
             if (ga[f] != 0.f) {
                 add_row(f, ga[f]);
                 atomicAdd(&p.dP[(size_t)j * 44 + 6 + f], ga[f]);
@@ -480,7 +493,7 @@ __global__ __launch_bounds__(256) void cls_bn_apply_kernel(const float* __restri
                                                            const float* __restrict__ b1, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, const float* __restrict__ stat,
                                                            const float* __restrict__ W2, const float* __restrict__ b2, int C1,
-                                                           float* __restrict__ logits) {
+                                                           float* __restrict__ logits, DropCfg drop, int cls_no) {
     const long long k = (long long)blockIdx.x * 256 + threadIdx.x;
     if (k >= E) return;
     float es[kEF];
@@ -491,8 +504,9 @@ __global__ __launch_bounds__(256) void cls_bn_apply_kernel(const float* __restri
         float z = b1[q];
 #pragma unroll
         for (int f = 0; f < kEF; ++f) z = fmaf(W1[q * kEF + f], es[f], z);
-        const float y = fmaf(gamma[q], (z - stat[2 * q]) * stat[2 * q + 1], beta[q]);
-        logit = fmaf(W2[q], fmaxf(y, 0.f), logit);
+        float y = fmaxf(fmaf(gamma[q], (z - stat[2 * q]) * stat[2 * q + 1], beta[q]), 0.f);
+        if (drop.p_cls > 0.f) y *= drop_scale(*drop.seed, kDropCls + cls_no, (unsigned long long)k * C1 + q, drop.p_cls);
+        logit = fmaf(W2[q], y, logit);
     }
     logits[k] = logit;
 }
@@ -503,7 +517,7 @@ __global__ __launch_bounds__(256) void bwd_cls_bn_reduce_kernel(const float* __r
                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                 const float* __restrict__ stat, const float* __restrict__ W2, int C1,
                                                                 double* __restrict__ sums, float* __restrict__ gW2,
-                                                                float* __restrict__ gb2) {
+                                                                float* __restrict__ gb2, DropCfg drop, int cls_no) {
     const long long k0 = (long long)blockIdx.x * 256 + threadIdx.x;
     const bool valid = k0 < E;
     const long long k = valid ? k0 : E - 1;
@@ -518,8 +532,9 @@ __global__ __launch_bounds__(256) void bwd_cls_bn_reduce_kernel(const float* __r
         for (int f = 0; f < kEF; ++f) z = fmaf(W1[q * kEF + f], es[f], z);
         const float zh = (z - stat[2 * q]) * stat[2 * q + 1];
         const float y = fmaf(gamma[q], zh, beta[q]);
-        wave_atomic_add(gW2 + q, dz * fmaxf(y, 0.f));
-        const double gy = y > 0.f ? (double)(W2[q] * dz) : 0.0;
+        const float sc = drop.p_cls > 0.f ? drop_scale(*drop.seed, kDropCls + cls_no, (unsigned long long)k * C1 + q, drop.p_cls) : 1.f;
+        wave_atomic_add(gW2 + q, dz * fmaxf(y, 0.f) * sc);
+        const double gy = y > 0.f ? (double)(W2[q] * dz * sc) : 0.0;
         const double s1 = wave_reduce_sum_d(gy), s2 = wave_reduce_sum_d(gy * (double)zh);
         if ((threadIdx.x & 63) == 0) {
             atomicAdd(&sums[q], s1);
@@ -659,28 +674,36 @@ static hipError_t launch_outer(const float* A, int lda, const float* B, int ldb,
 }
 
 // g[t] = y[t] > 0 ? g[t] : 0     (ReLU backward from the saved output)
-__global__ __launch_bounds__(256) void bwd_relu_mask_kernel(float* __restrict__ g, const float* __restrict__ y, long long n) {
+// g *= (y > 0) * scale: ReLU' from the saved output; with Dropout the saved output is post-Dropout (y > 0 <=> positive and kept)
+// and scale = 1 / (1 - p)
+__global__ __launch_bounds__(256) void bwd_relu_mask_kernel(float* __restrict__ g, const float* __restrict__ y, long long n, float scale) {
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (t < n && !(y[t] > 0.f)) g[t] = 0.f;
+    if (t < n) g[t] = y[t] > 0.f ? g[t] * scale : 0.f;
+}
+
+// y[t] *= Dropout scale of element t of `stream` (re-derives the forward's mask on a recomputed activation)
+__global__ __launch_bounds__(256) void apply_dropout_kernel(float* __restrict__ y, long long n, DropCfg drop, unsigned stream, float p) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t < n) y[t] *= drop_scale(*drop.seed, stream, (unsigned long long)t, p);
 }
 
 // out[n][k] = (y[n][k] > 0) * sum_o G[n][o] W[o][k]      (d activation of the previous layer)
 __global__ __launch_bounds__(256) void bwd_matmul_mask_kernel(const float* __restrict__ G, const float* __restrict__ W,
                                                               const float* __restrict__ y, float* __restrict__ out, int N, int O,
-                                                              int K) {
+                                                              int K, float scale) {
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
     if (t >= (long long)N * K) return;
     const int n = (int)(t / K), k = (int)(t - (long long)n * K);
     float acc = 0.f;
     for (int o = 0; o < O; ++o) acc = fmaf(G[(size_t)n * O + o], W[(size_t)o * K + k], acc);
-    out[t] = y[t] > 0.f ? acc : 0.f;
+    out[t] = y[t] > 0.f ? acc * scale : 0.f;
 }
 
 // edge encoder backward: g_e0 -> ReLU' -> d W_e0 [6][A], d b_e0.  Persistent grid with LDS-resident sums like
 // bwd_edge_kernel (A <= 7; wider raw edge attributes take one atomic per wave and value).
 __global__ __launch_bounds__(256) void bwd_edge_enc_kernel(const float* __restrict__ ge0, const float* __restrict__ e0,
                                                            const float* __restrict__ attr, int A, long long E,
-                                                           float* __restrict__ gW, float* __restrict__ gb) {
+                                                           float* __restrict__ gW, float* __restrict__ gb, float scale) {
     __shared__ float s_acc[kEF * 8];  // [f][0] d b[f], [f][1 + a] d W[f][a]
     for (int t = threadIdx.x; t < kEF * 8; t += 256) s_acc[t] = 0.f;
     __syncthreads();
@@ -698,7 +721,7 @@ __global__ __launch_bounds__(256) void bwd_edge_enc_kernel(const float* __restri
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     const int f = f0 + u;
-                    const float g = (valid && e0[k * kEF + f] > 0.f) ? ge0[k * kEF + f] : 0.f;
+                    const float g = (valid && e0[k * kEF + f] > 0.f) ? ge0[k * kEF + f] * scale : 0.f;
                     v[8 * u] = g;
 #pragma unroll
                     for (int a = 0; a < 7; ++a) v[8 * u + 1 + a] = g * at[a];
@@ -707,7 +730,7 @@ __global__ __launch_bounds__(256) void bwd_edge_enc_kernel(const float* __restri
             }
         } else {
             for (int f = 0; f < kEF; ++f) {
-                const float g = (valid && e0[k * kEF + f] > 0.f) ? ge0[k * kEF + f] : 0.f;
+                const float g = (valid && e0[k * kEF + f] > 0.f) ? ge0[k * kEF + f] * scale : 0.f;
                 wave_atomic_add(gb + f, g);
                 for (int a = 0; a < A; ++a) wave_atomic_add(gW + f * A + a, g * attr[k * A + a]);
             }

@@ -104,4 +104,33 @@ static int prof_end(Profiler* p, hipStream_t st) {
 
 static inline dim3 grid1(size_t n, int b) { return dim3((unsigned)((n + b - 1) / b)); }
 
+// ---- train-mode Dropout (models/mlp.py:20-21: nn.Dropout after the ReLU of every MLP layer wider than 1) ---------------------------
+// Masks are never stored: element `idx` of the activation tensor identified by `stream` is kept iff a counter-based hash of
+// (seed, stream, idx) says so, and forward and backward evaluate the same hash.  idx = row * width + column with row = the node
+// id or the CALLER's edge id.  oracle/mpn_oracle.py:dropout_keep is the numpy twin (tests, goldens).
+enum : unsigned {
+    kDropEncNode1 = 1, kDropEncNode2 = 2, kDropEncEdge = 3,
+    kDropEdgeStep = 16,   // + step (1-based)
+    kDropNodeStep = 48,   // + step
+    kDropCls = 80,        // + index of the classified step (0-based)
+};
+struct DropCfg {          // device-side view of gnncca_dropout; p == 0 everywhere when dropout is off
+    float p_enc, p_edge, p_node, p_cls;
+    const unsigned long long* seed;   // device word, read by the kernels (a captured training step replays with fresh masks)
+};
+__device__ __forceinline__ unsigned drop_hash(unsigned long long seed, unsigned stream, unsigned long long idx) {
+    unsigned long long x = idx * 0x9E3779B97F4A7C15ull + (seed ^ ((unsigned long long)stream * 0xD1B54A32D192ED03ull));
+    x ^= x >> 32;
+    x *= 0xD6E8FEB86659FD93ull;
+    x ^= x >> 32;
+    x *= 0xD6E8FEB86659FD93ull;
+    x ^= x >> 32;
+    return (unsigned)x;
+}
+// 0 (dropped) or 1 / (1 - p) (kept): uniform u = (hash >> 8) * 2^-24 in [0, 1), kept iff u >= p
+__device__ __forceinline__ float drop_scale(unsigned long long seed, unsigned stream, unsigned long long idx, float p) {
+    const float u = (float)(drop_hash(seed, stream, idx) >> 8) * (1.0f / 16777216.0f);
+    return u >= p ? 1.0f / (1.0f - p) : 0.0f;
+}
+
 }  // namespace gnncca

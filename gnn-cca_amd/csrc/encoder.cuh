@@ -562,6 +562,7 @@ struct TailParams {
     unsigned* flags;
     const unsigned* blockflags;
     int E;
+    DropCfg drop;   // train-mode Dropout (enc_tail_kernel only): p_enc on both encoder layers
 };
 
 __global__ __launch_bounds__(256) void enc_tail_kernel(const TailParams p) {
@@ -635,13 +636,19 @@ __global__ __launch_bounds__(256) void enc_tail_kernel(const TailParams p) {
                 for (int f = lane; f < p.F; f += 64) {
                     float v = f < 64 ? prev_b0 : (f < 128 ? prev_b1 : blob[p.off_prev_b + f]);
                     for (int gg = 0; gg < groups; ++gg) v += redbuf[gg * p.F + f];
-                    rowbuf[f] = p.relu_prev ? fmaxf(v, 0.f) : v;
+                    v = p.relu_prev ? fmaxf(v, 0.f) : v;
+                    if (p.drop.p_enc > 0.f && p.relu_prev)
+                        v *= drop_scale(*p.drop.seed, kDropEncNode1, (unsigned long long)node * p.F + f, p.drop.p_enc);
+                    rowbuf[f] = v;
                 }
             } else {
                 for (int f = lane; f < p.F; f += 64) {
                     float v = blob[p.off_prev_b + f];
                     for (int s = 0; s < p.ks; ++s) v += p.part[((size_t)s * p.N + node) * p.F + f];
-                    rowbuf[f] = p.relu_prev ? fmaxf(v, 0.f) : v;
+                    v = p.relu_prev ? fmaxf(v, 0.f) : v;
+                    if (p.drop.p_enc > 0.f && p.relu_prev)
+                        v *= drop_scale(*p.drop.seed, kDropEncNode1, (unsigned long long)node * p.F + f, p.drop.p_enc);
+                    rowbuf[f] = v;
                 }
             }
         }
@@ -668,6 +675,7 @@ __global__ __launch_bounds__(256) void enc_tail_kernel(const TailParams p) {
                 float acc = (acc0 + acc1) + (acc2 + acc3);
                 acc += __shfl_xor(acc, 32);
                 hv = fmaxf(acc + last_b, 0.f);
+                if (p.drop.p_enc > 0.f) hv *= drop_scale(*p.drop.seed, kDropEncNode2, (unsigned long long)node * kH + o, p.drop.p_enc);
             } else {
                 hv = rowbuf[o];
             }

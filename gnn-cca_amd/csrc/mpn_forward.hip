@@ -56,7 +56,7 @@ int gnncca_read_graph_flags(const void* workspace, uint32_t* flags_out, gnncca_s
 static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const float* x, const int64_t* edge_index,
                         const float* edge_attr, int64_t n_nodes, int64_t n_edges, void* workspace, size_t workspace_bytes,
                         float* logits_out, const gnncca_trace* trace, gnncca_stream_t stream, Profiler* prof,
-                        uint32_t options) {
+                        uint32_t options, const gnncca_dropout* dropout = nullptr) {
     if (!dims_valid(d) || n_nodes < 0 || n_edges < 0) return GNNCCA_ERR_INVALID_ARG;
     const Family fam = classify(d);
     if (fam == kFamilyNone) return GNNCCA_ERR_UNSUPPORTED;
@@ -64,6 +64,20 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
     if (n_nodes == 0) return n_edges == 0 ? GNNCCA_OK : GNNCCA_ERR_INVALID_ARG;
     if (!packed_dev || !x || !workspace) return GNNCCA_ERR_INVALID_ARG;
     if (n_edges > 0 && (!edge_index || !edge_attr || !logits_out)) return GNNCCA_ERR_INVALID_ARG;
+    DropCfg drop;
+    std::memset(&drop, 0, sizeof(drop));
+    if (dropout && (dropout->p_enc > 0.f || dropout->p_edge > 0.f || dropout->p_node > 0.f || dropout->p_cls > 0.f)) {
+        // train-mode Dropout lives in the general (traced) kernels of the MFMA family only
+        if (fam != kFamilyMfma32x6 || !trace || !trace->h_enc || !trace->e_enc || !trace->h_steps || !trace->e_steps ||
+            !dropout->seed_dev || d->enc_node.n_layers != 2)
+            return fam == kFamilyMfma32x6 ? GNNCCA_ERR_INVALID_ARG : GNNCCA_ERR_UNSUPPORTED;
+        const float ps[4] = {dropout->p_enc, dropout->p_edge, dropout->p_node, dropout->p_cls};
+        for (float q : ps)
+            if (!(q >= 0.f && q < 1.f)) return GNNCCA_ERR_INVALID_ARG;
+        drop.p_enc = dropout->p_enc, drop.p_edge = dropout->p_edge, drop.p_node = dropout->p_node, drop.p_cls = dropout->p_cls;
+        drop.seed = reinterpret_cast<const unsigned long long*>(dropout->seed_dev);
+    }
+    const bool dropping = drop.seed != nullptr;
     if (fam == kFamilyGeneric)
         return forward_generic(d, packed_dev, x, edge_index, edge_attr, n_nodes, n_edges, workspace, workspace_bytes,
                                logits_out, trace, static_cast<hipStream_t>(stream));
@@ -141,7 +155,7 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
             static const bool force_direct = std::getenv("GNNCCA_GEMM_DIRECT") != nullptr;  // diagnostics: A/B the GEMMs
             static const bool no_fuse = std::getenv("GNNCCA_NO_FUSE") != nullptr;             // A/B against GEMM + tail launch
             static const int lds_min = std::getenv("GNNCCA_GEMM_LDS_MIN") ? std::atoi(std::getenv("GNNCCA_GEMM_LDS_MIN")) : 12288;
-            const bool fusable = !no_fuse && nl == 2 && d->enc_node.layers[1].in_dim == 128 && d->enc_node.layers[1].out_dim == kH &&
+            const bool fusable = !no_fuse && !dropping && nl == 2 && d->enc_node.layers[1].in_dim == 128 && d->enc_node.layers[1].out_dim == kH &&
                                  !d->reattach_nodes && hdr.proj_wT != 0;
             const bool use_lds = N >= lds_min && O == 128 && !force_direct;
             if (use_lds) ks_split = std::min(enc_lds_ksplit(N, K), ws.ksplit);
@@ -270,14 +284,15 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
         tp.flags = flags;
         tp.blockflags = blockflags;
         tp.E = E;
+        tp.drop = drop;
         const unsigned blocks = (unsigned)std::min<size_t>(((size_t)N + 3) / 4, 2048) + 1;  // + plan-repair workgroup
         // register-resident tail in the latency-bound regime only: on big batches it is VALU-bound (readlane traffic) and
         // measured 15 % slower than the LDS form (72 vs 62 us at N = 65 536)
-        const bool tail_fast = N < 4096 && tp.F == 128 && tp.has_last && !tp.reatt_n && tp.trace_h == nullptr && tp.vec_reduce &&
+        const bool tail_fast = !dropping && N < 4096 && tp.F == 128 && tp.has_last && !tp.reatt_n && tp.trace_h == nullptr && tp.vec_reduce &&
                                (reinterpret_cast<uintptr_t>(part) & 15) == 0;
         // batches whose GEMM ran split-K: the tail on the matrix pipe, 32 nodes per workgroup
         static const bool no_mfma_tail = std::getenv("GNNCCA_NO_MFMA_TAIL") != nullptr;  // diagnostics: A/B the two tails
-        const bool tail_mfma = !fused_tail && !no_mfma_tail && N >= 8192 && tp.F == 128 && tp.has_last && nl == 2 && !tp.reatt_n &&
+        const bool tail_mfma = !dropping && !fused_tail && !no_mfma_tail && N >= 8192 && tp.F == 128 && tp.has_last && nl == 2 && !tp.reatt_n &&
                                (reinterpret_cast<uintptr_t>(part) & 15) == 0;
         if (fused_tail) {
             // nothing: h0, the projections and the plan's flag word all came out of the GEMM launch
@@ -341,6 +356,7 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
     sp.pd_lds = (N <= 1024) && d->num_enc_steps > 0;
     sp.e_bf16 = (options & GNNCCA_OPT_EDGE_STATE_BF16) != 0;  // honoured by the specialised kernels only
     sp.ell_S = use_ell ? ws.ell_S : 0;
+    sp.drop = drop;
     {
         static const bool no_nt = std::getenv("GNNCCA_NO_NT") != nullptr;  // diagnostics: A/B the cache policy
         const double state_bytes = (double)(sp.e_bf16 ? kEF / 2 : kEF) * (double)ws.e_stride * 4.0;
@@ -363,6 +379,8 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
         const bool want_h = trace && trace->h_steps;
         const bool msg = step < L || want_h;
         sp.first = step == 1;
+        sp.step_no = step;
+        sp.cls_no = out_idx;
         sp.stamp_slot = 2 + (step - 1 < 6 ? step - 1 : 5);
         sp.update = 1;
         sp.store_e = step < L;
@@ -403,6 +421,13 @@ int gnncca_mpn_forward_ex(const gnncca_mpn_dims* d, const void* packed_dev, cons
                           float* logits_out, const gnncca_trace* trace, uint32_t options, gnncca_stream_t stream) {
     return forward_impl(d, packed_dev, x, edge_index, edge_attr, n_nodes, n_edges, workspace, workspace_bytes, logits_out,
                         trace, stream, nullptr, options);
+}
+
+int gnncca_mpn_forward_train(const gnncca_mpn_dims* d, const void* packed_dev, const float* x, const int64_t* edge_index,
+                             const float* edge_attr, int64_t n_nodes, int64_t n_edges, void* workspace, size_t workspace_bytes,
+                             float* logits_out, const gnncca_trace* trace, const gnncca_dropout* dropout, gnncca_stream_t stream) {
+    return forward_impl(d, packed_dev, x, edge_index, edge_attr, n_nodes, n_edges, workspace, workspace_bytes, logits_out,
+                        trace, stream, nullptr, 0u, dropout);
 }
 
 int gnncca_mpn_forward_profiled(const gnncca_mpn_dims* d, const void* packed_dev, const float* x,
@@ -515,6 +540,23 @@ int gnncca_post_prune_cluster_frames(const int64_t* edge_index, const int64_t* p
 
 
 // ---- backward ---------------------------------------------------------------------------
+// gnncca_dropout -> DropCfg; GNNCCA_OK with all p == 0 for a null / inactive one
+static int drop_cfg(const gnncca_dropout* dropout, DropCfg* out) {
+    std::memset(out, 0, sizeof(*out));
+    if (!dropout) return GNNCCA_OK;
+    const float ps[4] = {dropout->p_enc, dropout->p_edge, dropout->p_node, dropout->p_cls};
+    bool any = false;
+    for (float q : ps) {
+        if (!(q >= 0.f && q < 1.f)) return GNNCCA_ERR_INVALID_ARG;
+        any = any || q > 0.f;
+    }
+    if (!any) return GNNCCA_OK;
+    if (!dropout->seed_dev) return GNNCCA_ERR_INVALID_ARG;
+    out->p_enc = dropout->p_enc, out->p_edge = dropout->p_edge, out->p_node = dropout->p_node, out->p_cls = dropout->p_cls;
+    out->seed = reinterpret_cast<const unsigned long long*>(dropout->seed_dev);
+    return GNNCCA_OK;
+}
+
 static bool backward_ok(const gnncca_mpn_dims* d) {
     if (classify(d) != kFamilyMfma32x6) return false;
     if (d->num_enc_steps < 1) return false;
@@ -544,6 +586,17 @@ static int param_index(const gnncca_mpn_dims* d, int mi, int l) {
 int gnncca_classifier_train(const gnncca_mpn_dims* d, const float* const* params_dev, int n_params, const float* e_steps,
                             int64_t n_edges, void* scratch /* 2*C1 doubles */, float* bn_stat_out /* [n_out][C1][2] */,
                             float* logits_out, gnncca_stream_t stream) {
+    return gnncca_classifier_train_dropout(d, params_dev, n_params, e_steps, n_edges, scratch, bn_stat_out, logits_out, nullptr, stream);
+}
+
+int gnncca_classifier_train_dropout(const gnncca_mpn_dims* d, const float* const* params_dev, int n_params, const float* e_steps,
+                                    int64_t n_edges, void* scratch /* 2*C1 doubles */, float* bn_stat_out /* [n_out][C1][2] */,
+                                    float* logits_out, const gnncca_dropout* dropout, gnncca_stream_t stream) {
+    DropCfg drop;
+    {
+        const int ds = drop_cfg(dropout, &drop);
+        if (ds != GNNCCA_OK) return ds;
+    }
     if (!dims_valid(d) || !params_dev || n_params != gnncca_param_count(d) || n_edges < 0) return GNNCCA_ERR_INVALID_ARG;
     if (!backward_ok(d) || d->cls_edge.n_layers != 2 || !d->cls_edge.layers[0].has_bn) return GNNCCA_ERR_UNSUPPORTED;
     if (n_edges == 0) return GNNCCA_OK;
@@ -565,7 +618,7 @@ int gnncca_classifier_train(const gnncca_mpn_dims* d, const float* const* params
         hipLaunchKernelGGL(cls_bn_stats_kernel, grid1((size_t)E, 256), dim3(256), 0, st, e, E, W1, b1, C1, sums);
         hipLaunchKernelGGL(cls_bn_finalize_kernel, dim3(1), dim3(64), 0, st, (const double*)sums, E, C1, stat, rm, rv);
         hipLaunchKernelGGL(cls_bn_apply_kernel, grid1((size_t)E, 256), dim3(256), 0, st, e, E, W1, b1, gamma, beta, (const float*)stat,
-                           W2, b2, C1, logits_out + (size_t)li * E);
+                           W2, b2, C1, logits_out + (size_t)li * E, drop, li);
         HIP_TRY(hipGetLastError());
         ++li;
     }
@@ -629,6 +682,20 @@ int gnncca_mpn_backward_ex(const gnncca_mpn_dims* d, const float* const* params_
                            const gnncca_trace* saved, const float* cls_bn_stat, const float* grad_logits,
                            float* const* grads_dev, void* workspace, size_t workspace_bytes, uint32_t options,
                            gnncca_stream_t stream) {
+    return gnncca_mpn_backward_train(d, params_dev, n_params, x, edge_index, edge_attr, n_nodes, n_edges, saved, cls_bn_stat,
+                                     grad_logits, grads_dev, workspace, workspace_bytes, options, nullptr, stream);
+}
+
+int gnncca_mpn_backward_train(const gnncca_mpn_dims* d, const float* const* params_dev, int n_params, const float* x,
+                              const int64_t* edge_index, const float* edge_attr, int64_t n_nodes, int64_t n_edges,
+                              const gnncca_trace* saved, const float* cls_bn_stat, const float* grad_logits,
+                              float* const* grads_dev, void* workspace, size_t workspace_bytes, uint32_t options,
+                              const gnncca_dropout* dropout, gnncca_stream_t stream) {
+    DropCfg drop;
+    {
+        const int ds = drop_cfg(dropout, &drop);
+        if (ds != GNNCCA_OK) return ds;
+    }
     if (!dims_valid(d) || n_nodes < 0 || n_edges < 0) return GNNCCA_ERR_INVALID_ARG;
     if (!backward_ok(d)) return GNNCCA_ERR_UNSUPPORTED;
     if (n_params != gnncca_param_count(d) || !params_dev || !grads_dev) return GNNCCA_ERR_INVALID_ARG;
@@ -722,9 +789,9 @@ int gnncca_mpn_backward_ex(const gnncca_mpn_dims* d, const float* const* params_
         if (g_h && d->agg == GNNCCA_AGG_MAX) {  // which edge attained each node's maximum
             HIP_TRY(hipMemsetAsync(hmax, 0, (size_t)2 * N * kH * 4, st));
             hipLaunchKernelGGL(bwd_max_kernel<false>, grid1((size_t)E, 256), dim3(256), 0, st, ei, e_cur, (const float*)Q, Wn,
-                               (long long)E, N, HI, hmax, hcnt);
+                               (long long)E, N, HI, hmax, hcnt, drop, s);
             hipLaunchKernelGGL(bwd_max_kernel<true>, grid1((size_t)E, 256), dim3(256), 0, st, ei, e_cur, (const float*)Q, Wn,
-                               (long long)E, N, HI, hmax, hcnt);
+                               (long long)E, N, HI, hmax, hcnt, drop, s);
             HIP_TRY(hipGetLastError());
             bp.hmax = hmax;
             bp.hcnt = hcnt;
@@ -734,7 +801,7 @@ int gnncca_mpn_backward_ex(const gnncca_mpn_dims* d, const float* const* params_
             const float* stat = cls_bn_stat + (size_t)out_idx * c1 * 2;
             HIP_TRY(hipMemsetAsync(bn_sums, 0, sizeof(double) * 2 * c1, st));
             hipLaunchKernelGGL(bwd_cls_bn_reduce_kernel, grid1((size_t)E, 256), dim3(256), 0, st, e_cur, bp.g_logit, (long long)E, Wc1,
-                               bc1, params_dev[12], params_dev[13], stat, Wc2, c1, bn_sums, gWc2, gbc2);
+                               bc1, params_dev[12], params_dev[13], stat, Wc2, c1, bn_sums, gWc2, gbc2, drop, out_idx);
             hipLaunchKernelGGL(bwd_cls_bn_finalize_kernel, dim3(1), dim3(64), 0, st, (const double*)bn_sums, (long long)E, c1, bn_red,
                                grads_dev[12], grads_dev[13]);
             HIP_TRY(hipGetLastError());
@@ -744,6 +811,9 @@ int gnncca_mpn_backward_ex(const gnncca_mpn_dims* d, const float* const* params_
             bp.bn_red = bn_red;
         }
         if (bp.g_logit) --out_idx;
+        bp.drop = drop;
+        bp.step_no = s;
+        bp.cls_no = bp.g_logit ? out_idx + 1 : 0;   // out_idx was already stepped down past this classified step
         bp.ge_in = ge_in;
         bp.ge_out = Gb[s & 1];
         bp.dP = dP;
@@ -797,7 +867,7 @@ int gnncca_mpn_backward_ex(const gnncca_mpn_dims* d, const float* const* params_
     // ---- encoders ---------------------------------------------------------------------------------------------------
     hipLaunchKernelGGL(bwd_edge_enc_kernel, dim3(std::min((unsigned)(((size_t)E + 255) / 256), 512u)), dim3(256), 0, st, ge_in,
                        saved->e_enc, edge_attr, A, (long long)E,
-                       gWe0, gbe0);
+                       gWe0, gbe0, 1.f / (1.f - drop.p_enc));
     HIP_TRY(hipGetLastError());
     {   // a1 = ReLU(x W1^T + b1) is recomputed instead of stored: the forward's split-K MFMA GEMM + its reduce kernel
         int ks = 1;
@@ -822,12 +892,18 @@ int gnncca_mpn_backward_ex(const gnncca_mpn_dims* d, const float* const* params_
         hipLaunchKernelGGL(reduce_bias_act_kernel, grid1((size_t)N * F1, 256), dim3(256), 0, st, (const float*)part, b1, a1, N, F1, ks,
                            1);
         HIP_TRY(hipGetLastError());
+        if (drop.p_enc > 0.f) {   // the forward's layer-2 input was a1 AFTER Dropout: re-derive the same mask
+            hipLaunchKernelGGL(apply_dropout_kernel, grid1((size_t)N * F1, 256), dim3(256), 0, st, a1, (long long)N * F1, drop,
+                               (unsigned)kDropEncNode1, drop.p_enc);
+            HIP_TRY(hipGetLastError());
+        }
     }
     float* gz2 = const_cast<float*>(g_h);  // [N][32] d loss / d h_enc, masked in place
-    hipLaunchKernelGGL(bwd_relu_mask_kernel, grid1((size_t)N * kH, 256), dim3(256), 0, st, gz2, saved->h_enc, (long long)N * kH);
+    const float enc_scale = 1.f / (1.f - drop.p_enc);
+    hipLaunchKernelGGL(bwd_relu_mask_kernel, grid1((size_t)N * kH, 256), dim3(256), 0, st, gz2, saved->h_enc, (long long)N * kH, enc_scale);
     HIP_TRY(launch_outer(gz2, kH, a1, F1, gW2, F1, gb2, N, kH, F1, st));
     hipLaunchKernelGGL(bwd_matmul_mask_kernel, grid1((size_t)N * F1, 256), dim3(256), 0, st, (const float*)gz2, W2, (const float*)a1,
-                       gz1, N, kH, F1);
+                       gz1, N, kH, F1, enc_scale);
     HIP_TRY(launch_outer(gz1, F1, x, D, gW1, D, gb1, N, F1, D, st));
     HIP_TRY(hipGetLastError());
     return GNNCCA_OK;

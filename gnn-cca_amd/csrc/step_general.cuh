@@ -47,6 +47,8 @@ struct StepParams {
     // the kernels then use the compact order for this forward.
     int ell_S;
     int nt_store, nt_load;   // non-temporal policy of the specialised step kernel's streams (see step_fast.cuh)
+    DropCfg drop;            // train-mode Dropout (general kernel only); all p == 0 in eval
+    int step_no, cls_no;     // 1-based step, 0-based index of this classified step: the dropout streams
 };
 
 template <bool REATT_E, bool MSG, bool AGG_MAX>
@@ -136,6 +138,7 @@ __global__ __launch_bounds__(256) void mpn_step_kernel(const StepParams p) {
                     for (int j = 0; j < p.edge_in; ++j) s = fmaf(blob[p.off_encw + f * p.edge_in + j], a[j], s);
                 }
                 e0v[f] = fmaxf(s, 0.f);
+                if (p.drop.p_enc > 0.f) e0v[f] *= drop_scale(*p.drop.seed, kDropEncEdge, (unsigned long long)ko * kEF + f, p.drop.p_enc);
             }
 #pragma unroll
             for (int f = 0; f < kEF; ++f) {
@@ -178,6 +181,8 @@ __global__ __launch_bounds__(256) void mpn_step_kernel(const StepParams p) {
 #pragma unroll
                 for (int g = 0; g < EFIN; ++g) s = fmaf(wee[f * EFIN + g], ein[g], s);
                 en[f] = fmaxf(s, 0.f);
+                if (p.drop.p_edge > 0.f)
+                    en[f] *= drop_scale(*p.drop.seed, kDropEdgeStep + p.step_no, (unsigned long long)ko * kEF + f, p.drop.p_edge);
             }
         } else {
 #pragma unroll
@@ -202,7 +207,10 @@ __global__ __launch_bounds__(256) void mpn_step_kernel(const StepParams p) {
                     float z = blob[p.off_cb1 + q];
 #pragma unroll
                     for (int f = 0; f < kEF; ++f) z = fmaf(blob[p.off_cw1 + q * kEF + f], en[f], z);
-                    logit = fmaf(blob[p.off_cw2 + q], fmaxf(z, 0.f), logit);
+                    z = fmaxf(z, 0.f);
+                    if (p.drop.p_cls > 0.f)
+                        z *= drop_scale(*p.drop.seed, kDropCls + p.cls_no, (unsigned long long)ko * p.cls_hidden + q, p.drop.p_cls);
+                    logit = fmaf(blob[p.off_cw2 + q], z, logit);
                 }
             } else {
                 logit = blob[p.off_cb1];
@@ -225,7 +233,22 @@ __global__ __launch_bounds__(256) void mpn_step_kernel(const StepParams p) {
                 d1 = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(r[1]), bw[s], d1, 0, 0, 0);
             }
             // accumulator register i of lane (ch, half) is edge (i&3) + 8*(i>>2) + 4*half of the tile
-            if (base + 64 <= seg_t) {
+            if (p.drop.p_node > 0.f) {
+                // train-mode Dropout on the messages (node_mlp's output, before aggregation): element (edge ko, channel ch)
+                const unsigned long long seed = *p.drop.seed;
+                const int rem = seg_t - base;
+                const float ident = agg_max ? -INFINITY : 0.f;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int eo = (i & 3) + 8 * (i >> 2) + 4 * half;
+                    const int ko0 = __shfl(ko, eo), ko1 = __shfl(ko, eo + 32);   // caller's ids of the two tiles' edges
+                    float m0 = fmaxf(d0[i], 0.f) * drop_scale(seed, kDropNodeStep + p.step_no, (unsigned long long)ko0 * kH + ch, p.drop.p_node);
+                    float m1 = fmaxf(d1[i], 0.f) * drop_scale(seed, kDropNodeStep + p.step_no, (unsigned long long)ko1 * kH + ch, p.drop.p_node);
+                    if (eo >= rem) m0 = ident;
+                    if (eo + 32 >= rem) m1 = ident;
+                    acc[i] = agg_max ? fmaxf(acc[i], fmaxf(m0, m1)) : acc[i] + (m0 + m1);
+                }
+            } else if (base + 64 <= seg_t) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const float m0 = fmaxf(d0[i], 0.f), m1 = fmaxf(d1[i], 0.f);

@@ -105,8 +105,9 @@ class _MPNTrainFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, module, x, edge_index, edge_attr, *params):
         trace = {}
+        drop, seed = module._dropout_for_this_call(x.device)   # (nat.Dropout or None, the device seed word it points at)
         with torch.no_grad():
-            out = module._forward_native(x, edge_index, edge_attr, trace)
+            out = module._forward_native(x, edge_index, edge_attr, trace, dropout=drop)
             bn_stat = torch.zeros(1, dtype=torch.float32, device=x.device)
             bn = module._classifier_batchnorm()
             if bn is not None and edge_index.shape[1] > 0:
@@ -117,14 +118,15 @@ class _MPNTrainFunction(torch.autograd.Function):
                 scratch = torch.empty(2 * c1, dtype=torch.float64, device=x.device)
                 pp = (C.c_void_p * len(params))(*[p.data_ptr() for p in params])
                 with torch.cuda.device(x.device):
-                    st = lib.gnncca_classifier_train(C.byref(d), pp, len(params), trace['e_steps'].data_ptr(), e,
-                                                     scratch.data_ptr(), bn_stat.data_ptr(), out.data_ptr(),
-                                                     _raw_stream(x.device))
+                    st = lib.gnncca_classifier_train_dropout(C.byref(d), pp, len(params), trace['e_steps'].data_ptr(), e,
+                                                             scratch.data_ptr(), bn_stat.data_ptr(), out.data_ptr(),
+                                                             C.byref(drop) if drop is not None else None, _raw_stream(x.device))
                 nat.check(st, "gnncca_classifier_train")
                 bn.num_batches_tracked += n_out  # one BatchNorm call per classified step (models/mpn.py:292)
         ctx.module = module
         ctx.n_params = len(params)
         ctx.has_bn = bn is not None
+        ctx.drop, ctx.drop_seed = drop, seed   # the backward re-derives the same masks from the same seed word
         ctx.save_for_backward(x, edge_index, edge_attr, trace['h_enc'], trace['e_enc'], trace['h_steps'], trace['e_steps'],
                               bn_stat, *params)
         return out
@@ -150,10 +152,11 @@ class _MPNTrainFunction(torch.autograd.Function):
         ws = torch.empty(lib.gnncca_backward_workspace_bytes(C.byref(d), n, e) + 256, dtype=torch.uint8, device=dev)
         saved = nat.Trace(h_enc.data_ptr(), e_enc.data_ptr(), h_steps.data_ptr(), e_steps.data_ptr())
         with torch.cuda.device(dev):
-            st = lib.gnncca_mpn_backward_ex(C.byref(d), pp, len(params), x.data_ptr(), edge_index.data_ptr(),
-                                            edge_attr.data_ptr(), n, e, C.byref(saved),
-                                            bn_stat.data_ptr() if ctx.has_bn else None, g.data_ptr(), gp, ws.data_ptr(),
-                                            ws.numel(), nat.BWD_GRADS_ZEROED, _raw_stream(dev))
+            st = lib.gnncca_mpn_backward_train(C.byref(d), pp, len(params), x.data_ptr(), edge_index.data_ptr(),
+                                               edge_attr.data_ptr(), n, e, C.byref(saved),
+                                               bn_stat.data_ptr() if ctx.has_bn else None, g.data_ptr(), gp, ws.data_ptr(),
+                                               ws.numel(), nat.BWD_GRADS_ZEROED,
+                                               C.byref(ctx.drop) if ctx.drop is not None else None, _raw_stream(dev))
         nat.check(st, "gnncca_mpn_backward")
         return (None, None, None, None, *[gr if p.requires_grad else None for gr, p in zip(grads, params)])
 
@@ -495,10 +498,43 @@ class MOTMPNet(nn.Module):
                 "train-mode forward/backward on the HIP path covers the shipped config shapes (BatchNorm nowhere or only "
                 "inside the classifier, two-layer node encoder); this configuration is "
                 "outside it (SURVEY.md 8f row N3)")
-        for mod in self.modules():
-            if isinstance(mod, nn.Dropout) and mod.p > 0:
-                raise NotImplementedError("Dropout with p > 0 in train mode is not implemented on the HIP path")
+        self._dropout_ps()   # raises if the Dropout modules of one group disagree
         self._trainable_checked = True
+
+    # -- train-mode Dropout (models/mlp.py:20-21) -------------------------------------------------------------------------
+    def _dropout_ps(self):
+        """(p_enc, p_edge, p_node, p_cls) read from the nn.Dropout modules of the MLPs (so a p edited after construction
+        counts, as on the reference).  The two encoder MLPs share one config entry and one kernel parameter."""
+        def group_p(*mlps):
+            ps = {float(m.p) for mlp in mlps if mlp is not None for m in mlp.fc_layers if isinstance(m, nn.Dropout)}
+            if len(ps) > 1:
+                raise NotImplementedError(f"different Dropout probabilities inside one MLP group ({sorted(ps)}) are not supported")
+            return ps.pop() if ps else 0.0
+        ps = (group_p(self.encoder.node_mlp, self.encoder.edge_mlp), group_p(self.MPNet.edge_model.edge_mlp),
+              group_p(self.MPNet.node_model.node_mlp), group_p(self.classifier.edge_mlp))
+        if any(not 0.0 <= q < 1.0 for q in ps):
+            raise ValueError("Dropout probabilities must lie in [0, 1)")
+        return ps
+
+    def set_dropout_seed(self, seed):
+        """Seed of the train-mode Dropout masks (a device word; it advances by one per training forward).  Without this call
+        the first training forward draws it from torch's RNG."""
+        self._drop_seed_value = int(seed) & 0x7FFFFFFFFFFFFFFF
+        self._drop_seed = None
+
+    def _dropout_for_this_call(self, device):
+        ps = self._dropout_ps()
+        if not any(q > 0 for q in ps):
+            return None, None
+        if getattr(self, '_drop_seed', None) is None or self._drop_seed.device != device:
+            value = getattr(self, '_drop_seed_value', None)
+            if value is None:
+                value = int(torch.randint(0, 2 ** 62, (1,)).item())
+            self._drop_seed = torch.tensor([value], dtype=torch.int64, device=device)
+        seed = self._drop_seed.clone()   # this iteration's word: forward and backward both read it
+        self._drop_seed.add_(1)          # capturable: a replayed training step draws fresh masks
+        drop = nat.Dropout(ps[0], ps[1], ps[2], ps[3], seed.data_ptr())
+        return drop, seed
 
     def _forward_train(self, data):
         self._check_trainable()
@@ -510,8 +546,9 @@ class MOTMPNet(nn.Module):
         logits = _MPNTrainFunction.apply(self, x.detach(), edge_index, edge_attr.detach(), *params)
         return {'classified_edges': list(logits.unbind(0))}
 
-    def _forward_native(self, x, edge_index, edge_attr, trace=None):
-        """Eval-semantics forward through gnncca_mpn_forward; returns logits [n_out, E, 1]."""
+    def _forward_native(self, x, edge_index, edge_attr, trace=None, dropout=None):
+        """Eval-semantics forward through gnncca_mpn_forward (train-mode Dropout when `dropout` is given); returns logits
+        [n_out, E, 1]."""
         lib, d, dev, x, edge_index, edge_attr, n, e, blob, logits, ws = self._prepare(x, edge_index, edge_attr)
         if ws is None:
             if trace is not None:
@@ -530,6 +567,13 @@ class MOTMPNet(nn.Module):
             trace['e_steps'] = torch.empty((L, e, d.edge_dim), dtype=torch.float32, device=dev)
             tr = C.byref(nat.Trace(trace['h_enc'].data_ptr(), trace['e_enc'].data_ptr(),
                                    trace['h_steps'].data_ptr(), trace['e_steps'].data_ptr()))
+        if dropout is not None:
+            with torch.cuda.device(dev):
+                st = lib.gnncca_mpn_forward_train(C.byref(d), blob.data_ptr(), x.data_ptr(), edge_index.data_ptr(),
+                                                  edge_attr.data_ptr(), n, e, ws.data_ptr(), ws.numel(), logits.data_ptr(), tr,
+                                                  C.byref(dropout), _raw_stream(dev))
+            nat.check(st, "gnncca_mpn_forward_train")
+            return logits
         args = (C.byref(d), blob.data_ptr(), x.data_ptr(), edge_index.data_ptr(), edge_attr.data_ptr(), n, e, ws.data_ptr(),
                 ws.numel(), logits.data_ptr(), tr, self._options(), _raw_stream(dev))
         if torch._C._cuda_getDevice() == dev.index:   # the usual case: no device guard to enter and leave

@@ -166,6 +166,18 @@ GNNCCA_API int gnncca_mpn_forward_profiled(const gnncca_mpn_dims* dims, const vo
                                 int64_t n_edges, void* workspace, size_t workspace_bytes, float* logits_out,
                                 gnncca_stream_t stream, gnncca_profile* profile);
 
+/* Train-mode Dropout (models/mlp.py:20-21; config keys `dropout_p` of encoder_feats_dict / edge_model_feats_dict /
+ * node_model_feats_dict / classifier_feats_dict).  Masks are generated on the device by a counter-based hash of
+ * (*seed_dev, tensor, element) and are NOT stored: the backward evaluates the same hash, so both calls of one training
+ * iteration must see the same seed word.  p = 0 switches a group off; a null pointer switches everything off. */
+typedef struct gnncca_dropout {
+    float p_enc;    /* encoder.node_mlp and encoder.edge_mlp */
+    float p_edge;   /* MPNet.edge_model.edge_mlp             */
+    float p_node;   /* MPNet.node_model.node_mlp (the messages, before aggregation) */
+    float p_cls;    /* classifier.edge_mlp                   */
+    const uint64_t* seed_dev;   /* DEVICE word */
+} gnncca_dropout;
+
 /* gnncca_mpn_forward with options.  GNNCCA_OPT_EDGE_STATE_BF16: keep the edge latents BETWEEN steps as bf16 in HBM
  * (round to nearest even; all arithmetic, the classifier input and every other buffer stay fp32) -- halves the
  * dominant traffic of the step kernels; honoured by the specialised kernels (shipped config shape), ignored elsewhere.
@@ -269,6 +281,24 @@ GNNCCA_API int gnncca_mpn_backward_ex(const gnncca_mpn_dims* dims, const float* 
 GNNCCA_API int gnncca_classifier_train(const gnncca_mpn_dims* dims, const float* const* params_dev, int n_params,
                                        const float* e_steps, int64_t n_edges, void* scratch, float* bn_stat_out,
                                        float* logits_out, gnncca_stream_t stream);
+
+/* Train-mode variants with Dropout (train.py:454-494 with `dropout_p` > 0 somewhere in GRAPH_NET_PARAMS): the same three
+ * calls with a gnncca_dropout; `trace` is required (the post-dropout latents it receives are what the backward reads, and
+ * they carry the ReLU x Dropout masks of every saved activation: y_saved > 0 <=> kept and positive).  A null `dropout`
+ * makes each of them its plain counterpart. */
+GNNCCA_API int gnncca_mpn_forward_train(const gnncca_mpn_dims* dims, const void* packed_dev, const float* x,
+                                        const int64_t* edge_index, const float* edge_attr, int64_t n_nodes, int64_t n_edges,
+                                        void* workspace, size_t workspace_bytes, float* logits_out, const gnncca_trace* trace,
+                                        const gnncca_dropout* dropout, gnncca_stream_t stream);
+GNNCCA_API int gnncca_classifier_train_dropout(const gnncca_mpn_dims* dims, const float* const* params_dev, int n_params,
+                                               const float* e_steps, int64_t n_edges, void* scratch, float* bn_stat_out,
+                                               float* logits_out, const gnncca_dropout* dropout, gnncca_stream_t stream);
+GNNCCA_API int gnncca_mpn_backward_train(const gnncca_mpn_dims* dims, const float* const* params_dev, int n_params,
+                                         const float* x, const int64_t* edge_index, const float* edge_attr, int64_t n_nodes,
+                                         int64_t n_edges, const gnncca_trace* saved, const float* cls_bn_stat,
+                                         const float* grad_logits, float* const* grads_dev, void* workspace,
+                                         size_t workspace_bytes, uint32_t options, const gnncca_dropout* dropout,
+                                         gnncca_stream_t stream);
 
 /* Synchronises `stream` and returns the flag word of the last forward that used `workspace`. */
 GNNCCA_API int gnncca_read_graph_flags(const void* workspace, uint32_t* flags_out, gnncca_stream_t stream);

@@ -247,6 +247,29 @@ def load_case(path):
 # --------------------------------------------------------------------------------------------------
 # train-mode flavour with autograd (row N3): the reference's forward under torch autograd
 # --------------------------------------------------------------------------------------------------
+# ---- train-mode Dropout: numpy twin of the device-side mask generator (gnn-cca_amd/csrc/common.cuh: drop_hash / drop_scale) ----------
+DROP_ENC_NODE1, DROP_ENC_NODE2, DROP_ENC_EDGE, DROP_EDGE_STEP, DROP_NODE_STEP, DROP_CLS = 1, 2, 3, 16, 48, 80
+_M64 = (1 << 64) - 1
+
+
+def dropout_scale(seed, stream, rows, cols, p):
+    """[rows, cols] float32 array of 0 (dropped) or 1 / (1 - p) (kept) for the activation tensor `stream` (DROP_* + step):
+    element idx = row * cols + col is kept iff the hash of (seed, stream, idx) maps to u >= p.  Same integer arithmetic as the
+    kernels (uint64 wrap-around), so forward, backward and this oracle agree on every mask."""
+    with np.errstate(over="ignore"):
+        idx = np.arange(rows * cols, dtype=np.uint64)
+        key = np.uint64((int(seed) & _M64) ^ ((int(stream) * 0xD1B54A32D192ED03) & _M64))
+        x = idx * np.uint64(0x9E3779B97F4A7C15) + key
+        x ^= x >> np.uint64(32)
+        x *= np.uint64(0xD6E8FEB86659FD93)
+        x ^= x >> np.uint64(32)
+        x *= np.uint64(0xD6E8FEB86659FD93)
+        x ^= x >> np.uint64(32)
+    u = ((x & np.uint64(0xFFFFFFFF)) >> np.uint64(8)).astype(np.float32) * np.float32(1.0 / 16777216.0)
+    keep = u >= np.float32(p)
+    return (keep.astype(np.float32) * (np.float32(1.0) / (np.float32(1.0) - np.float32(p)))).reshape(rows, cols)
+
+
 _SCATTER_MAX_FN = None
 
 
@@ -283,18 +306,27 @@ def _scatter_max_first(torch, src, index, dim_size):
 
 class TorchTrainOracle(TorchOracle):
     """TorchOracle with gradients: parameters are autograd leaves, BatchNorm1d runs in TRAIN mode (batch statistics,
-    running buffers updated with momentum 0.1 as torch.nn.BatchNorm1d does, models/mlp.py:15), Dropout must be 0.
+    running buffers updated with momentum 0.1 as torch.nn.BatchNorm1d does, models/mlp.py:15).  Dropout (models/mlp.py:20-21:
+    after the ReLU of every layer wider than 1) is applied with the masks of `dropout_scale` when `dropout` =
+    dict(p_enc=, p_edge=, p_node=, p_cls=, seed=) is given -- the mask generator the HIP kernels use.
     `loss_and_grads` forms the loss exactly as train.py:80-97 does with LOSS NAME 'BCE' (sum over the classified
     steps of BCEWithLogitsLoss(reduction='mean'))."""
 
-    def __init__(self, model_params, arch, sd):
+    def __init__(self, model_params, arch, sd, dropout=None):
         super().__init__(model_params, arch, sd)
         self.buffers = {k: v.clone() for k, v in self.sd.items() if "running_" in k}
         self.sd = {k: (v.clone().requires_grad_(True) if "running_" not in k else v) for k, v in self.sd.items()}
+        self.dropout = dropout
 
-    def _mlp(self, prefix, x):
+    def _drop(self, x, stream, p):
+        if not self.dropout or p <= 0:
+            return x
+        return x * self.torch.from_numpy(dropout_scale(self.dropout["seed"], stream, x.shape[0], x.shape[1], p))
+
+    def _mlp(self, prefix, x, streams=None, drop_p=0.0):
+        """`streams`: per layer, the dropout stream id of that layer's output (None: no dropout on this call)."""
         torch = self.torch
-        for lin, _in, _out, bn, relu in self.lay[prefix]:
+        for li, (lin, _in, _out, bn, relu) in enumerate(self.lay[prefix]):
             p = f"{prefix}.fc_layers.{lin}."
             x = torch.nn.functional.linear(x, self.sd[p + "weight"], self.sd[p + "bias"])
             if bn is not None:
@@ -303,19 +335,23 @@ class TorchTrainOracle(TorchOracle):
                                                    self.sd[q + "weight"], self.sd[q + "bias"], True, 0.1, BN_EPS)
             if relu:
                 x = torch.relu(x)
+                if streams is not None and li < len(streams) and streams[li] is not None:
+                    x = self._drop(x, streams[li], drop_p)   # nn.Dropout sits behind the ReLU (only layers wider than 1 have either)
         return x
 
     def forward(self, x, edge_index, edge_attr):
         torch = self.torch
         lay = self.lay
+        dr = self.dropout or {}
+        p_enc, p_edge, p_node, p_cls = (dr.get(k, 0.0) for k in ("p_enc", "p_edge", "p_node", "p_cls"))
         x = torch.as_tensor(x).float()
         e = torch.as_tensor(edge_attr).float()
         edge_index = torch.as_tensor(edge_index).long()
         row, col = edge_index[0], edge_index[1]
         n = x.shape[0]
         if lay["encoder.edge_mlp"] is not None:
-            e = self._mlp("encoder.edge_mlp", e)
-        h = self._mlp("encoder.node_mlp", x) if lay["encoder.node_mlp"] is not None else x
+            e = self._mlp("encoder.edge_mlp", e, [DROP_ENC_EDGE], p_enc)
+        h = self._mlp("encoder.node_mlp", x, [DROP_ENC_NODE1, DROP_ENC_NODE2], p_enc) if lay["encoder.node_mlp"] is not None else x
         e0, h0 = e, h
         L, first = lay["L"], lay["L"] - lay["n_cls"] + 1
         logits = []
@@ -324,13 +360,13 @@ class TorchTrainOracle(TorchOracle):
                 e = torch.cat((e0, e), dim=1)
             if lay["reattach_nodes"]:
                 h = torch.cat((h0, h), dim=1)
-            e = self._mlp("MPNet.edge_model.edge_mlp", torch.cat([h[row], h[col], e], dim=1))
-            flow = self._mlp("MPNet.node_model.node_mlp", torch.cat([h[row], e], dim=1))
+            e = self._mlp("MPNet.edge_model.edge_mlp", torch.cat([h[row], h[col], e], dim=1), [DROP_EDGE_STEP + step], p_edge)
+            flow = self._mlp("MPNet.node_model.node_mlp", torch.cat([h[row], e], dim=1), [DROP_NODE_STEP + step], p_node)
             h = self._aggregate(flow, row, n)
             if step >= first:
-                logits.append(self._mlp("classifier.edge_mlp", e))
+                logits.append(self._mlp("classifier.edge_mlp", e, [DROP_CLS + len(logits)], p_cls))
         if L == 0:
-            logits.append(self._mlp("classifier.edge_mlp", e))
+            logits.append(self._mlp("classifier.edge_mlp", e, [DROP_CLS], p_cls))
         return logits
 
     def loss_and_grads(self, x, edge_index, edge_attr, labels):

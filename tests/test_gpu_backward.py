@@ -10,7 +10,7 @@ import torch
 
 from conftest import GOLDEN_DIR
 from oracle.mpn_oracle import TorchTrainOracle
-from test_backward_oracle import load_bwd
+from test_backward_oracle import DROP_CASES, load_bwd
 
 pytestmark = pytest.mark.gpu
 CASES = sorted(os.path.basename(p)[4:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "bwd_*.npz")))
@@ -274,3 +274,101 @@ def test_max_aggregation_gradient_goes_to_the_first_arg_max():
             scale = max(1.0, float(np.abs(r).max()))
             assert float(np.abs(p.grad.cpu().numpy() - r).max()) <= 3e-5 * scale, (it, k)
         assert float(np.abs(gw[:8, 32:] - rw[:8, 32:]).max()) <= 3e-5
+
+
+def _dropout_params(name, p_enc, p_edge, p_node, p_cls, **over):
+    """GRAPH_NET_PARAMS of a backward golden with Dropout switched on in the four MLP groups (models/mlp.py:20-21)."""
+    params, arch, sd, _, _, a = load_bwd(name)
+    params = copy.deepcopy(params)
+    params.update(over)
+    params["encoder_feats_dict"]["nodes"][arch]["dropout_p"] = p_enc
+    params["edge_model_feats_dict"]["dropout_p"] = p_edge
+    params["node_model_feats_dict"]["dropout_p"] = p_node
+    params["classifier_feats_dict"]["dropout_p"] = p_cls
+    return params, arch, sd, a
+
+
+@pytest.mark.parametrize("name,ps,over", [
+    ("terrace32", (0.2, 0.1, 0.3, 0.25), {}),
+    ("terrace32", (0.0, 0.0, 0.5, 0.0), {}),                 # only the messages
+    ("terrace32_mean", (0.3, 0.2, 0.0, 0.1), {}),
+    ("terrace32_max", (0.1, 0.1, 0.4, 0.1), {}),             # the maximum is taken over the messages AFTER Dropout
+    ("terrace32_reatt_ne_mean", (0.2, 0.2, 0.2, 0.2), {}),
+    ("cls_bn_train", (0.15, 0.1, 0.2, 0.3), {}),             # train-mode BatchNorm -> ReLU -> Dropout in the classifier
+    ("dense20_shuf", (0.2, 0.1, 0.3, 0.2), {}),              # unsorted rows: masks are indexed by the CALLER's edge ids
+])
+def test_train_mode_dropout_matches_autograd_oracle(name, ps, over):
+    """Dropout with p > 0 in train mode (row N3): logits, loss and every parameter gradient against torch autograd over the
+    CPU oracle, which applies the SAME masks (oracle.dropout_scale is the numpy twin of the kernels' counter-based hash of
+    (seed, tensor, element); nothing is stored between forward and backward on either side)."""
+    from gnn_cca_amd import MOTMPNet
+    params, arch, sd, a = _dropout_params(name, *ps, **over)
+    m = MOTMPNet(copy.deepcopy(params), None, arch)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    m = m.cuda().train()
+    seed = 0x1234ABCD5678
+    m.set_dropout_seed(seed)
+    orc = TorchTrainOracle(params, arch, sd, dropout=dict(p_enc=ps[0], p_edge=ps[1], p_node=ps[2], p_cls=ps[3], seed=seed))
+    ref_loss, ref_logits, ref = orc.loss_and_grads(a["x"], a["edge_index"], a["edge_attr"], a["labels"])
+    d = Data(torch.from_numpy(a["x"]).cuda(), torch.from_numpy(a["edge_index"]).cuda(), torch.from_numpy(a["edge_attr"]).cuda())
+    out = m(d)
+    loss = loss_of(out, torch.from_numpy(a["labels"]).cuda())
+    loss.backward()
+    for t, r in zip(out["classified_edges"], ref_logits):
+        assert np.abs(t.detach().cpu().numpy() - r.numpy()).max() <= 2e-5, name
+    assert abs(float(loss) - ref_loss) <= 1e-5
+    for k, prm in m.named_parameters():
+        r = ref[k].numpy()
+        scale = max(1.0, float(np.abs(r).max()))
+        if k == "classifier.edge_mlp.fc_layers.0.bias" and name == "cls_bn_train":
+            continue   # analytically zero behind a train-mode BatchNorm: rounding residue on both sides
+        assert float(np.abs(prm.grad.cpu().numpy() - r).max()) <= 5e-5 * scale, (name, k)
+    # the seed word advanced: the next forward draws different masks; re-seeding reproduces the first one bit for bit
+    first = torch.cat([t.detach().view(-1) for t in out["classified_edges"]])
+    with torch.no_grad():
+        again = torch.cat([t.view(-1) for t in m(d)["classified_edges"]])
+        m.set_dropout_seed(seed)
+        same = torch.cat([t.view(-1) for t in m(d)["classified_edges"]])
+    if name == "terrace32":   # (some goldens have constant logits: their dead ReLUs hide the masks)
+        assert not torch.equal(again, first)
+    assert torch.equal(same, first)
+    m.eval()
+    with torch.no_grad():   # eval: Dropout is the identity again
+        ev = m(d)["classified_edges"][-1]
+    assert torch.isfinite(ev).all()
+
+
+def test_dropout_keep_rate_and_expectation():
+    """Statistics of the device masks: with only the message Dropout on, the keep rate is 1 - p and E[logit] over seeds
+    approaches the eval-mode logit's neighbourhood (inverted-dropout scaling 1 / (1 - p))."""
+    from oracle.mpn_oracle import dropout_scale
+    keep = np.mean([float((dropout_scale(s, 48 + 1, 768, 32, 0.4) > 0).mean()) for s in range(20)])
+    assert abs(keep - 0.6) < 0.01
+    sc = dropout_scale(7, 3, 100, 6, 0.25)
+    assert set(np.unique(sc).tolist()) <= {0.0, np.float32(1.0 / 0.75)}
+
+
+@pytest.mark.parametrize("name", DROP_CASES)
+def test_train_mode_dropout_matches_reference_golden(name):
+    """The HIP path in train mode with Dropout against the REFERENCE's own module run with the same masks injected
+    (tests/golden/drop_*.npz, make_golden_dropout.py): logits, loss, every parameter gradient."""
+    from gnn_cca_amd import MOTMPNet
+    params, arch, sd, grads, _, a = load_bwd(name, "drop_")
+    m = MOTMPNet(copy.deepcopy(params), None, arch)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    m = m.cuda().train()
+    m.set_dropout_seed(int(a["dropout_seed"]))
+    assert [round(q, 6) for q in m._dropout_ps()] == [round(float(v), 6) for v in a["dropout_p"]]
+    d = Data(torch.from_numpy(a["x"]).cuda(), torch.from_numpy(a["edge_index"]).cuda(), torch.from_numpy(a["edge_attr"]).cuda())
+    out = m(d)
+    loss = loss_of(out, torch.from_numpy(a["labels"]).cuda())
+    loss.backward()
+    assert abs(float(loss) - float(a["loss"])) <= 1e-5
+    for i, t in enumerate(out["classified_edges"]):
+        assert np.abs(t.detach().cpu().numpy() - a[f"logits_{i}"]).max() <= 2e-5
+    for k, ref in grads.items():
+        g = dict(m.named_parameters())[k].grad
+        scale = max(1.0, float(np.abs(ref).max()))
+        if k == "classifier.edge_mlp.fc_layers.0.bias" and "cls_bn" in name:
+            continue   # analytically zero behind a train-mode BatchNorm
+        assert np.abs(g.cpu().numpy() - ref).max() <= 5e-5 * scale, (name, k)

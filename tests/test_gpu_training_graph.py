@@ -50,3 +50,43 @@ def test_graphed_step_trains_like_eager():
     assert losses1[-1] < losses1[0]
     for (k, p1), (_, p2) in zip(m1.state_dict().items(), m2.state_dict().items()):
         assert torch.allclose(p1.float(), p2.float(), rtol=1e-4, atol=1e-6), k
+
+
+def test_graphed_step_with_dropout_draws_fresh_masks_every_replay():
+    """Dropout under whole-step capture: the seed lives in a device word that the captured step copies and advances, so every
+    replay draws new masks -- the same sequence of masks, hence of losses and weights, as the eager loop from the same seed."""
+    from gnn_cca_amd import MOTMPNet
+    from gnn_cca_amd.training import GraphedTrainStep
+    params, arch, sd, _, _, a = load_bwd("terrace32")
+    params = copy.deepcopy(params)
+    params["encoder_feats_dict"]["nodes"][arch]["dropout_p"] = 0.2
+    params["edge_model_feats_dict"]["dropout_p"] = 0.1
+    params["node_model_feats_dict"]["dropout_p"] = 0.3
+    params["classifier_feats_dict"]["dropout_p"] = 0.2
+    crit = torch.nn.BCEWithLogitsLoss()
+    loss_fn = lambda out, lab: sum(crit(t.view(-1), lab) for t in out["classified_edges"])
+    models = []
+    for _ in range(2):
+        m = MOTMPNet(copy.deepcopy(params), None, arch)
+        m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+        m = m.cuda().train()
+        m.set_dropout_seed(424242)
+        models.append(m)
+    m1, m2 = models
+    d = Data()
+    d.x, d.edge_index, d.edge_attr = (torch.from_numpy(a[k]).cuda() for k in ("x", "edge_index", "edge_attr"))
+    labels = torch.from_numpy(np.asarray(a["labels"])).cuda().float()
+    o1 = torch.optim.SGD(m1.parameters(), lr=0.05)
+    o2 = torch.optim.SGD(m2.parameters(), lr=0.05)
+    step = GraphedTrainStep(m2, o2, loss_fn, warmup=2)
+    losses1, losses2 = [], []
+    for it in range(7):
+        o1.zero_grad()
+        l1 = loss_fn(m1(d), labels)
+        l1.backward()
+        o1.step()
+        losses1.append(float(l1))
+        losses2.append(float(step(d, labels)))
+    assert len(step._graphs) == 1
+    assert np.allclose(losses1, losses2, rtol=2e-5, atol=1e-6), (losses1, losses2)
+    assert len({round(v, 6) for v in losses2[3:]}) > 1   # replays do not repeat one mask
