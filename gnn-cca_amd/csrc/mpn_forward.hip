@@ -350,6 +350,8 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
         const long long want = 4096 / (long long)N;  // waves per node that would fill the chip
         int wps = chunks >= 4 ? 4 : (chunks >= 2 ? 2 : 1);
         while (wps > 1 && wps > want) wps >>= 1;
+        static const int force_wps = std::getenv("GNNCCA_WPS") ? std::atoi(std::getenv("GNNCCA_WPS")) : 0;  // diagnostics
+        if (force_wps == 1 || force_wps == 2 || force_wps == 4) wps = std::min(force_wps, chunks >= 4 ? 4 : (chunks >= 2 ? 2 : 1));
         sp.wps = wps;
     }
     sp.hin = hin;

@@ -1,0 +1,15 @@
+import copy, json, sys, time, os
+sys.path.insert(0, os.getcwd())
+import numpy as np, torch, bench
+g, n = (int(v) for v in sys.argv[1].split("x"))
+params = bench.graph_net_params(L=4)
+dev = torch.device("cuda:0")
+model = bench.build_model(copy.deepcopy(params), n).to(dev)
+data = bench.make_data(n, g, 1, dev)
+with torch.no_grad():
+    for _ in range(3): model(data)
+    kinds = {}
+    for _ in range(10):
+        _, times = model.forward_profiled(data)
+        for i, (k, t) in enumerate(times): kinds.setdefault(f"{i}:{k}", []).append(t * 1e3)
+print(os.environ.get("GNNCCA_WPS"), sys.argv[1], {k: round(float(np.median(v)), 1) for k, v in kinds.items()})
