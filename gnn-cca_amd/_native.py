@@ -105,6 +105,12 @@ _SIGNATURES = {
     "gnncca_mpn_backward_train": (C.c_int, [C.POINTER(MpnDims), C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                             C.c_int64, C.c_int64, C.POINTER(Trace), C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p),
                                             C.c_void_p, C.c_size_t, C.c_uint32, C.POINTER(Dropout), C.c_void_p]),
+    "gnncca_train_tape_bytes": (C.c_size_t, [C.POINTER(MpnDims), C.c_int64, C.c_int64]),
+    "gnncca_train_forward": (C.c_int, [C.POINTER(MpnDims), C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_int64, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(Dropout), C.c_void_p]),
+    "gnncca_train_backward": (C.c_int, [C.POINTER(MpnDims), C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_int64, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_void_p),
+                                        C.POINTER(Dropout), C.c_void_p]),
     "gnncca_read_graph_flags": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.c_void_p]),
 }
 

@@ -28,6 +28,7 @@
 #include "postprocess.cuh"
 #include "backward.cuh"
 #include "pack_device.cuh"
+#include "train_generic.cuh"
 
 using namespace gnncca;
 
@@ -430,6 +431,28 @@ int gnncca_mpn_forward_train(const gnncca_mpn_dims* d, const void* packed_dev, c
                              float* logits_out, const gnncca_trace* trace, const gnncca_dropout* dropout, gnncca_stream_t stream) {
     return forward_impl(d, packed_dev, x, edge_index, edge_attr, n_nodes, n_edges, workspace, workspace_bytes, logits_out,
                         trace, stream, nullptr, 0u, dropout);
+}
+
+size_t gnncca_train_tape_bytes(const gnncca_mpn_dims* d, int64_t n_nodes, int64_t n_edges) {
+    TrPlan P;
+    if (!d || n_nodes < 0 || n_edges < 0 || !tr_plan(d, n_nodes, n_edges, &P)) return 0;
+    return P.total;
+}
+
+int gnncca_train_forward(const gnncca_mpn_dims* d, float* const* params_dev, int n_params, const float* x, const int64_t* edge_index,
+                         const float* edge_attr, int64_t n_nodes, int64_t n_edges, void* tape, size_t tape_bytes, float* logits_out,
+                         const gnncca_dropout* dropout, gnncca_stream_t stream) {
+    if (!x || (n_edges > 0 && (!edge_index || !edge_attr || !logits_out))) return GNNCCA_ERR_INVALID_ARG;
+    return train_forward_impl(d, params_dev, n_params, x, edge_index, edge_attr, n_nodes, n_edges, tape, tape_bytes, logits_out, dropout,
+                              static_cast<hipStream_t>(stream));
+}
+
+int gnncca_train_backward(const gnncca_mpn_dims* d, float* const* params_dev, int n_params, const float* x, const int64_t* edge_index,
+                          const float* edge_attr, int64_t n_nodes, int64_t n_edges, void* tape, size_t tape_bytes,
+                          const float* grad_logits, float* const* grads_dev, const gnncca_dropout* dropout, gnncca_stream_t stream) {
+    if (!x || (n_edges > 0 && (!edge_index || !edge_attr))) return GNNCCA_ERR_INVALID_ARG;
+    return train_backward_impl(d, params_dev, n_params, x, edge_index, edge_attr, n_nodes, n_edges, tape, tape_bytes, grad_logits,
+                               grads_dev, dropout, static_cast<hipStream_t>(stream));
 }
 
 int gnncca_mpn_forward_profiled(const gnncca_mpn_dims* d, const void* packed_dev, const float* x,

@@ -161,6 +161,55 @@ class _MPNTrainFunction(torch.autograd.Function):
         return (None, None, None, None, *[gr if p.requires_grad else None for gr, p in zip(grads, params)])
 
 
+class _LayerwiseTrainFunction(torch.autograd.Function):
+    """Autograd bridge to the layer-by-layer training engine (gnncca_train_forward / gnncca_train_backward, csrc/train_generic.cuh):
+    every legal GRAPH_NET_PARAMS in train mode -- BatchNorm with batch statistics in any MLP, Dropout, the generic family.  The tape
+    (what autograd would keep) is one device buffer owned by this call."""
+
+    @staticmethod
+    def forward(ctx, module, x, edge_index, edge_attr, *params):
+        lib, d = nat.lib(), module.native_dims()
+        dev = x.device
+        n, e = x.shape[0], edge_index.shape[1]
+        n_out = lib.gnncca_num_outputs(C.byref(d))
+        drop, seed = module._dropout_for_this_call(dev)
+        logits = torch.zeros((n_out, e, 1), dtype=torch.float32, device=dev)
+        tape = torch.empty(lib.gnncca_train_tape_bytes(C.byref(d), n, e) + 256, dtype=torch.uint8, device=dev)
+        pp = (C.c_void_p * len(params))(*[p.data_ptr() for p in params])
+        with torch.cuda.device(dev):
+            st = lib.gnncca_train_forward(C.byref(d), pp, len(params), x.data_ptr(), edge_index.data_ptr(), edge_attr.data_ptr(),
+                                          n, e, tape.data_ptr(), tape.numel(), logits.data_ptr(),
+                                          C.byref(drop) if drop is not None else None, _raw_stream(dev))
+        nat.check(st, "gnncca_train_forward")
+        module._count_batchnorm_calls(n_out if e > 0 else 0, e > 0)
+        ctx.module, ctx.tape, ctx.drop, ctx.drop_seed = module, tape, drop, seed
+        ctx.save_for_backward(x, edge_index, edge_attr, *params)
+        return logits
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x, edge_index, edge_attr = ctx.saved_tensors[:3]
+        params = ctx.saved_tensors[3:]
+        lib, d = nat.lib(), ctx.module.native_dims()
+        dev = x.device
+        n, e = x.shape[0], edge_index.shape[1]
+        g = grad_out.reshape(grad_out.shape[0], -1).float().contiguous()
+        offs, total = [], 0
+        for p in params:
+            offs.append(total)
+            total += (p.numel() + 3) // 4 * 4
+        flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        grads = [flat[o:o + p.numel()].view(p.shape) for o, p in zip(offs, params)]
+        pp = (C.c_void_p * len(params))(*[p.data_ptr() for p in params])
+        gp = (C.c_void_p * len(params))(*[t.data_ptr() for t in grads])
+        with torch.cuda.device(dev):
+            st = lib.gnncca_train_backward(C.byref(d), pp, len(params), x.data_ptr(), edge_index.data_ptr(), edge_attr.data_ptr(),
+                                           n, e, ctx.tape.data_ptr(), ctx.tape.numel(), g.data_ptr(), gp,
+                                           C.byref(ctx.drop) if ctx.drop is not None else None, _raw_stream(dev))
+        nat.check(st, "gnncca_train_backward")
+        return (None, None, None, None, *[gr if p.requires_grad else None for gr, p in zip(grads, params)])
+
+
 def _fill_mlp(dst, mlp):
     dst.n_layers = 0 if mlp is None else len(mlp.plan)
     if dst.n_layers > nat.MAX_LAYERS:
@@ -210,6 +259,9 @@ class MOTMPNet(nn.Module):
         # split-bf16 products of the first encoder layer on batches of >= 4096 nodes: 6 (default, fp32-level accuracy) or 3
         # (GNNCCA_OPT_ENC_SPLIT3: ~2^-17 relative on that layer, logits measured 1.5e-7 off; the GEMM runs 19-28 % faster)
         self.encoder_products = 6
+        # train mode: 'auto' = the fused kernels where they apply (the shipped shapes), else the layer-by-layer engine;
+        # 'layerwise' / 'fused' force one (set it before the first training forward, or call .train() again)
+        self.train_engine = 'auto'
 
     def _options(self):
         if self.edge_state_dtype not in ('fp32', 'bf16'):
@@ -493,13 +545,31 @@ class MOTMPNet(nn.Module):
         if self._trainable_checked:  # reset by .train() / _apply(); Dropout.p edited by hand afterwards is not re-read
             return
         lib, d = nat.lib(), self.native_dims()
-        if lib.gnncca_backward_supported(C.byref(d)) != nat.OK:
-            raise NotImplementedError(
-                "train-mode forward/backward on the HIP path covers the shipped config shapes (BatchNorm nowhere or only "
-                "inside the classifier, two-layer node encoder); this configuration is "
-                "outside it (SURVEY.md 8f row N3)")
+        # the shipped shapes (BatchNorm nowhere or only inside the classifier, two-layer node encoder) train on the fused kernels;
+        # everything else -- BatchNorm in the encoder / MPN MLPs, the generic family -- on the layer-by-layer engine
+        fused_ok = lib.gnncca_backward_supported(C.byref(d)) == nat.OK
+        want = getattr(self, 'train_engine', 'auto')
+        if want not in ('auto', 'fused', 'layerwise'):
+            raise ValueError("train_engine must be 'auto', 'fused' or 'layerwise'")
+        if want == 'fused' and not fused_ok:
+            raise NotImplementedError("the fused training kernels cover the shipped config shapes only; this configuration trains "
+                                      "on train_engine = 'layerwise' (SURVEY.md 8f row N3)")
+        self._train_path = 'fused' if (fused_ok and want != 'layerwise') else 'layerwise'
         self._dropout_ps()   # raises if the Dropout modules of one group disagree
         self._trainable_checked = True
+
+    def _count_batchnorm_calls(self, n_cls_calls, edges):
+        """num_batches_tracked of every BatchNorm1d after one train-mode forward (one increment per call of its MLP)."""
+        L = int(self.num_enc_steps)
+        calls = ((self.encoder.node_mlp, 1), (self.encoder.edge_mlp, 1 if edges else 0),
+                 (self.MPNet.edge_model.edge_mlp, L if edges else 0), (self.MPNet.node_model.node_mlp, L if edges else 0),
+                 (self.classifier.edge_mlp, n_cls_calls))
+        for mlp, k in calls:
+            if mlp is None or k == 0:
+                continue
+            for mod in mlp.fc_layers:
+                if isinstance(mod, nn.BatchNorm1d):
+                    mod.num_batches_tracked += k
 
     # -- train-mode Dropout (models/mlp.py:20-21) -------------------------------------------------------------------------
     def _dropout_ps(self):
@@ -543,7 +613,8 @@ class MOTMPNet(nn.Module):
             raise RuntimeError("gnn_cca_amd.MOTMPNet runs on MI355X only: move the module and `data` to the GPU "
                                "(there is no CPU fallback)")
         x, edge_index, edge_attr = self._check_inputs(data.x, data.edge_index, data.edge_attr)
-        logits = _MPNTrainFunction.apply(self, x.detach(), edge_index, edge_attr.detach(), *params)
+        fn = _MPNTrainFunction if self._train_path == 'fused' else _LayerwiseTrainFunction
+        logits = fn.apply(self, x.detach(), edge_index, edge_attr.detach(), *params)
         return {'classified_edges': list(logits.unbind(0))}
 
     def _forward_native(self, x, edge_index, edge_attr, trace=None, dropout=None):

@@ -300,6 +300,25 @@ GNNCCA_API int gnncca_mpn_backward_train(const gnncca_mpn_dims* dims, const floa
                                          size_t workspace_bytes, uint32_t options, const gnncca_dropout* dropout,
                                          gnncca_stream_t stream);
 
+/* Layer-by-layer training engine (SURVEY.md 8f row N3 remainder; train.py:454-494 through models/mpn.py:250-299 and
+ * models/mlp.py:4-28 op for op): EVERY legal GRAPH_NET_PARAMS in train mode -- BatchNorm1d with batch statistics in any MLP
+ * (running_mean / running_var updated in place with momentum 0.1, as torch.nn.BatchNorm1d; the caller bumps num_batches_tracked),
+ * Dropout behind any ReLU (masks from `dropout`, as above), any widths / depths, sum | mean | max, both reattach flags.
+ * `params_dev`: the gnncca_pack_weights order (per layer: weight, bias, [BatchNorm weight, bias, running_mean, running_var]).
+ * `tape` (gnncca_train_tape_bytes) receives what autograd would keep and is read back by gnncca_train_backward, which ADDS
+ * d loss / d parameter into `grads_dev` (same order; entries of buffers may be null; zero them first) given
+ * `grad_logits` [n_out][E].  The shipped shapes have the fused pair gnncca_mpn_forward_train / gnncca_mpn_backward_train;
+ * this engine is the one that covers everything else (one launch per op, correctness first). */
+GNNCCA_API size_t gnncca_train_tape_bytes(const gnncca_mpn_dims* dims, int64_t n_nodes, int64_t n_edges);
+GNNCCA_API int gnncca_train_forward(const gnncca_mpn_dims* dims, float* const* params_dev, int n_params, const float* x,
+                                    const int64_t* edge_index, const float* edge_attr, int64_t n_nodes, int64_t n_edges,
+                                    void* tape, size_t tape_bytes, float* logits_out, const gnncca_dropout* dropout,
+                                    gnncca_stream_t stream);
+GNNCCA_API int gnncca_train_backward(const gnncca_mpn_dims* dims, float* const* params_dev, int n_params, const float* x,
+                                     const int64_t* edge_index, const float* edge_attr, int64_t n_nodes, int64_t n_edges,
+                                     void* tape, size_t tape_bytes, const float* grad_logits, float* const* grads_dev,
+                                     const gnncca_dropout* dropout, gnncca_stream_t stream);
+
 /* Synchronises `stream` and returns the flag word of the last forward that used `workspace`. */
 GNNCCA_API int gnncca_read_graph_flags(const void* workspace, uint32_t* flags_out, gnncca_stream_t stream);
 

@@ -252,6 +252,15 @@ DROP_ENC_NODE1, DROP_ENC_NODE2, DROP_ENC_EDGE, DROP_EDGE_STEP, DROP_NODE_STEP, D
 _M64 = (1 << 64) - 1
 
 
+def drop_stream(base, li):
+    """Dropout stream of layer `li` of an MLP call whose first layer has stream `base` (csrc/train_generic.cuh: drop_stream)."""
+    if li == 0:
+        return base
+    if base == DROP_ENC_NODE1 and li == 1:
+        return DROP_ENC_NODE2
+    return base + 256 * li
+
+
 def dropout_scale(seed, stream, rows, cols, p):
     """[rows, cols] float32 array of 0 (dropped) or 1 / (1 - p) (kept) for the activation tensor `stream` (DROP_* + step):
     element idx = row * cols + col is kept iff the hash of (seed, stream, idx) maps to u >= p.  Same integer arithmetic as the
@@ -323,8 +332,8 @@ class TorchTrainOracle(TorchOracle):
             return x
         return x * self.torch.from_numpy(dropout_scale(self.dropout["seed"], stream, x.shape[0], x.shape[1], p))
 
-    def _mlp(self, prefix, x, streams=None, drop_p=0.0):
-        """`streams`: per layer, the dropout stream id of that layer's output (None: no dropout on this call)."""
+    def _mlp(self, prefix, x, base=None, drop_p=0.0):
+        """`base`: the dropout stream of this call's first layer (layer li draws from drop_stream(base, li)); None: no dropout."""
         torch = self.torch
         for li, (lin, _in, _out, bn, relu) in enumerate(self.lay[prefix]):
             p = f"{prefix}.fc_layers.{lin}."
@@ -335,8 +344,8 @@ class TorchTrainOracle(TorchOracle):
                                                    self.sd[q + "weight"], self.sd[q + "bias"], True, 0.1, BN_EPS)
             if relu:
                 x = torch.relu(x)
-                if streams is not None and li < len(streams) and streams[li] is not None:
-                    x = self._drop(x, streams[li], drop_p)   # nn.Dropout sits behind the ReLU (only layers wider than 1 have either)
+                if base is not None:
+                    x = self._drop(x, drop_stream(base, li), drop_p)   # nn.Dropout sits behind the ReLU (only layers wider than 1 have either)
         return x
 
     def forward(self, x, edge_index, edge_attr):
@@ -350,8 +359,8 @@ class TorchTrainOracle(TorchOracle):
         row, col = edge_index[0], edge_index[1]
         n = x.shape[0]
         if lay["encoder.edge_mlp"] is not None:
-            e = self._mlp("encoder.edge_mlp", e, [DROP_ENC_EDGE], p_enc)
-        h = self._mlp("encoder.node_mlp", x, [DROP_ENC_NODE1, DROP_ENC_NODE2], p_enc) if lay["encoder.node_mlp"] is not None else x
+            e = self._mlp("encoder.edge_mlp", e, DROP_ENC_EDGE, p_enc)
+        h = self._mlp("encoder.node_mlp", x, DROP_ENC_NODE1, p_enc) if lay["encoder.node_mlp"] is not None else x
         e0, h0 = e, h
         L, first = lay["L"], lay["L"] - lay["n_cls"] + 1
         logits = []
@@ -360,13 +369,13 @@ class TorchTrainOracle(TorchOracle):
                 e = torch.cat((e0, e), dim=1)
             if lay["reattach_nodes"]:
                 h = torch.cat((h0, h), dim=1)
-            e = self._mlp("MPNet.edge_model.edge_mlp", torch.cat([h[row], h[col], e], dim=1), [DROP_EDGE_STEP + step], p_edge)
-            flow = self._mlp("MPNet.node_model.node_mlp", torch.cat([h[row], e], dim=1), [DROP_NODE_STEP + step], p_node)
+            e = self._mlp("MPNet.edge_model.edge_mlp", torch.cat([h[row], h[col], e], dim=1), DROP_EDGE_STEP + step, p_edge)
+            flow = self._mlp("MPNet.node_model.node_mlp", torch.cat([h[row], e], dim=1), DROP_NODE_STEP + step, p_node)
             h = self._aggregate(flow, row, n)
             if step >= first:
-                logits.append(self._mlp("classifier.edge_mlp", e, [DROP_CLS + len(logits)], p_cls))
+                logits.append(self._mlp("classifier.edge_mlp", e, DROP_CLS + len(logits), p_cls))
         if L == 0:
-            logits.append(self._mlp("classifier.edge_mlp", e, [DROP_CLS], p_cls))
+            logits.append(self._mlp("classifier.edge_mlp", e, DROP_CLS, p_cls))
         return logits
 
     def loss_and_grads(self, x, edge_index, edge_attr, labels):

@@ -14,6 +14,7 @@ CASES = sorted(os.path.basename(p)[4:-4] for p in glob.glob(os.path.join(GOLDEN_
 
 
 DROP_CASES = sorted(os.path.basename(p)[5:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "drop_*.npz")))
+LW_CASES = sorted(os.path.basename(p)[3:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "lw_*.npz")))
 
 
 def load_bwd(name, prefix="bwd_"):
@@ -58,3 +59,24 @@ def test_autograd_oracle_with_dropout_matches_reference(name):
     for k in grads:
         scale = max(1.0, float(np.abs(grads[k]).max()))
         assert np.abs(g[k].numpy() - grads[k]).max() <= 2e-6 * scale, k
+
+
+@pytest.mark.parametrize("name", LW_CASES)
+def test_autograd_oracle_matches_reference_bn_dropout_generic(name):
+    """tests/golden/lw_*.npz (make_golden_layerwise.py): the reference's module in train mode with BatchNorm in the encoder / MPN
+    MLPs, injected Dropout masks in multi-layer MLPs (stream of layer li = drop_stream(base, li)) and the generic family's widths.
+    Pins the oracle the layer-by-layer HIP engine is checked against: logits, loss, every gradient, the BatchNorm buffers."""
+    params, arch, sd, grads, after, a = load_bwd(name, "lw_")
+    ps = [float(v) for v in a["dropout_p"]]
+    orc = TorchTrainOracle(params, arch, sd, dropout=dict(p_enc=ps[0], p_edge=ps[1], p_node=ps[2], p_cls=ps[3],
+                                                          seed=int(a["dropout_seed"])))
+    loss, logits, g = orc.loss_and_grads(a["x"], a["edge_index"], a["edge_attr"], a["labels"])
+    assert abs(loss - float(a["loss"])) <= 2e-6
+    for i, t in enumerate(logits):
+        assert np.abs(t.numpy() - a[f"logits_{i}"]).max() <= 2e-6
+    for k in grads:
+        scale = max(1.0, float(np.abs(grads[k]).max()))
+        assert np.abs(g[k].numpy() - grads[k]).max() <= 2e-6 * scale, k
+    for k, v in after.items():
+        if "running_" in k:
+            assert np.abs(orc.buffers[k].numpy() - v).max() <= 1e-6, k

@@ -79,7 +79,11 @@ def test_no_cpu_fallback_and_unsupported_train_mode_refused():
     m.train()
     with pytest.raises(RuntimeError):          # train mode of a shipped shape: supported, but GPU only
         m(D())
-    m2, _, _, _, _ = _model("generic_dims")    # the generic family has no HIP backward: loud refusal
+    m2, _, _, _, _ = _model("generic_dims")    # the generic family trains on the layer-by-layer engine: GPU only as well
+    m2.train()
+    with pytest.raises(RuntimeError):
+        m2(D())
+    m2.train_engine = "fused"                  # ... and cannot be forced onto the fused kernels of the shipped shapes
     m2.train()
     with pytest.raises(NotImplementedError):
         m2(D())

@@ -1,0 +1,193 @@
+"""Row N3 remainder on the GPU: the layer-by-layer training engine (gnncca_train_forward / gnncca_train_backward,
+csrc/train_generic.cuh) -- train-mode BatchNorm in the encoder / MPN MLPs, Dropout, the generic family -- against the REFERENCE's
+own module under torch autograd (tests/golden/lw_*.npz, make_golden_layerwise.py), against the goldens of the fused training path
+(bwd_*.npz, drop_*.npz) with the engine forced, against the fused path itself, and against the autograd oracle on a larger
+irregular graph over three SGD steps."""
+import copy
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN_DIR
+from oracle.mpn_oracle import TorchTrainOracle
+from test_backward_oracle import DROP_CASES, LW_CASES, load_bwd
+
+pytestmark = pytest.mark.gpu
+BWD_CASES = sorted(os.path.basename(p)[4:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "bwd_*.npz")))
+
+
+class Data:
+    def __init__(self, x, edge_index, edge_attr):
+        self.x, self.edge_index, self.edge_attr = x, edge_index, edge_attr
+
+
+def build(params, arch, sd, engine="auto"):
+    from gnn_cca_amd import MOTMPNet
+    m = MOTMPNet(copy.deepcopy(params), None, arch)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    m.train_engine = engine
+    return m.cuda().train()
+
+
+def loss_of(out, labels):
+    crit = torch.nn.BCEWithLogitsLoss(reduction="mean")
+    return sum(crit(t.view(-1), labels) for t in out["classified_edges"])  # train.py:80-97
+
+
+def data_of(a):
+    return Data(torch.from_numpy(a["x"]).cuda(), torch.from_numpy(a["edge_index"]).cuda(), torch.from_numpy(a["edge_attr"]).cuda())
+
+
+def check_against(m, out, loss, a, grads, after, tol_logit=2e-5, tol_grad=5e-5):
+    assert abs(float(loss.detach()) - float(a["loss"])) <= 2e-5
+    assert len(out["classified_edges"]) == int(a["n_logits"])
+    for i, t in enumerate(out["classified_edges"]):
+        assert t.shape == a[f"logits_{i}"].shape
+        assert np.abs(t.detach().cpu().numpy() - a[f"logits_{i}"]).max() <= tol_logit, i
+    got = dict(m.named_parameters())
+    assert sorted(got) == sorted(grads)
+    for k, ref in grads.items():
+        g = got[k].grad
+        assert g is not None, k
+        scale = max(1.0, float(np.abs(ref).max()))
+        err = float(np.abs(g.cpu().numpy() - ref).max())
+        # a Linear bias directly in front of a train-mode BatchNorm has an analytically zero gradient: rounding residue on both sides
+        assert err <= tol_grad * scale, (k, err)
+    state = m.state_dict()
+    for k, v in after.items():
+        if "running_" in k:
+            assert np.abs(state[k].cpu().numpy().astype(np.float64) - v).max() <= 2e-6 * max(1.0, float(np.abs(v).max())), k
+        if "num_batches_tracked" in k:
+            assert int(state[k]) == int(v), k
+
+
+@pytest.mark.parametrize("name", LW_CASES)
+def test_layerwise_engine_matches_reference_golden(name):
+    """BatchNorm in any MLP (batch statistics, running buffers, num_batches_tracked), Dropout in multi-layer MLPs, generic widths,
+    max / mean / sum, both reattach flags, L = 0: logits, loss, every parameter gradient and every buffer of the reference."""
+    params, arch, sd, grads, after, a = load_bwd(name, "lw_")
+    m = build(params, arch, sd)
+    m.set_dropout_seed(int(a["dropout_seed"]))
+    d = data_of(a)
+    out = m(d)
+    assert m._train_path == "layerwise"
+    loss = loss_of(out, torch.from_numpy(a["labels"]).cuda())
+    loss.backward()
+    check_against(m, out, loss, a, grads, after)
+
+
+@pytest.mark.parametrize("name", BWD_CASES)
+def test_layerwise_engine_on_the_fused_paths_goldens(name):
+    """The shipped shapes (the fused path's territory) through the layer-by-layer engine: same reference gradients."""
+    params, arch, sd, grads, after, a = load_bwd(name)
+    m = build(params, arch, sd, engine="layerwise")
+    out = m(data_of(a))
+    assert m._train_path == "layerwise"
+    loss = loss_of(out, torch.from_numpy(a["labels"]).cuda())
+    loss.backward()
+    a = dict(a)
+    check_against(m, out, loss, a, grads, after)
+
+
+@pytest.mark.parametrize("name", DROP_CASES)
+def test_layerwise_engine_on_the_dropout_goldens(name):
+    params, arch, sd, grads, after, a = load_bwd(name, "drop_")
+    m = build(params, arch, sd, engine="layerwise")
+    m.set_dropout_seed(int(a["dropout_seed"]))
+    out = m(data_of(a))
+    loss = loss_of(out, torch.from_numpy(a["labels"]).cuda())
+    loss.backward()
+    check_against(m, out, loss, a, grads, after)
+
+
+def test_fused_and_layerwise_engines_agree_and_auto_picks_fused():
+    params, arch, sd, _, _, a = load_bwd("terrace32")
+    res = {}
+    for engine in ("auto", "layerwise"):
+        m = build(params, arch, sd, engine=engine)
+        out = m(data_of(a))
+        loss = loss_of(out, torch.from_numpy(a["labels"]).cuda())
+        loss.backward()
+        res[engine] = (m._train_path, float(loss.detach()), {k: p.grad.cpu().numpy() for k, p in m.named_parameters()})
+    assert res["auto"][0] == "fused" and res["layerwise"][0] == "layerwise"
+    assert abs(res["auto"][1] - res["layerwise"][1]) <= 5e-6
+    for k, g in res["auto"][2].items():
+        scale = max(1.0, float(np.abs(g).max()))
+        assert np.abs(g - res["layerwise"][2][k]).max() <= 5e-5 * scale, k
+    # a configuration outside the fused kernels cannot be forced onto them
+    params2, arch2, sd2, _, _, _ = load_bwd("generic_dims", "lw_")
+    m = build(params2, arch2, sd2, engine="fused")
+    z = np.load(os.path.join(GOLDEN_DIR, "lw_generic_dims.npz"))
+    with pytest.raises(NotImplementedError):
+        m(Data(torch.from_numpy(z["x"]).cuda(), torch.from_numpy(z["edge_index"]).cuda(), torch.from_numpy(z["edge_attr"]).cuda()))
+
+
+def test_layerwise_engine_bigger_irregular_graph_vs_oracle_and_sgd_steps():
+    """600 nodes / 9 000 random edges (unsorted, duplicates, isolated nodes), BatchNorm + Dropout everywhere, default widths with a
+    2048-d input: gradients against the autograd oracle, then three SGD steps tracking the oracle's parameters."""
+    from gnn_cca_amd import MOTMPNet
+    import bench
+    params = bench.graph_net_params(L=3, n_cls=2, agg="mean", cls_bn=True)
+    params["encoder_feats_dict"]["nodes"]["resnet50"].update(use_batchnorm=True, dropout_p=0.1)
+    params["edge_model_feats_dict"].update(use_batchnorm=True, dropout_p=0.2)
+    params["node_model_feats_dict"].update(use_batchnorm=True, dropout_p=0.1)
+    params["classifier_feats_dict"]["dropout_p"] = 0.15
+    torch.manual_seed(5)
+    m = MOTMPNet(copy.deepcopy(params), None, "resnet50")
+    sd = {k: v.detach().clone().numpy() for k, v in m.state_dict().items()}
+    rng = np.random.default_rng(3)
+    n, e = 600, 9000
+    x = rng.standard_normal((n, 2048)).astype(np.float32) * 0.05
+    ei = np.stack([rng.integers(0, 560, size=e), rng.integers(0, n, size=e)]).astype(np.int64)
+    ea = rng.random((e, 4)).astype(np.float32)
+    labels = (rng.random(e) < 0.3).astype(np.float32)
+    seed = 424242
+    m = m.cuda().train()
+    m.set_dropout_seed(seed)
+    ps = m._dropout_ps()
+    lr = 0.05
+    opt = torch.optim.SGD(m.parameters(), lr=lr)
+    d = Data(torch.from_numpy(x).cuda(), torch.from_numpy(ei).cuda(), torch.from_numpy(ea).cuda())
+    cur = sd
+    for it in range(3):
+        orc = TorchTrainOracle(params, "resnet50", cur, dropout=dict(p_enc=ps[0], p_edge=ps[1], p_node=ps[2], p_cls=ps[3], seed=seed + it))
+        ref_loss, ref_logits, ref = orc.loss_and_grads(x, ei, ea, labels)
+        opt.zero_grad()
+        out = m(d)
+        assert m._train_path == "layerwise"
+        loss = loss_of(out, torch.from_numpy(labels).cuda())
+        loss.backward()
+        assert abs(float(loss.detach()) - ref_loss) <= 5e-5, it
+        for t, r in zip(out["classified_edges"], ref_logits):
+            assert np.abs(t.detach().cpu().numpy() - r.numpy()).max() <= 1e-4, it
+        for k, prm in m.named_parameters():
+            r = ref[k].numpy()
+            scale = max(1.0, float(np.abs(r).max()))
+            assert float(np.abs(prm.grad.cpu().numpy() - r).max()) <= 2e-4 * scale, (it, k)
+        opt.step()
+        # the oracle's next iterate: same SGD step on its own gradients, BatchNorm buffers as it updated them
+        nxt = {}
+        for k, v in cur.items():
+            if k in ref:
+                nxt[k] = np.asarray(v) - lr * ref[k].numpy()
+            elif "running_" in k:
+                nxt[k] = orc.buffers[k].numpy()
+            else:
+                nxt[k] = np.asarray(v)
+        state = m.state_dict()
+        for k, v in nxt.items():
+            if "num_batches_tracked" in k:
+                assert int(state[k]) == it + 1 if "encoder" in k else True
+                continue
+            assert np.abs(state[k].cpu().numpy() - v).max() <= 2e-5 * max(1.0, float(np.abs(v).max())), (it, k)
+        # continue from the oracle's iterate exactly (BatchNorm + ReLU + Dropout amplify rounding-level differences of the
+        # parameters into 1e-3 logit differences within one step: each iteration checks one step from a common point)
+        with torch.no_grad():
+            for k, t in m.state_dict().items():
+                if "num_batches_tracked" not in k:
+                    t.copy_(torch.from_numpy(np.asarray(nxt[k])))
+        m.train()
+        cur = nxt
