@@ -105,6 +105,14 @@ _SIGNATURES = {
     "gnncca_mpn_backward_train": (C.c_int, [C.POINTER(MpnDims), C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                             C.c_int64, C.c_int64, C.POINTER(Trace), C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p),
                                             C.c_void_p, C.c_size_t, C.c_uint32, C.POINTER(Dropout), C.c_void_p]),
+    "gnncca_mlp_eval_workspace_bytes": (C.c_size_t, [C.POINTER(Mlp), C.c_int64]),
+    "gnncca_mlp_eval": (C.c_int, [C.POINTER(Mlp), C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                  C.c_size_t, C.c_void_p]),
+    "gnncca_gather_cat": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_int64,
+                                    C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
+    "gnncca_aggregate_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64]),
+    "gnncca_aggregate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t,
+                                   C.c_void_p]),
     "gnncca_train_tape_bytes": (C.c_size_t, [C.POINTER(MpnDims), C.c_int64, C.c_int64]),
     "gnncca_train_forward": (C.c_int, [C.POINTER(MpnDims), C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_int64, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(Dropout), C.c_void_p]),

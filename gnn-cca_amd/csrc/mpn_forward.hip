@@ -433,6 +433,36 @@ int gnncca_mpn_forward_train(const gnncca_mpn_dims* d, const void* packed_dev, c
                         trace, stream, nullptr, 0u, dropout);
 }
 
+size_t gnncca_mlp_eval_workspace_bytes(const gnncca_mlp* mlp, int64_t rows) {
+    if (!mlp_shape_ok(mlp) || rows < 0) return 0;
+    return mlp_eval_ws(mlp, rows, nullptr, nullptr, nullptr, nullptr);
+}
+
+int gnncca_mlp_eval(const gnncca_mlp* mlp, const float* const* params_dev, int n_params, const float* in, int64_t rows, float* out,
+                    void* workspace, size_t workspace_bytes, gnncca_stream_t stream) {
+    return mlp_eval_impl(mlp, params_dev, n_params, in, rows, out, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+}
+
+int gnncca_gather_cat(const float* a, const int64_t* ia, int wa, int64_t rows_a, const float* b, const int64_t* ib, int wb, int64_t rows_b,
+                      const float* c, const int64_t* ic, int wc, int64_t rows_c, int64_t rows, float* out, gnncca_stream_t stream) {
+    if (rows < 0 || wa < 0 || wb < 0 || wc < 0 || wa + wb + wc <= 0 || !out) return GNNCCA_ERR_INVALID_ARG;
+    if ((wa > 0 && (!a || rows_a <= 0)) || (wb > 0 && (!b || rows_b <= 0)) || (wc > 0 && (!c || rows_c <= 0))) return rows == 0 ? GNNCCA_OK : GNNCCA_ERR_INVALID_ARG;
+    if (rows == 0) return GNNCCA_OK;
+    hipLaunchKernelGGL(tr_cat64_kernel, grid1((size_t)rows * (wa + wb + wc), 256), dim3(256), 0, static_cast<hipStream_t>(stream), a,
+                       reinterpret_cast<const long long*>(ia), wa, (long long)rows_a, b, reinterpret_cast<const long long*>(ib), wb,
+                       (long long)rows_b, c, reinterpret_cast<const long long*>(ic), wc, (long long)rows_c, out, (long long)rows);
+    HIP_TRY(hipGetLastError());
+    return GNNCCA_OK;
+}
+
+size_t gnncca_aggregate_workspace_bytes(int64_t n_nodes, int64_t n_edges) { return agg_ws(n_nodes, n_edges).total; }
+
+int gnncca_aggregate(const float* messages, const int64_t* edge_index, int64_t n_nodes, int64_t n_edges, int width, int agg, float* out,
+                     void* workspace, size_t workspace_bytes, gnncca_stream_t stream) {
+    return aggregate_impl(messages, edge_index, n_nodes, n_edges, width, agg, out, workspace, workspace_bytes,
+                          static_cast<hipStream_t>(stream));
+}
+
 size_t gnncca_train_tape_bytes(const gnncca_mpn_dims* d, int64_t n_nodes, int64_t n_edges) {
     TrPlan P;
     if (!d || n_nodes < 0 || n_edges < 0 || !tr_plan(d, n_nodes, n_edges, &P)) return 0;

@@ -113,9 +113,10 @@ __global__ void tr_bn_var_kernel(const double* __restrict__ sums, long long M, i
 }
 
 // a = [ReLU](z * alpha + beta'), alpha = invstd * gamma, beta' = beta - mean * alpha (the form of torch's CPU kernel)
-__global__ __launch_bounds__(256) void tr_bn_apply_kernel(const float* __restrict__ z, const float* __restrict__ stat,
+// (z and a may be the same buffer: the stand-alone MLP evaluation normalises in place)
+__global__ __launch_bounds__(256) void tr_bn_apply_kernel(const float* z, const float* __restrict__ stat,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                          float* __restrict__ a, long long M, int O, int relu) {
+                                                          float* a, long long M, int O, int relu) {
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
     if (t >= M * O) return;
     const int c = (int)(t % O);
@@ -688,6 +689,151 @@ static int train_backward_impl(const gnncca_mpn_dims* d, float* const* params, i
         s = tr_mlp_backward(c, P.enc_node, x, g, gN0, gN1, false, nullptr);
         if (s != GNNCCA_OK) return s;
     }
+    return GNNCCA_OK;
+}
+
+
+// ============================================================================================================
+// Stand-alone calls of the sub-modules (models/mlp.py:26-28, models/mpn.py:32-54,59-101,128-142 called on their own, which the
+// reference allows): eval semantics (BatchNorm from the running statistics, Dropout = identity), the same one-launch-per-op
+// kernels as the engine above.  MOTMPNet.forward never comes through here; gnn-cca_amd/mpn.py: _standalone_*.
+// ============================================================================================================
+__global__ void tr_bn_eval_stat_kernel(const float* __restrict__ rm, const float* __restrict__ rv, float* __restrict__ stat, int O) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c < O) {
+        stat[c] = rm[c];
+        stat[O + c] = (float)(1.0 / sqrt((double)rv[c] + (double)kBnEps));
+    }
+}
+
+// out[r][:] = cat(a[ia[r]], b[ib[r]], c[ic[r]]) with int64 row ids (null: the row itself); dense inputs (ld = width)
+__global__ __launch_bounds__(256) void tr_cat64_kernel(const float* __restrict__ a, const long long* __restrict__ ia, int wa, long long na,
+                                                       const float* __restrict__ b, const long long* __restrict__ ib, int wb, long long nb,
+                                                       const float* __restrict__ cc, const long long* __restrict__ ic, int wc, long long nc,
+                                                       float* __restrict__ out, long long M) {
+    const int W = wa + wb + wc;
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= M * W) return;
+    const long long r = t / W;
+    int col = (int)(t - r * W);
+    const float* src = a;
+    const long long* idx = ia;
+    int w = wa;
+    long long rows = na;
+    if (col >= wa) {
+        col -= wa, src = b, idx = ib, w = wb, rows = nb;
+        if (col >= wb) col -= wb, src = cc, idx = ic, w = wc, rows = nc;
+    }
+    long long rr = idx ? idx[r] : r;
+    rr = rr < 0 ? 0 : (rr >= rows ? rows - 1 : rr);   // out-of-range ids: stay in bounds (the reference raises an IndexError)
+    out[t] = src[(size_t)rr * w + col];
+}
+
+static size_t mlp_eval_ws(const gnncca_mlp* m, int64_t rows, size_t* wt_off, size_t* bp_off, size_t* stat_off, size_t* buf_off) {
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = (off + bytes + 255) / 256 * 256; return o; };
+    int maxo = 1;
+    for (int l = 0; l < m->n_layers; ++l) {
+        const int OP = (m->layers[l].out_dim + 7) / 8 * 8;
+        const size_t w = take((size_t)m->layers[l].in_dim * OP * 4), b = take((size_t)OP * 4), st = take(2 * (size_t)m->layers[l].out_dim * 4);
+        if (wt_off) wt_off[l] = w, bp_off[l] = b, stat_off[l] = st;
+        maxo = std::max(maxo, (int)m->layers[l].out_dim);
+    }
+    for (int i = 0; i < 2; ++i) {
+        const size_t o = take((size_t)std::max<int64_t>(rows, 0) * maxo * 4);
+        if (buf_off) buf_off[i] = o;
+    }
+    return off;
+}
+
+static bool mlp_shape_ok(const gnncca_mlp* m) {
+    if (!m || m->n_layers < 0 || m->n_layers > GNNCCA_MAX_LAYERS) return false;
+    for (int l = 0; l < m->n_layers; ++l) {
+        if (m->layers[l].in_dim <= 0 || m->layers[l].out_dim <= 0) return false;
+        if (l > 0 && m->layers[l].in_dim != m->layers[l - 1].out_dim) return false;
+    }
+    return true;
+}
+
+static int mlp_eval_impl(const gnncca_mlp* m, const float* const* params, int n_params, const float* in, int64_t rows, float* out,
+                         void* ws, size_t ws_bytes, hipStream_t st) {
+    if (!mlp_shape_ok(m) || !params || !in || !out || rows < 0 || rows > 0x7fffffffLL) return GNNCCA_ERR_INVALID_ARG;
+    if (n_params != mlp_param_count(*m)) return GNNCCA_ERR_INVALID_ARG;
+    size_t wt[GNNCCA_MAX_LAYERS], bp[GNNCCA_MAX_LAYERS], stat[GNNCCA_MAX_LAYERS], buf[2];
+    if (ws_bytes < mlp_eval_ws(m, rows, wt, bp, stat, buf) || (!ws && m->n_layers > 0)) return GNNCCA_ERR_WORKSPACE;
+    char* base = static_cast<char*>(ws);
+    const long long M = rows;
+    if (m->n_layers == 0 || M == 0) return GNNCCA_OK;
+    const GenSeg none = {nullptr, nullptr, 0, 0};
+    const float* cur = in;
+    int pi = 0;
+    for (int l = 0; l < m->n_layers; ++l) {
+        const gnncca_layer& L = m->layers[l];
+        const int O = L.out_dim, K = L.in_dim, OP = (O + 7) / 8 * 8;
+        float* Wt = reinterpret_cast<float*>(base + wt[l]);
+        float* bpad = reinterpret_cast<float*>(base + bp[l]);
+        hipLaunchKernelGGL(tr_transpose_pad_kernel, grid1((size_t)K * OP, 256), dim3(256), 0, st, params[pi], params[pi + 1], Wt, bpad, O, K, OP);
+        const bool last = l == m->n_layers - 1;
+        float* dst = last ? out : reinterpret_cast<float*>(base + buf[l & 1]);
+        for (int o0 = 0; o0 < O; o0 += 2048) {
+            const int og = std::min(2048, O - o0);
+            const int rows_per_block = 256 / ((og + 7) / 8);
+            hipLaunchKernelGGL(gen_dense_kernel, dim3((unsigned)((M + rows_per_block - 1) / rows_per_block)), dim3(256), 0, st,
+                               GenSeg{cur, nullptr, K, K}, none, none, (const float*)Wt + o0, (const float*)bpad + o0, dst + o0, M, K, og, OP, O,
+                               (L.has_bn ? 0 : L.relu));
+        }
+        if (L.has_bn) {
+            float* sp = reinterpret_cast<float*>(base + stat[l]);
+            hipLaunchKernelGGL(tr_bn_eval_stat_kernel, dim3((O + 255) / 256), dim3(256), 0, st, params[pi + 4], params[pi + 5], sp, O);
+            hipLaunchKernelGGL(tr_bn_apply_kernel, grid1((size_t)M * O, 256), dim3(256), 0, st, (const float*)dst, (const float*)sp,
+                               params[pi + 2], params[pi + 3], dst, M, O, (int)L.relu);
+        }
+        HIP_TRY(hipGetLastError());
+        cur = dst;
+        pi += 2 + (L.has_bn ? 4 : 0);
+    }
+    return GNNCCA_OK;
+}
+
+struct AggWs { size_t flags, blockflags, seg_ptr, col32, perm, cursor, total; };
+static AggWs agg_ws(int64_t n, int64_t e) {
+    AggWs w;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = (off + bytes + 255) / 256 * 256; return o; };
+    const size_t N = (size_t)std::max<int64_t>(n, 0), E = (size_t)std::max<int64_t>(e, 0);
+    w.flags = take(256), w.blockflags = take((E / 256 + 2) * 4), w.seg_ptr = take((N + 1) * 4), w.col32 = take(E * 4);
+    w.perm = take(E * 4), w.cursor = take((N + 1) * 4), w.total = off;
+    return w;
+}
+
+static int aggregate_impl(const float* msg, const int64_t* edge_index, int64_t n_nodes, int64_t n_edges, int H, int agg, float* out,
+                          void* ws, size_t ws_bytes, hipStream_t st) {
+    if (!out || n_nodes < 0 || n_edges < 0 || n_nodes > 0x7fffffffLL || n_edges > 0x7fffffffLL || H <= 0) return GNNCCA_ERR_INVALID_ARG;
+    if (agg != GNNCCA_AGG_SUM && agg != GNNCCA_AGG_MEAN && agg != GNNCCA_AGG_MAX) return GNNCCA_ERR_INVALID_ARG;
+    if (n_edges > 0 && (!msg || !edge_index)) return GNNCCA_ERR_INVALID_ARG;
+    const AggWs w = agg_ws(n_nodes, n_edges);
+    if (!ws || ws_bytes < w.total) return GNNCCA_ERR_WORKSPACE;
+    if (n_nodes == 0) return GNNCCA_OK;
+    char* base = static_cast<char*>(ws);
+    const int N = (int)n_nodes, E = (int)n_edges;
+    const long long* ei = reinterpret_cast<const long long*>(edge_index);
+    unsigned* flags = reinterpret_cast<unsigned*>(base + w.flags);
+    unsigned* blockflags = reinterpret_cast<unsigned*>(base + w.blockflags);
+    int* seg_ptr = reinterpret_cast<int*>(base + w.seg_ptr);
+    int* col32 = reinterpret_cast<int*>(base + w.col32);
+    int* perm = reinterpret_cast<int*>(base + w.perm);
+    int* cursor = reinterpret_cast<int*>(base + w.cursor);
+    if (E > 0) {
+        EncPlanParams ep;
+        std::memset(&ep, 0, sizeof(ep));
+        ep.ei = ei, ep.seg_ptr = seg_ptr, ep.col32 = col32, ep.blockflags = blockflags, ep.E = E, ep.N = N;
+        hipLaunchKernelGGL(enc_gemm_plan_kernel, dim3(plan_num_blocks(E)), dim3(256), 0, st, ep);
+    }
+    hipLaunchKernelGGL(gen_plan_finish_kernel, dim3(1), dim3(256), 0, st, ei, E, N, seg_ptr, col32, perm, cursor, flags,
+                       (const unsigned*)blockflags);
+    hipLaunchKernelGGL(gen_aggregate_kernel, dim3((unsigned)N), dim3(256), 0, st, msg, (const int*)seg_ptr, (const int*)perm,
+                       (const unsigned*)flags, out, N, H, agg);
+    HIP_TRY(hipGetLastError());
     return GNNCCA_OK;
 }
 

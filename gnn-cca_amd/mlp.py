@@ -51,5 +51,7 @@ class MLP(nn.Module):
         return out
 
     def forward(self, input):
-        raise RuntimeError("gnn_cca_amd.MLP holds parameters only; the arithmetic runs inside MOTMPNet.forward "
-                           "(HIP kernels, libgnncca_mpn.so)")
+        """models/mlp.py:26-28 called on its own (MOTMPNet.forward never comes through here: its arithmetic is fused):
+        gnncca_mlp_eval, eval semantics, GPU tensors only."""
+        from . import mpn
+        return mpn.standalone_mlp(self, input)

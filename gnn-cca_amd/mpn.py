@@ -18,25 +18,85 @@ from . import _native as nat
 from .mlp import MLP
 
 
+# ---- stand-alone calls of the sub-modules (the reference allows them; MOTMPNet.forward itself runs fused) ---------------------------
+def _standalone_check(mod, what, *tensors):
+    if mod.training:
+        raise RuntimeError(f"{what} called on its own runs in eval mode only (train through MOTMPNet: its autograd bridge covers "
+                           "the whole forward); call .eval() first")
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("gnn_cca_amd runs on MI355X only: move the module and its inputs to the GPU (there is no CPU fallback)")
+    return next(t for t in tensors if t is not None).device
+
+
+def _f32(t, what):
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"{what} must be float32, got {t.dtype}")   # the reference's fp32 Linear layers raise as well
+    return t.detach().contiguous()
+
+
+def standalone_mlp(mlp, x):
+    """MLP.forward(input) on its own (models/mlp.py:26-28): gnncca_mlp_eval."""
+    dev = _standalone_check(mlp, "MLP", x)
+    x = _f32(x, "input")
+    if x.dim() != 2 or (mlp.plan and x.shape[1] != mlp.plan[0][0]):
+        raise RuntimeError(f"mat1 and mat2 shapes cannot be multiplied ({tuple(x.shape)} into Linear({mlp.plan[0][0] if mlp.plan else '?'}, ...))")
+    if not mlp.plan:
+        return x
+    lib = nat.lib()
+    desc = nat.Mlp()
+    _fill_mlp(desc, mlp)
+    params = mlp.native_params()
+    if any(p.device != dev for p in params):
+        raise RuntimeError("module and input are on different devices")
+    rows = x.shape[0]
+    out = torch.empty((rows, mlp.plan[-1][1]), dtype=torch.float32, device=dev)
+    ws = torch.empty(lib.gnncca_mlp_eval_workspace_bytes(C.byref(desc), rows) + 256, dtype=torch.uint8, device=dev)
+    pp = (C.c_void_p * len(params))(*[p.data_ptr() for p in params])
+    with torch.cuda.device(dev):
+        st = lib.gnncca_mlp_eval(C.byref(desc), pp, len(params), x.data_ptr(), rows, out.data_ptr(), ws.data_ptr(), ws.numel(),
+                                 _raw_stream(dev))
+    nat.check(st, "gnncca_mlp_eval")
+    return out
+
+
+def _gather_cat(parts, rows, dev):
+    """cat([t[idx] or t for (t, idx) in parts], dim=1) by gnncca_gather_cat (no torch kernel); idx: int64 [rows] or None."""
+    parts = [(t, i) for t, i in parts if t is not None]
+    assert 1 <= len(parts) <= 3
+    for t, i in parts:
+        if i is not None and i.dtype != torch.int64:
+            raise RuntimeError("tensors used as indices must be long")   # the reference's x[row] raises the same way
+    parts += [(None, None)] * (3 - len(parts))
+    width = sum(t.shape[1] for t, _ in parts if t is not None)
+    out = torch.empty((rows, width), dtype=torch.float32, device=dev)
+    args = []
+    for t, i in parts:
+        args += [t.data_ptr() if t is not None else None, i.data_ptr() if i is not None else None,
+                 t.shape[1] if t is not None else 0, t.shape[0] if t is not None else 0]
+    with torch.cuda.device(dev):
+        st = nat.lib().gnncca_gather_cat(*args, rows, out.data_ptr(), _raw_stream(dev))
+    nat.check(st, "gnncca_gather_cat")
+    return out
+
+
 class _Replayed(nn.Module):
     """Base of the three top-level containers (encoder, MPNet, classifier).  They hold parameters; the arithmetic of a
-    forward runs fused inside libgnncca_mpn.so.  When a caller has registered forward hooks on one of them (the way
+    MOTMPNet forward runs fused inside libgnncca_mpn.so.  When a caller has registered forward hooks on one of them (the way
     per-step latents are usually tapped from the reference), MOTMPNet.forward runs the traced native forward and then
     REPLAYS the reference's call sequence (models/mpn.py:266-297) through ``__call__`` of these containers: each call returns
     the tensors the fused kernels produced for it, so hooks see the same inputs and outputs as on the reference.  A
-    container called on its own, outside MOTMPNet.forward, raises."""
+    container called on its own, outside MOTMPNet.forward, evaluates itself with the stand-alone entry points (eval mode)."""
 
-    def _take_replayed(self, what):
+    def _take_replayed(self):
         queue = getattr(self, '_replay_queue', None)
-        if not queue:
-            raise RuntimeError(f"{what} is a parameter container here: its arithmetic runs fused inside "
-                               "MOTMPNet.forward (libgnncca_mpn.so); register forward hooks on it and call the whole "
-                               "model to observe its inputs and outputs")
-        return queue.pop(0)
+        return queue.pop(0) if queue else None
 
 
 class MetaLayer(_Replayed):
-    """Container mirroring models/mpn.py:10-57 (``edge_model`` / ``node_model`` children)."""
+    """models/mpn.py:10-57 (``edge_model`` / ``node_model`` children)."""
 
     def __init__(self, edge_model=None, node_model=None):
         super().__init__()
@@ -44,29 +104,62 @@ class MetaLayer(_Replayed):
         self.node_model = node_model
 
     def forward(self, x, edge_index, edge_attr):
-        return self._take_replayed("MetaLayer")   # (x, edge_attr), models/mpn.py:54
+        got = self._take_replayed()
+        if got is not None:
+            return got                                  # (x, edge_attr), models/mpn.py:54
+        dev = _standalone_check(self, "MetaLayer", x, edge_index, edge_attr)
+        x, edge_attr = _f32(x, "x"), _f32(edge_attr, "edge_attr")
+        row, col = edge_index[0].contiguous(), edge_index[1].contiguous()   # mpn.py:44
+        e = edge_attr.shape[0]
+        src = _gather_cat([(x, row)], e, dev)           # x[row], x[col] (mpn.py:48)
+        dst = _gather_cat([(x, col)], e, dev)
+        edge_attr = self.edge_model(src, dst, edge_attr)
+        x = self.node_model(x, edge_index, edge_attr)   # mpn.py:52
+        return x, edge_attr
 
 
 class EdgeModel(nn.Module):
-    """Container mirroring models/mpn.py:59-69: owns ``edge_mlp`` (input = cat[x[row], x[col], e])."""
+    """models/mpn.py:59-69: owns ``edge_mlp`` (input = cat[source, target, edge_attr])."""
 
     def __init__(self, edge_mlp):
         super().__init__()
         self.edge_mlp = edge_mlp
 
+    def forward(self, source, target, edge_attr):
+        dev = _standalone_check(self, "EdgeModel", source, target, edge_attr)
+        out = _gather_cat([(_f32(source, "source"), None), (_f32(target, "target"), None), (_f32(edge_attr, "edge_attr"), None)],
+                          source.shape[0], dev)         # mpn.py:68
+        return self.edge_mlp(out)
+
 
 class NodeModel(nn.Module):
-    """Container mirroring models/mpn.py:71-101: owns ``node_mlp`` (input = cat[x[row], e']) and the name of the
-    aggregator applied over ``row``."""
+    """models/mpn.py:71-101: owns ``node_mlp`` (input = cat[x[row], e']) and the aggregator applied over ``row``."""
 
     def __init__(self, node_mlp, node_agg_fn):
         super().__init__()
         self.node_mlp = node_mlp
         self.node_agg_fn = node_agg_fn
 
+    def forward(self, x, edge_index, edge_attr):
+        dev = _standalone_check(self, "NodeModel", x, edge_index, edge_attr)
+        x, edge_attr = _f32(x, "x"), _f32(edge_attr, "edge_attr")
+        if edge_index.dtype != torch.int64:
+            raise RuntimeError("tensors used as indices must be long")
+        edge_index = edge_index.contiguous()
+        n, e = x.shape[0], edge_attr.shape[0]
+        flow = self.node_mlp(_gather_cat([(x, edge_index[0]), (edge_attr, None)], e, dev))   # mpn.py:97-98
+        lib = nat.lib()
+        out = torch.empty((n, flow.shape[1]), dtype=torch.float32, device=dev)
+        ws = torch.empty(lib.gnncca_aggregate_workspace_bytes(n, e) + 256, dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            st = lib.gnncca_aggregate(flow.data_ptr(), edge_index.data_ptr(), n, e, flow.shape[1], nat.AGG[self.node_agg_fn], out.data_ptr(),
+                                      ws.data_ptr(), ws.numel(), _raw_stream(dev))
+        nat.check(st, "gnncca_aggregate")
+        return out                                       # mpn.py:99
+
 
 class MLPGraphIndependent(_Replayed):
-    """Container mirroring models/mpn.py:103-142: an optional node MLP and an optional edge MLP."""
+    """models/mpn.py:103-142: an optional node MLP and an optional edge MLP."""
 
     def __init__(self, edge_in_dim=None, node_in_dim=None, edge_out_dim=None, node_out_dim=None,
                  node_fc_dims=None, edge_fc_dims=None, dropout_p=None, use_batchnorm=None):
@@ -79,7 +172,12 @@ class MLPGraphIndependent(_Replayed):
             self.edge_mlp = MLP(edge_in_dim, list(edge_fc_dims) + [edge_out_dim], dropout_p, use_batchnorm)
 
     def forward(self, edge_feats=None, nodes_feats=None):
-        return self._take_replayed("MLPGraphIndependent")   # (edge_out, node_out): edge first, models/mpn.py:142
+        got = self._take_replayed()
+        if got is not None:
+            return got                                   # (edge_out, node_out): edge first, models/mpn.py:142
+        node_out = self.node_mlp(nodes_feats) if self.node_mlp is not None and nodes_feats is not None else nodes_feats   # mpn.py:130-140
+        edge_out = self.edge_mlp(edge_feats) if self.edge_mlp is not None and edge_feats is not None else edge_feats
+        return edge_out, node_out
 
 
 def _raw_stream(device):

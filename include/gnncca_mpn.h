@@ -319,6 +319,23 @@ GNNCCA_API int gnncca_train_backward(const gnncca_mpn_dims* dims, float* const* 
                                      void* tape, size_t tape_bytes, const float* grad_logits, float* const* grads_dev,
                                      const gnncca_dropout* dropout, gnncca_stream_t stream);
 
+/* Stand-alone calls of the sub-modules, which the reference allows (models/mlp.py:26-28 MLP.forward; models/mpn.py:128-142
+ * MLPGraphIndependent.forward, :59-69 EdgeModel.forward, :71-101 NodeModel.forward, :32-54 MetaLayer.forward): eval semantics
+ * (BatchNorm from the running statistics, Dropout = identity), one launch per op.  MOTMPNet.forward does not use them.
+ *   gnncca_mlp_eval     : out[rows][out_dim] = mlp(in[rows][in_dim]); params in the order weight, bias, [BN weight, bias, mean, var]
+ *   gnncca_gather_cat   : out[r] = cat(a[ia[r]], b[ib[r]], c[ic[r]]) (null ids: row r itself; width 0: segment absent) -- the
+ *                         x[row], x[col] gathers and the torch.cat of mpn.py:48,68,97 without a torch kernel
+ *   gnncca_aggregate    : out[i] = sum | mean | max over {k : edge_index[0][k] == i} of messages[k], empty -> 0 (mpn.py:99,192-202) */
+GNNCCA_API size_t gnncca_mlp_eval_workspace_bytes(const gnncca_mlp* mlp, int64_t rows);
+GNNCCA_API int gnncca_mlp_eval(const gnncca_mlp* mlp, const float* const* params_dev, int n_params, const float* in, int64_t rows,
+                               float* out, void* workspace, size_t workspace_bytes, gnncca_stream_t stream);
+GNNCCA_API int gnncca_gather_cat(const float* a, const int64_t* ia, int wa, int64_t rows_a, const float* b, const int64_t* ib, int wb,
+                                 int64_t rows_b, const float* c, const int64_t* ic, int wc, int64_t rows_c, int64_t rows, float* out,
+                                 gnncca_stream_t stream);
+GNNCCA_API size_t gnncca_aggregate_workspace_bytes(int64_t n_nodes, int64_t n_edges);
+GNNCCA_API int gnncca_aggregate(const float* messages, const int64_t* edge_index, int64_t n_nodes, int64_t n_edges, int width, int agg,
+                                float* out, void* workspace, size_t workspace_bytes, gnncca_stream_t stream);
+
 /* Synchronises `stream` and returns the flag word of the last forward that used `workspace`. */
 GNNCCA_API int gnncca_read_graph_flags(const void* workspace, uint32_t* flags_out, gnncca_stream_t stream);
 

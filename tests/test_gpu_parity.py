@@ -515,8 +515,10 @@ def test_forward_hooks_on_containers_see_reference_tensors(name):
     for (dec, none), o, p in zip(seen["cls"], out, plain):
         assert none is None and dec is o
         assert np.abs(o.cpu().numpy() - p.cpu().numpy()).max() <= TOL_TIGHT
-    with pytest.raises(RuntimeError):                  # a container on its own has nothing to replay
-        m.MPNet(h_enc, d.edge_index, e_enc)
+    # a container on its own, outside MOTMPNet.forward: evaluates itself (test_submodules_called_on_their_own)
+    if L > 0:
+        h1, e1 = m.MPNet(seen["mp_in"][0][0], d.edge_index, seen["mp_in"][0][2])
+        assert np.abs(h1.cpu().numpy() - a["h_step_1"]).max() <= 2e-5 and np.abs(e1.cpu().numpy() - a["e_step_1"]).max() <= 2e-5
 
 
 def test_wrong_input_dtypes_raise_like_the_reference():
@@ -536,3 +538,59 @@ def test_wrong_input_dtypes_raise_like_the_reference():
         assert not xt.is_contiguous()
         out = m(Data(xt, d.edge_index, d.edge_attr))["classified_edges"]
     assert np.abs(out[-1].cpu().numpy() - a[f"logits_{int(a['n_logits']) - 1}"]).max() <= TOL_TIGHT
+
+
+@pytest.mark.parametrize("name", ["terrace32", "ragged_max", "ragged_mean", "reattach_n1e1", "generic_dims", "generic_reattach_max",
+                                  "dense24_shuffled", "steps_L0"])
+def test_submodules_called_on_their_own(name):
+    """The reference's sub-modules are callable by themselves (models/mpn.py:128-142 encoder / classifier, :32-54 MetaLayer,
+    :59-69 EdgeModel, :71-101 NodeModel, models/mlp.py:26-28 MLP).  Here they evaluate through gnncca_mlp_eval /
+    gnncca_gather_cat / gnncca_aggregate (eval mode); chained by hand as models/mpn.py:266-297 chains them they reproduce the
+    reference's golden latents and logits."""
+    params, arch, sd, a = load_case(os.path.join(GOLDEN_DIR, name + ".npz"))
+    m = build(params, arch, sd)
+    d = to_data(a)
+    tol = 2e-5
+    with torch.no_grad():
+        e_enc, h_enc = m.encoder(d.edge_attr, d.x)              # edge first (mpn.py:142)
+        assert np.abs(h_enc.cpu().numpy() - a["h_enc"]).max() <= tol and np.abs(e_enc.cpu().numpy() - a["e_enc"]).max() <= tol
+        assert m.encoder(None, d.x)[0] is None                   # None passes through (mpn.py:133-140)
+        h, e = h_enc, e_enc
+        L, first = int(params["num_enc_steps"]), int(params["num_enc_steps"]) - int(params["num_class_steps"]) + 1
+        logits = []
+        for step in range(1, L + 1):
+            if params["reattach_initial_edges"]:
+                e = torch.cat((e_enc, e), dim=1)
+            if params["reattach_initial_nodes"]:
+                h = torch.cat((h_enc, h), dim=1)
+            if step == 1:   # the two halves of a MetaLayer by hand (mpn.py:48,52)
+                row, col = d.edge_index
+                e_new = m.MPNet.edge_model(h[row], h[col], e)
+                h_new = m.MPNet.node_model(h, d.edge_index, e_new)
+                h2, e2 = m.MPNet(h, d.edge_index, e)
+                assert torch.equal(h2, h_new) and torch.equal(e2, e_new)
+                h, e = h_new, e_new
+            else:
+                h, e = m.MPNet(h, d.edge_index, e)
+            assert np.abs(h.cpu().numpy() - a[f"h_step_{step}"]).max() <= tol, (name, step)
+            assert np.abs(e.cpu().numpy() - a[f"e_step_{step}"]).max() <= tol, (name, step)
+            if step >= first:
+                dec, none = m.classifier(e)
+                assert none is None
+                logits.append(dec)
+        if L == 0:
+            logits.append(m.classifier(e)[0])
+        assert len(logits) == int(a["n_logits"])
+        for i, t in enumerate(logits):
+            assert t.shape == a[f"logits_{i}"].shape and np.abs(t.cpu().numpy() - a[f"logits_{i}"]).max() <= tol, (name, i)
+        # a bare MLP
+        y = m.encoder.node_mlp(d.x)
+        assert torch.equal(y, h_enc)
+    m.train()
+    with pytest.raises(RuntimeError):                            # stand-alone calls are eval-only
+        m.encoder(d.edge_attr, d.x)
+    m.eval()
+    with pytest.raises(RuntimeError):                            # no CPU fallback
+        m.encoder.node_mlp(d.x.cpu())
+    with pytest.raises(RuntimeError):                            # wrong dtype raises like the reference's Linear
+        m.encoder.node_mlp(d.x.double())
