@@ -102,6 +102,21 @@ static int prof_end(Profiler* p, hipStream_t st) {
     } while (0)
 
 
+// ---- LDS-DMA (global_load_lds): a load that writes LDS directly, no VGPR destination, tracked by the issuing wave's vmcnt only ----
+// The compiler neither counts these nor waits for them: pair every use with a counted GNNCCA_WAIT_VM and a barrier before the
+// ds_read (cdna_hip_programming.md: "Read a staged buffer one phase AFTER the wait that retires it").  Lane l's 16 bytes at
+// `gsrc` land at lds_dst + 16 l: the LDS image of one wave instruction is lane-linear (1 KB), the SOURCE address is per lane.
+__device__ __forceinline__ unsigned lds_off(const void* p) {
+    return (unsigned)(unsigned long long)(const __attribute__((address_space(3))) void*)p;
+}
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {   // M0 is written in the statement that reads it
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+#define GNNCCA_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+#define GNNCCA_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
 static inline dim3 grid1(size_t n, int b) { return dim3((unsigned)((n + b - 1) / b)); }
 
 // ---- train-mode Dropout (models/mlp.py:20-21: nn.Dropout after the ReLU of every MLP layer wider than 1) ---------------------------

@@ -268,14 +268,21 @@ struct EncFuseParams {
 // no conversion / LDS stores 183 us -- the kernel is bound by its x stream, not by the matrix pipe: walking a 256-row tile in
 // 128-B-per-row chunks with one workgroup per CU streams at 4.4 TB/s even in a bare copy loop (tools/ubench_rowtile.hip:
 // 122 us for these 537 MB; a linear sweep of the same bytes 86 us).
-template <bool FUSE, bool P3>
+// RING (round 2): the x operand arrives by LDS-DMA as raw fp32 into a three-slot ring, TWO chunks ahead of the MFMAs (the register
+// form above asks for chunk kt + 1 at the top of iteration kt and needs it at the bottom: one MFMA phase, 1.5-3 k cycles, against
+// an HBM latency under load of ~2 us), and the W pieces by LDS-DMA one chunk ahead; swizzles move to the SOURCE address (the LDS
+// image of a DMA instruction is lane-linear).  A fragments are read as fp32 and split into their three bf16 pieces in registers
+// by the wave that multiplies them (the same three roundings as store_stage: operands bit for bit those of the register form).
+// No compiler-tracked global load is left in the loop, so nothing drains the DMA queue but the counted waits below.
+template <bool FUSE, bool P3, bool RING = false>
 __global__ __launch_bounds__(512) void enc_gemm_split_lds_kernel(const float* __restrict__ x, const unsigned short* __restrict__ w3,
                                                                  float* __restrict__ out, int M, int K, int O, int kslice,
                                                                  const EncFuseParams fp) {
     constexpr int BK = 32, RA = kLdsGemmRows, RB = 128;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    __bf16* sa = reinterpret_cast<__bf16*>(lds_raw);                 // [2][3][RA][32]
-    __bf16* sb = sa + (size_t)2 * 3 * RA * BK;                       // [2][3][RB][32]
+    __bf16* sa = reinterpret_cast<__bf16*>(lds_raw);                 // [2][3][RA][32]          (register form)
+    __bf16* sb = sa + (size_t)2 * 3 * RA * BK;                       // [2][3][RB][32]          (both forms: same offset, 96 KB)
+    float* xring = reinterpret_cast<float*>(lds_raw);                // [3][RA][32] fp32 = 96 KB (RING)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1, h = lane >> 5, l32 = lane & 31;
@@ -382,18 +389,114 @@ __global__ __launch_bounds__(512) void enc_gemm_split_lds_kernel(const float* __
                 }
         }
     };
-    load_w(0);
-    load_x(0);
-    store_stage(0);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) {
-            load_w(kt + 1);
-            load_x(kt + 1);
-        }
-        mfma_chunk(kt & 1);
-        if (kt + 1 < nk) store_stage((kt + 1) & 1);
+    if (!RING) {
+        load_w(0);
+        load_x(0);
+        store_stage(0);
         __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 1 < nk) {
+                load_w(kt + 1);
+                load_x(kt + 1);
+            }
+            mfma_chunk(kt & 1);
+            if (kt + 1 < nk) store_stage((kt + 1) & 1);
+            __syncthreads();
+        }
+    } else {
+        // x chunk = 32 DMA instructions of 8 rows x 128 B (wave w issues 4 w .. 4 w + 3): lane -> (row 8 j + l / 8, LDS granule
+        // l % 8) which receives source granule (l % 8) ^ swz(row), swz(row) = (row >> 1) & 7 -- a ds_read_b128 of 16 consecutive
+        // rows then covers all 64 banks.  W chunk = 24 instructions of 16 columns x 64 B (wave w: 3 w .. 3 w + 2), source granule
+        // (l % 4) ^ ((col >> 2) & 3): the image mfma_chunk's B reads expect.
+        const float* xs[4];
+        unsigned xd[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = wave * 4 + u, r = 8 * j + (lane >> 3), g = (lane & 7) ^ ((r >> 1) & 7);
+            xs[u] = x + (size_t)min(row0 + r, M - 1) * K + kbeg + 4 * g;
+            xd[u] = __builtin_amdgcn_readfirstlane(lds_off(xring) + j * 1024);
+        }
+        const unsigned short* wsrc[3];
+        unsigned wd[3];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int i = wave * 3 + u, p = i >> 3, col = 16 * (i & 7) + (lane >> 2), g = (lane & 3) ^ ((col >> 2) & 3);
+            wsrc[u] = w3 + (size_t)(kbeg / BK) * wchunk + ((size_t)(p * RB + col) * 4 + g) * 8;
+            wd[u] = __builtin_amdgcn_readfirstlane(lds_off(sb) + i * 1024);
+        }
+        auto issue_x = [&](int kt) {
+            const unsigned slot = (unsigned)(kt % 3) * (RA * BK * 4);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) glds16(xs[u] + kt * BK, xd[u] + slot);
+        };
+        auto issue_w = [&](int kt) {
+            const unsigned stage = (unsigned)(kt & 1) * (3 * RB * BK * 2);
+#pragma unroll
+            for (int u = 0; u < 3; ++u) glds16(wsrc[u] + (size_t)kt * wchunk, wd[u] + stage);
+        };
+        // A fragments from the fp32 ring: 8 consecutive k of row ra = granules 2 kc, 2 kc + 1, each at position g ^ swz(ra)
+        auto mfma_chunk_ring = [&](int kt) {
+            const float* a = xring + (size_t)(kt % 3) * RA * BK;
+            const __bf16* b = sb + (size_t)(kt & 1) * 3 * RB * BK;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int kc = 2 * ks + h;
+                bf16x8 af[2][3], bf[2][3];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int ra = wr * 64 + t * 32 + l32, sw = (ra >> 1) & 7;
+                    const f32x4 lo = *reinterpret_cast<const f32x4*>(a + ra * BK + (((2 * kc) ^ sw) << 2));
+                    const f32x4 hi = *reinterpret_cast<const f32x4*>(a + ra * BK + (((2 * kc + 1) ^ sw) << 2));
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const float v = q < 4 ? lo[q & 3] : hi[q & 3];
+                        const __bf16 h0 = (__bf16)v;
+                        const float r1 = v - (float)h0;
+                        const __bf16 h1 = (__bf16)r1;
+                        const float r2 = r1 - (float)h1;
+                        af[t][0][q] = h0, af[t][1][q] = h1, af[t][2][q] = (__bf16)r2;
+                    }
+#pragma unroll
+                    for (int p = 0; p < 3; ++p)
+                        bf[t][p] = *reinterpret_cast<const bf16x8*>(b + p * RB * BK + brow[t] + ((kc ^ bswz[t]) << 3));
+                }
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct) {
+                        if (!P3) {
+                            acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[rt][2], bf[ct][0], acc[rt][ct], 0, 0, 0);
+                            acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[rt][1], bf[ct][1], acc[rt][ct], 0, 0, 0);
+                            acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[rt][0], bf[ct][2], acc[rt][ct], 0, 0, 0);
+                        }
+                        acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[rt][1], bf[ct][0], acc[rt][ct], 0, 0, 0);
+                        acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[rt][0], bf[ct][1], acc[rt][ct], 0, 0, 0);
+                        acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[rt][0], bf[ct][0], acc[rt][ct], 0, 0, 0);
+                    }
+            }
+        };
+        // prologue: x(0), W(0), then x(1); the first wait leaves x(1) in flight
+        issue_x(0);
+        issue_w(0);
+        if (nk > 1) {
+            issue_x(1);
+            GNNCCA_WAIT_VM(4);
+        } else {
+            GNNCCA_WAIT_VM(0);
+        }
+        GNNCCA_LDS_BARRIER();
+        for (int kt = 0; kt < nk; ++kt) {
+            // slot (kt + 2) % 3 and W stage (kt + 1) & 1 were last read in iteration kt - 1: every wave is past that barrier
+            if (kt + 1 < nk) issue_w(kt + 1);
+            if (kt + 2 < nk) issue_x(kt + 2);
+            mfma_chunk_ring(kt);
+            // chunk kt + 1 (x issued an iteration ago, W just now) must have landed before the barrier; x(kt + 2) stays in flight
+            if (kt + 2 < nk)
+                GNNCCA_WAIT_VM(4);
+            else
+                GNNCCA_WAIT_VM(0);
+            GNNCCA_LDS_BARRIER();
+        }
     }
     if (!FUSE) {
         float* __restrict__ dst = out + (size_t)blockIdx.y * M * O;
