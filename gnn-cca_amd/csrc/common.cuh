@@ -35,6 +35,29 @@ __device__ unsigned long long* g_stamps = nullptr;
     } while (0)
 #endif
 
+// Diagnostic build only: per-wave TOTALS of the cycles spent in up to 8 phases of a loop (s_memtime deltas accumulated in registers,
+// written once at the end: g_stamps[slot][block < 4096][wave & 3][0..7]).  Nothing in the product build.
+#ifdef GNNCCA_STAMPS
+#define PHASE_T_DECL unsigned long long pt_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pt_last = __builtin_amdgcn_s_memtime(), pt_real0 = __builtin_amdgcn_s_memrealtime()
+#define PHASE_T(i)                                                      \
+    do {                                                                \
+        const unsigned long long pt_now = __builtin_amdgcn_s_memtime(); \
+        pt_acc[i] += pt_now - pt_last;                                  \
+        pt_last = pt_now;                                               \
+    } while (0)
+#define PHASE_T_FLUSH(slot)                                                                                                   \
+    do {                                                                                                                      \
+ pt_acc[7] = __builtin_amdgcn_s_memrealtime() - pt_real0; /* 100 MHz */                                              \
+        if (g_stamps && (threadIdx.x & 63) == 0 && blockIdx.x < 4096 && (threadIdx.x >> 6) < 4)                               \
+            for (int q = 0; q < 8; ++q)                                                                                       \
+                g_stamps[((((size_t)(slot)) * 4096 + blockIdx.x) * 4 + (threadIdx.x >> 6)) * 16 + q] = pt_acc[q];             \
+    } while (0)
+#else
+#define PHASE_T_DECL do { } while (0)
+#define PHASE_T(i) do { } while (0)
+#define PHASE_T_FLUSH(slot) do { } while (0)
+#endif
+
 #define HIP_TRY(expr)                                  \
     do {                                               \
         hipError_t _e = (expr);                        \
@@ -101,21 +124,6 @@ static int prof_end(Profiler* p, hipStream_t st) {
             hipLaunchKernelGGL(kernel, grid, block, lds, st, __VA_ARGS__);                                            \
     } while (0)
 
-
-// ---- LDS-DMA (global_load_lds): a load that writes LDS directly, no VGPR destination, tracked by the issuing wave's vmcnt only ----
-// The compiler neither counts these nor waits for them: pair every use with a counted GNNCCA_WAIT_VM and a barrier before the
-// ds_read (cdna_hip_programming.md: "Read a staged buffer one phase AFTER the wait that retires it").  Lane l's 16 bytes at
-// `gsrc` land at lds_dst + 16 l: the LDS image of one wave instruction is lane-linear (1 KB), the SOURCE address is per lane.
-__device__ __forceinline__ unsigned lds_off(const void* p) {
-    return (unsigned)(unsigned long long)(const __attribute__((address_space(3))) void*)p;
-}
-__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {   // M0 is written in the statement that reads it
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
-#define GNNCCA_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
-#define GNNCCA_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
 static inline dim3 grid1(size_t n, int b) { return dim3((unsigned)((n + b - 1) / b)); }
 

@@ -268,21 +268,20 @@ struct EncFuseParams {
 // no conversion / LDS stores 183 us -- the kernel is bound by its x stream, not by the matrix pipe: walking a 256-row tile in
 // 128-B-per-row chunks with one workgroup per CU streams at 4.4 TB/s even in a bare copy loop (tools/ubench_rowtile.hip:
 // 122 us for these 537 MB; a linear sweep of the same bytes 86 us).
-// RING (round 2): the x operand arrives by LDS-DMA as raw fp32 into a three-slot ring, TWO chunks ahead of the MFMAs (the register
-// form above asks for chunk kt + 1 at the top of iteration kt and needs it at the bottom: one MFMA phase, 1.5-3 k cycles, against
-// an HBM latency under load of ~2 us), and the W pieces by LDS-DMA one chunk ahead; swizzles move to the SOURCE address (the LDS
-// image of a DMA instruction is lane-linear).  A fragments are read as fp32 and split into their three bf16 pieces in registers
-// by the wave that multiplies them (the same three roundings as store_stage: operands bit for bit those of the register form).
-// No compiler-tracked global load is left in the loop, so nothing drains the DMA queue but the counted waits below.
-template <bool FUSE, bool P3, bool RING = false>
+// PIPE (round 2): the same operands, stages and MFMAs, software-pipelined by k-HALF with the chunk's one barrier BETWEEN the halves.
+// With the barrier at the chunk end (the form above) every wave of the workgroup converts / stores / reads fragments at the same
+// time and then queues for the matrix pipe at the same time -- 48 % MFMA-busy, and an LDS-DMA variant that hid ALL of the x latency
+// ran no faster.  Here, while the 24 MFMAs of one half run, the wave reads the fragments of the next half
+// (the next chunk's first half included: that chunk is published at the mid-chunk barrier) and converts + stores the chunk after
+// it; x is requested two chunks ahead in two register sets.
+template <bool FUSE, bool P3, bool PIPE = false>
 __global__ __launch_bounds__(512) void enc_gemm_split_lds_kernel(const float* __restrict__ x, const unsigned short* __restrict__ w3,
                                                                  float* __restrict__ out, int M, int K, int O, int kslice,
                                                                  const EncFuseParams fp) {
     constexpr int BK = 32, RA = kLdsGemmRows, RB = 128;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    __bf16* sa = reinterpret_cast<__bf16*>(lds_raw);                 // [2][3][RA][32]          (register form)
-    __bf16* sb = sa + (size_t)2 * 3 * RA * BK;                       // [2][3][RB][32]          (both forms: same offset, 96 KB)
-    float* xring = reinterpret_cast<float*>(lds_raw);                // [3][RA][32] fp32 = 96 KB (RING)
+    __bf16* sa = reinterpret_cast<__bf16*>(lds_raw);                 // [2][3][RA][32]
+    __bf16* sb = sa + (size_t)2 * 3 * RA * BK;                       // [2][3][RB][32]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1, h = lane >> 5, l32 = lane & 31;
@@ -389,7 +388,7 @@ __global__ __launch_bounds__(512) void enc_gemm_split_lds_kernel(const float* __
                 }
         }
     };
-    if (!RING) {
+    if (!PIPE) {
         load_w(0);
         load_x(0);
         store_stage(0);
@@ -404,99 +403,117 @@ __global__ __launch_bounds__(512) void enc_gemm_split_lds_kernel(const float* __
             __syncthreads();
         }
     } else {
-        // x chunk = 32 DMA instructions of 8 rows x 128 B (wave w issues 4 w .. 4 w + 3): lane -> (row 8 j + l / 8, LDS granule
-        // l % 8) which receives source granule (l % 8) ^ swz(row), swz(row) = (row >> 1) & 7 -- a ds_read_b128 of 16 consecutive
-        // rows then covers all 64 banks.  W chunk = 24 instructions of 16 columns x 64 B (wave w: 3 w .. 3 w + 2), source granule
-        // (l % 4) ^ ((col >> 2) & 3): the image mfma_chunk's B reads expect.
-        const float* xs[4];
-        unsigned xd[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int j = wave * 4 + u, r = 8 * j + (lane >> 3), g = (lane & 7) ^ ((r >> 1) & 7);
-            xs[u] = x + (size_t)min(row0 + r, M - 1) * K + kbeg + 4 * g;
-            xd[u] = __builtin_amdgcn_readfirstlane(lds_off(xring) + j * 1024);
-        }
-        const unsigned short* wsrc[3];
-        unsigned wd[3];
-#pragma unroll
-        for (int u = 0; u < 3; ++u) {
-            const int i = wave * 3 + u, p = i >> 3, col = 16 * (i & 7) + (lane >> 2), g = (lane & 3) ^ ((col >> 2) & 3);
-            wsrc[u] = w3 + (size_t)(kbeg / BK) * wchunk + ((size_t)(p * RB + col) * 4 + g) * 8;
-            wd[u] = __builtin_amdgcn_readfirstlane(lds_off(sb) + i * 1024);
-        }
-        auto issue_x = [&](int kt) {
-            const unsigned slot = (unsigned)(kt % 3) * (RA * BK * 4);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) glds16(xs[u] + kt * BK, xd[u] + slot);
+        struct Frag {
+            bf16x8 a[2][3], b[2][3];
         };
-        auto issue_w = [&](int kt) {
-            const unsigned stage = (unsigned)(kt & 1) * (3 * RB * BK * 2);
+        auto read_frag = [&](int stage, int ks, Frag& f) {
+            const __bf16* a = sa + (size_t)stage * 3 * RA * BK;
+            const __bf16* b = sb + (size_t)stage * 3 * RB * BK;
+            const int kc = 2 * ks + h;
 #pragma unroll
-            for (int u = 0; u < 3; ++u) glds16(wsrc[u] + (size_t)kt * wchunk, wd[u] + stage);
-        };
-        // A fragments from the fp32 ring: 8 consecutive k of row ra = granules 2 kc, 2 kc + 1, each at position g ^ swz(ra)
-        auto mfma_chunk_ring = [&](int kt) {
-            const float* a = xring + (size_t)(kt % 3) * RA * BK;
-            const __bf16* b = sb + (size_t)(kt & 1) * 3 * RB * BK;
+            for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const int kc = 2 * ks + h;
-                bf16x8 af[2][3], bf[2][3];
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const int ra = wr * 64 + t * 32 + l32, sw = (ra >> 1) & 7;
-                    const f32x4 lo = *reinterpret_cast<const f32x4*>(a + ra * BK + (((2 * kc) ^ sw) << 2));
-                    const f32x4 hi = *reinterpret_cast<const f32x4*>(a + ra * BK + (((2 * kc + 1) ^ sw) << 2));
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        const float v = q < 4 ? lo[q & 3] : hi[q & 3];
-                        const __bf16 h0 = (__bf16)v;
-                        const float r1 = v - (float)h0;
-                        const __bf16 h1 = (__bf16)r1;
-                        const float r2 = r1 - (float)h1;
-                        af[t][0][q] = h0, af[t][1][q] = h1, af[t][2][q] = (__bf16)r2;
-                    }
-#pragma unroll
-                    for (int p = 0; p < 3; ++p)
-                        bf[t][p] = *reinterpret_cast<const bf16x8*>(b + p * RB * BK + brow[t] + ((kc ^ bswz[t]) << 3));
+                for (int p = 0; p < 3; ++p) {
+                    f.a[t][p] = *reinterpret_cast<const bf16x8*>(a + p * RA * BK + arow[t] + ((kc ^ aswz[t]) << 3));
+                    f.b[t][p] = *reinterpret_cast<const bf16x8*>(b + p * RB * BK + brow[t] + ((kc ^ bswz[t]) << 3));
                 }
-#pragma unroll
-                for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-                    for (int ct = 0; ct < 2; ++ct) {
-                        if (!P3) {
-                            acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[rt][2], bf[ct][0], acc[rt][ct], 0, 0, 0);
-                            acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[rt][1], bf[ct][1], acc[rt][ct], 0, 0, 0);
-                            acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[rt][0], bf[ct][2], acc[rt][ct], 0, 0, 0);
-                        }
-                        acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[rt][1], bf[ct][0], acc[rt][ct], 0, 0, 0);
-                        acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[rt][0], bf[ct][1], acc[rt][ct], 0, 0, 0);
-                        acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[rt][0], bf[ct][0], acc[rt][ct], 0, 0, 0);
-                    }
-            }
         };
-        // prologue: x(0), W(0), then x(1); the first wait leaves x(1) in flight
-        issue_x(0);
-        issue_w(0);
-        if (nk > 1) {
-            issue_x(1);
-            GNNCCA_WAIT_VM(4);
-        } else {
-            GNNCCA_WAIT_VM(0);
+        auto mfma_half = [&](const Frag& f) {
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) {
+                    if (!P3) {
+                        acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[rt][2], f.b[ct][0], acc[rt][ct], 0, 0, 0);
+                        acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[rt][1], f.b[ct][1], acc[rt][ct], 0, 0, 0);
+                        acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[rt][0], f.b[ct][2], acc[rt][ct], 0, 0, 0);
+                    }
+                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[rt][1], f.b[ct][0], acc[rt][ct], 0, 0, 0);
+                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[rt][0], f.b[ct][1], acc[rt][ct], 0, 0, 0);
+                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[rt][0], f.b[ct][0], acc[rt][ct], 0, 0, 0);
+                }
+        };
+        // x in two register sets (chunk k in set k & 1), W in one (its source is L2-resident)
+        f32x4 xs[1][4];
+        auto load_x2 = [&](int kt, f32x4 (&dst)[4]) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) dst[u] = *reinterpret_cast<const f32x4*>(xsrc[u] + kt * BK);
+        };
+        auto store_stage2 = [&](int stage, const f32x4 (&src)[4]) {
+            __bf16* a = sa + (size_t)stage * 3 * RA * BK;
+            __bf16* b = sb + (size_t)stage * 3 * RB * BK;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                bf16x4 p0, p1, p2;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float v = src[u][q];
+                    const __bf16 h0 = (__bf16)v;
+                    const float r1 = v - (float)h0;
+                    const __bf16 h1 = (__bf16)r1;
+                    const float r2 = r1 - (float)h1;
+                    p0[q] = h0, p1[q] = h1, p2[q] = (__bf16)r2;
+                }
+                *reinterpret_cast<bf16x4*>(a + xdst[u]) = p0;
+                *reinterpret_cast<bf16x4*>(a + RA * BK + xdst[u]) = p1;
+                *reinterpret_cast<bf16x4*>(a + 2 * RA * BK + xdst[u]) = p2;
+            }
+#pragma unroll
+            for (int u = 0; u < 3; ++u) *reinterpret_cast<bf16x8*>(b + wdst[u]) = wreg[u];
+        };
+        Frag f0, f1;
+        // chunk k lives in stage k & 1.  Phase 1 of chunk kt: MFMAs of its first half while its second half is read.  Barrier: every
+        // wave has read all of chunk kt (its stage is free) and chunk kt + 1 -- stored a chunk ago -- is visible.  Phase 2: MFMAs of
+        // the second half while chunk kt + 2 is converted and stored into the freed stage, the loads of chunk kt + 3 are issued (they
+        // have a whole chunk to land: an HBM round trip under load is about one) and the first half of chunk kt + 1 is read.
+        load_w(0);
+        load_x2(0, xs[0]);
+        store_stage2(0, xs[0]);
+        load_w(min(1, nk - 1));
+        load_x2(min(1, nk - 1), xs[0]);
+        store_stage2(1, xs[0]);
+        load_w(min(2, nk - 1));
+        load_x2(min(2, nk - 1), xs[0]);
+        __syncthreads();
+        read_frag(0, 0, f0);
+        PHASE_T_DECL;
+        for (int kt = 0; kt < nk - 1; ++kt) {   // every chunk but the last: straight-line phases (loads unconditional, clamped)
+            const int stage = kt & 1;
+            PHASE_T(3);
+            __builtin_amdgcn_sched_barrier(0);
+            read_frag(stage, 1, f1);
+            mfma_half(f0);
+#pragma unroll
+            for (int i = 0; i < 12; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, P3 ? 1 : 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            PHASE_T(0);
+            __syncthreads();
+            PHASE_T(1);
+            store_stage2(stage, xs[0]);                  // chunk kt + 2 (for kt + 2 >= nk: a clamped duplicate nobody reads)
+            load_w(min(kt + 3, nk - 1));
+            load_x2(min(kt + 3, nk - 1), xs[0]);
+            read_frag(stage ^ 1, 0, f0);
+            mfma_half(f1);
+#pragma unroll
+            for (int i = 0; i < (P3 ? 12 : 24); ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);   // one MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, P3 ? 10 : 5, 1);   // conversion arithmetic
+                __builtin_amdgcn_sched_group_barrier(0x080, P3 ? 3 : 2, 1);    // LDS stores / fragment reads
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 1);   // a global load
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            PHASE_T(2);
         }
-        GNNCCA_LDS_BARRIER();
-        for (int kt = 0; kt < nk; ++kt) {
-            // slot (kt + 2) % 3 and W stage (kt + 1) & 1 were last read in iteration kt - 1: every wave is past that barrier
-            if (kt + 1 < nk) issue_w(kt + 1);
-            if (kt + 2 < nk) issue_x(kt + 2);
-            mfma_chunk_ring(kt);
-            // chunk kt + 1 (x issued an iteration ago, W just now) must have landed before the barrier; x(kt + 2) stays in flight
-            if (kt + 2 < nk)
-                GNNCCA_WAIT_VM(4);
-            else
-                GNNCCA_WAIT_VM(0);
-            GNNCCA_LDS_BARRIER();
+        PHASE_T_FLUSH(6);
+        {   // last chunk: nothing left to stage
+            read_frag((nk - 1) & 1, 1, f1);
+            mfma_half(f0);
+            mfma_half(f1);
         }
+        __syncthreads();   // the epilogue overwrites the stages
     }
     if (!FUSE) {
         float* __restrict__ dst = out + (size_t)blockIdx.y * M * O;

@@ -213,15 +213,15 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
                 // 256-row workgroups, both operands through LDS (144 KB: one workgroup per CU, 8 waves); split-K by whole
                 // rounds of 256 workgroups (internal.h: enc_lds_ksplit)
                 const dim3 fgrid((N + 255) / 256 + 1, 1), sgrid((N + 255) / 256, ks_split);
-                static const bool gemm_ring = std::getenv("GNNCCA_GEMM_RING") != nullptr;   // A/B: x / W by LDS-DMA (encoder.cuh: RING)
-                if (gemm_ring && fused_tail && split3)
+                static const bool gemm_pipe = std::getenv("GNNCCA_GEMM_NOPIPE") == nullptr;   // diagnostics: A/B against the barrier-per-chunk form (encoder.cuh: PIPE)
+                if (gemm_pipe && fused_tail && split3)
                     GNNCCA_LAUNCH((enc_gemm_split_lds_kernel<true, true, true>), fgrid, dim3(512), kLdsGemmBytes, st, cur_in, w3, part, N, K, O, K, fp);
-                else if (gemm_ring && fused_tail)
+                else if (gemm_pipe && fused_tail)
                     GNNCCA_LAUNCH((enc_gemm_split_lds_kernel<true, false, true>), fgrid, dim3(512), kLdsGemmBytes, st, cur_in, w3, part, N, K, O, K, fp);
-                else if (gemm_ring && split3)
+                else if (gemm_pipe && split3)
                     GNNCCA_LAUNCH((enc_gemm_split_lds_kernel<false, true, true>), sgrid, dim3(512), kLdsGemmBytes, st, cur_in, w3, part, N, K, O,
                                   K / ks_split, fp);
-                else if (gemm_ring)
+                else if (gemm_pipe)
                     GNNCCA_LAUNCH((enc_gemm_split_lds_kernel<false, false, true>), sgrid, dim3(512), kLdsGemmBytes, st, cur_in, w3, part, N, K, O,
                                   K / ks_split, fp);
                 else if (fused_tail && split3)

@@ -656,6 +656,20 @@ class MOTMPNet(nn.Module):
         self._dropout_ps()   # raises if the Dropout modules of one group disagree
         self._trainable_checked = True
 
+    def _check_batchnorm_rows(self, n, e):
+        """torch.nn.BatchNorm1d in train mode refuses a batch of one row (and an empty one): so does this module, with torch's words."""
+        for mlp, rows in ((self.encoder.node_mlp, n), (self.encoder.edge_mlp, e), (self.MPNet.edge_model.edge_mlp, e),
+                          (self.MPNet.node_model.node_mlp, e), (self.classifier.edge_mlp, e)):
+            if mlp is None or rows > 1:
+                continue
+            if mlp is not self.encoder.node_mlp and mlp is not self.encoder.edge_mlp and mlp is not self.classifier.edge_mlp \
+                    and int(self.num_enc_steps) == 0:
+                continue   # the MPN MLPs are never called when L == 0
+            for mod in mlp.fc_layers:
+                if isinstance(mod, nn.BatchNorm1d):
+                    raise ValueError(f"Expected more than 1 value per channel when training, got input size "
+                                     f"torch.Size([{rows}, {mod.num_features}])")
+
     def _count_batchnorm_calls(self, n_cls_calls, edges):
         """num_batches_tracked of every BatchNorm1d after one train-mode forward (one increment per call of its MLP)."""
         L = int(self.num_enc_steps)
@@ -711,6 +725,7 @@ class MOTMPNet(nn.Module):
             raise RuntimeError("gnn_cca_amd.MOTMPNet runs on MI355X only: move the module and `data` to the GPU "
                                "(there is no CPU fallback)")
         x, edge_index, edge_attr = self._check_inputs(data.x, data.edge_index, data.edge_attr)
+        self._check_batchnorm_rows(x.shape[0], edge_index.shape[1])
         fn = _MPNTrainFunction if self._train_path == 'fused' else _LayerwiseTrainFunction
         logits = fn.apply(self, x.detach(), edge_index, edge_attr.detach(), *params)
         return {'classified_edges': list(logits.unbind(0))}

@@ -191,3 +191,22 @@ def test_layerwise_engine_bigger_irregular_graph_vs_oracle_and_sgd_steps():
                     t.copy_(torch.from_numpy(np.asarray(nxt[k])))
         m.train()
         cur = nxt
+
+
+def test_batchnorm_refuses_a_single_row_like_torch():
+    """nn.BatchNorm1d in train mode raises ValueError for one value per channel; the reference would raise inside its first
+    BatchNorm call.  Same exception type and wording here, before any kernel runs."""
+    params, arch, sd, _, _, a = load_bwd("bn_everywhere", "lw_")
+    m = build(params, arch, sd)
+    x = torch.from_numpy(a["x"]).cuda()
+    one_edge = Data(x, torch.tensor([[0], [1]], dtype=torch.int64).cuda(), torch.from_numpy(a["edge_attr"][:1]).cuda())
+    with pytest.raises(ValueError, match="Expected more than 1 value per channel"):
+        m(one_edge)
+    one_node = Data(x[:1], torch.from_numpy(a["edge_index"]).cuda() * 0, torch.from_numpy(a["edge_attr"]).cuda())
+    with pytest.raises(ValueError, match="Expected more than 1 value per channel"):
+        m(one_node)
+    params2, arch2, sd2, _, _, a2 = load_bwd("cls_bn_train")           # the fused path's classifier BatchNorm, too
+    m2 = build(params2, arch2, sd2)
+    with pytest.raises(ValueError):
+        m2(Data(torch.from_numpy(a2["x"]).cuda(), torch.tensor([[0], [1]], dtype=torch.int64).cuda(),
+                torch.from_numpy(a2["edge_attr"][:1]).cuda()))
