@@ -155,7 +155,7 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
             const unsigned short* w3 = reinterpret_cast<const unsigned short*>(blob + hdr.enc_w3);
             static const bool force_direct = std::getenv("GNNCCA_GEMM_DIRECT") != nullptr;  // diagnostics: A/B the GEMMs
             static const bool no_fuse = std::getenv("GNNCCA_NO_FUSE") != nullptr;             // A/B against GEMM + tail launch
-            static const int lds_min = std::getenv("GNNCCA_GEMM_LDS_MIN") ? std::atoi(std::getenv("GNNCCA_GEMM_LDS_MIN")) : 12288;
+            static const int lds_min = std::getenv("GNNCCA_GEMM_LDS_MIN") ? std::atoi(std::getenv("GNNCCA_GEMM_LDS_MIN")) : 6144;
             const bool fusable = !no_fuse && !dropping && nl == 2 && d->enc_node.layers[1].in_dim == 128 && d->enc_node.layers[1].out_dim == kH &&
                                  !d->reattach_nodes && hdr.proj_wT != 0;
             const bool use_lds = N >= lds_min && O == 128 && !force_direct;
