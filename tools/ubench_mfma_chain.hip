@@ -60,7 +60,11 @@ int main() {
         run<4, 3>(w, out, sink);
         run<4, 6>(w, out, sink);
         run<2, 12>(w, out, sink);
-        run<4, 12>(w, out, sink);
+        run<4, 12>(w, out, sink);   // 24 MFMAs per trip: only two of the four tiles are touched
+        run<2, 1>(w, out, sink);
+        run<2, 6>(w, out, sink);
+        run<3, 8>(w, out, sink);
+        run<4, 24>(w, out, sink);   // one tile per trip, four tiles in rotation over trips
     }
     return 0;
 }
