@@ -95,6 +95,55 @@ __global__ __launch_bounds__(256) void tr_col_reduce_kernel(const float* __restr
     }
 }
 
+// The same reductions for NARROW matrices (O <= 256: every MLP of the shipped shapes), where a 64-column tile would leave most lanes
+// idle (O = 6: 6 of 64): the block walks its rows in passes of RB = 256 / O whole rows -- 256 consecutive floats, coalesced -- and a
+// thread keeps ONE column (t % O) for all passes; eight passes are requested before they are added.
+__global__ __launch_bounds__(256) void tr_col_reduce_narrow_kernel(const float* __restrict__ A, const float* __restrict__ Z,
+                                                                   const float* __restrict__ stat, long long M, int O, int rows_per_block,
+                                                                   double* __restrict__ out, int mode) {
+    __shared__ double s0[256], s1[256];
+    const int RB = 256 / O;                       // rows per pass
+    const int t = threadIdx.x;
+    const int rl = t / O, c = t - rl * O;
+    const bool on = rl < RB;
+    const long long r0 = (long long)blockIdx.x * rows_per_block, r1 = min(r0 + rows_per_block, M);
+    double a0 = 0.0, a1 = 0.0;
+    if (on) {
+        const float mean = mode >= 1 ? stat[c] : 0.f, invstd = mode == 2 ? stat[O + c] : 0.f;
+        for (long long rb = r0 + rl; rb < r1; rb += 8LL * RB) {
+            float z[8], g[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const long long r = rb + (long long)u * RB;
+                const bool ok = r < r1;
+                z[u] = ok ? Z[(size_t)r * O + c] : mean;
+                g[u] = (ok && mode == 2) ? A[(size_t)r * O + c] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const bool ok = rb + (long long)u * RB < r1;
+                if (mode == 0)
+                    a0 += ok ? (double)z[u] : 0.0;
+                else if (mode == 1) {
+                    const double dz = (double)z[u] - (double)mean;
+                    a0 += dz * dz;
+                } else {
+                    a0 += (double)g[u];
+                    a1 += (double)g[u] * (double)((z[u] - mean) * invstd);
+                }
+            }
+        }
+    }
+    s0[t] = a0, s1[t] = a1;
+    __syncthreads();
+    if (t < O) {   // the RB row lanes of column t, in order
+        double b0 = 0.0, b1 = 0.0;
+        for (int q = 0; q < RB; ++q) b0 += s0[q * O + t], b1 += s1[q * O + t];
+        atomicAdd(&out[t], b0);
+        if (mode == 2) atomicAdd(&out[O + t], b1);
+    }
+}
+
 __global__ void tr_bn_mean_kernel(const double* __restrict__ sums, long long M, int O, float* __restrict__ stat) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c < O) stat[c] = (float)(sums[c] / (double)M);
@@ -334,9 +383,17 @@ struct TrCtx {
 static int tr_col_reduce(const TrCtx& c, const float* A, const float* Z, const float* stat, long long M, int O, int mode) {
     double* sums = reinterpret_cast<double*>(c.base + c.P->dsum);
     HIP_TRY(hipMemsetAsync(sums, 0, 2 * (size_t)O * 8, c.st));
-    const int rows = 1024;
-    hipLaunchKernelGGL(tr_col_reduce_kernel, dim3((unsigned)((O + 63) / 64), (unsigned)((M + rows - 1) / rows)), dim3(256), 0, c.st, A, Z,
-                       stat, M, O, rows, sums, mode);
+    if (O <= 256) {
+        const int RB = 256 / O;
+        long long rows = (M + 1023) / 1024;                       // aim at ~1024 blocks ...
+        rows = std::max<long long>((rows + 8LL * RB - 1) / (8LL * RB) * (8LL * RB), 8LL * RB);   // ... of whole rounds of 8 passes
+        hipLaunchKernelGGL(tr_col_reduce_narrow_kernel, dim3((unsigned)((M + rows - 1) / rows)), dim3(256), 0, c.st, A, Z, stat, M, O,
+                           (int)rows, sums, mode);
+    } else {
+        const int rows = 1024;
+        hipLaunchKernelGGL(tr_col_reduce_kernel, dim3((unsigned)((O + 63) / 64), (unsigned)((M + rows - 1) / rows)), dim3(256), 0, c.st, A, Z,
+                           stat, M, O, rows, sums, mode);
+    }
     HIP_TRY(hipGetLastError());
     return GNNCCA_OK;
 }

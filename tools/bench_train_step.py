@@ -19,6 +19,12 @@ frames = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 cams = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 per = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 params = bench.graph_net_params(cls_bn=False)  # config_training.yaml shape
+ENGINE = os.environ.get("GNNCCA_TRAIN_ENGINE", "auto")   # 'layerwise': the layer-by-layer engine; + GNNCCA_TRAIN_BN=1: BatchNorm in every MLP
+if os.environ.get("GNNCCA_TRAIN_BN"):
+    params["encoder_feats_dict"]["nodes"]["resnet50"]["use_batchnorm"] = True
+    params["edge_model_feats_dict"]["use_batchnorm"] = True
+    params["node_model_feats_dict"]["use_batchnorm"] = True
+    params["classifier_feats_dict"]["use_batchnorm"] = True
 n_g = cams * per
 rows, cols = [], []
 for f in range(frames):
@@ -33,7 +39,9 @@ rng = np.random.default_rng(0)
 x = rng.standard_normal((N, 2048)).astype(np.float32); x /= np.linalg.norm(x, axis=0, keepdims=True)
 ea = rng.random((E, 4)).astype(np.float32)
 lab = (rng.random(E) < 0.2).astype(np.float32)
-model = bench.build_model(copy.deepcopy(params), n_g).cuda().train()
+model = bench.build_model(copy.deepcopy(params), n_g).cuda()
+model.train_engine = ENGINE
+model.train()
 class D: pass
 d = D(); d.x, d.edge_index, d.edge_attr = torch.from_numpy(x).cuda(), torch.from_numpy(ei).cuda(), torch.from_numpy(ea).cuda()
 labels = torch.from_numpy(lab).cuda()
@@ -66,7 +74,9 @@ try:
     for _ in range(50): graph.replay()
     torch.cuda.synchronize(); t_graph = (time.perf_counter() - t0) / 50
     # the replayed step must keep training: compare against eager steps from the same state
-    ref_model = bench.build_model(copy.deepcopy(params), n_g).cuda().train()
+    ref_model = bench.build_model(copy.deepcopy(params), n_g).cuda()
+    ref_model.train_engine = ENGINE
+    ref_model.train()
     ref_model.load_state_dict(model.state_dict())
     graph.replay(); torch.cuda.synchronize()
     ref_opt = torch.optim.SGD(ref_model.parameters(), lr=1e-3)
@@ -83,6 +93,6 @@ orc.loss_and_grads(x, ei, ea, lab)
 t0 = time.perf_counter()
 for _ in range(3): orc.loss_and_grads(x, ei, ea, lab)
 t_cpu = (time.perf_counter() - t0) / 3
-print(json.dumps({"stage": "train step (fwd+loss+bwd+SGD)", "frames": frames, "nodes": N, "edges": E, "gpu_ms": t_gpu * 1e3, "gpu_ms_hip_graph_replay": None if t_graph is None else t_graph * 1e3,
+print(json.dumps({"stage": "train step (fwd+loss+bwd+SGD)", "engine": model._train_path, "batchnorm_everywhere": bool(os.environ.get("GNNCCA_TRAIN_BN")), "frames": frames, "nodes": N, "edges": E, "gpu_ms": t_gpu * 1e3, "gpu_ms_hip_graph_replay": None if t_graph is None else t_graph * 1e3,
                   "graph_replay_loss_matches_eager": graph_ok,
                   "cpu_autograd_oracle_ms_16thr": t_cpu * 1e3, "speedup": t_cpu / t_gpu}))
