@@ -308,7 +308,8 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
                                (reinterpret_cast<uintptr_t>(part) & 15) == 0;
         // batches whose GEMM ran split-K: the tail on the matrix pipe, 32 nodes per workgroup
         static const bool no_mfma_tail = std::getenv("GNNCCA_NO_MFMA_TAIL") != nullptr;  // diagnostics: A/B the two tails
-        const bool tail_mfma = !dropping && !fused_tail && !no_mfma_tail && N >= 8192 && tp.F == 128 && tp.has_last && nl == 2 && !tp.reatt_n &&
+        static const int kTailMfmaMin = std::getenv("GNNCCA_TAIL_MFMA_MIN") ? std::atoi(std::getenv("GNNCCA_TAIL_MFMA_MIN")) : 6144;
+        const bool tail_mfma = !dropping && !fused_tail && !no_mfma_tail && N >= kTailMfmaMin && tp.F == 128 && tp.has_last && nl == 2 && !tp.reatt_n &&
                                (reinterpret_cast<uintptr_t>(part) & 15) == 0;
         if (fused_tail) {
             // nothing: h0, the projections and the plan's flag word all came out of the GEMM launch
