@@ -625,8 +625,9 @@ static int train_backward_impl(const gnncca_mpn_dims* d, float* const* params, i
     TrPlan P;
     int s = tr_prepare(d, params, n_params, n_nodes, n_edges, tape, tape_bytes, &P);
     if (s != GNNCCA_OK) return s;
-    if (!grads || !grad_logits) return GNNCCA_ERR_INVALID_ARG;
-    if (n_edges == 0) return GNNCCA_OK;
+    if (!grads) return GNNCCA_ERR_INVALID_ARG;
+    if (n_edges == 0) return GNNCCA_OK;   // no edge, no logit: nothing reaches any parameter (an empty grad_logits may be a null pointer)
+    if (!grad_logits) return GNNCCA_ERR_INVALID_ARG;
     TrCtx c;
     c.d = d, c.P = &P, c.base = static_cast<char*>(tape), c.params = params, c.grads = grads, c.drop = tr_dropcfg(dropout), c.st = st;
     const int N = (int)n_nodes, E = (int)n_edges, H = d->node_dim, EF = d->edge_dim;

@@ -210,3 +210,17 @@ def test_batchnorm_refuses_a_single_row_like_torch():
     with pytest.raises(ValueError):
         m2(Data(torch.from_numpy(a2["x"]).cuda(), torch.tensor([[0], [1]], dtype=torch.int64).cuda(),
                 torch.from_numpy(a2["edge_attr"][:1]).cuda()))
+
+
+@pytest.mark.parametrize("engine", ["auto", "layerwise"])
+def test_train_mode_graph_without_edges(engine):
+    """A frame whose detections all come from one camera has no edges: the train-mode forward returns empty logits (one tensor
+    per classified step) and a backward through them leaves every gradient at zero -- on both engines, without a launch fault."""
+    params, arch, sd, _, _, a = load_bwd("terrace32")
+    m = build(params, arch, sd, engine=engine)
+    d = Data(torch.from_numpy(a["x"]).cuda(), torch.zeros((2, 0), dtype=torch.int64).cuda(), torch.zeros((0, 4)).cuda())
+    out = m(d)["classified_edges"]
+    assert len(out) == 3 and all(tuple(t.shape) == (0, 1) for t in out)
+    sum(t.sum() for t in out).backward()
+    for k, p in m.named_parameters():
+        assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
