@@ -1,3 +1,6 @@
+"""Per-launch kernel times of one forward (events attached to every dispatch, model.forward_profiled): median over 10 forwards.
+    python tools/prof_kernels.py <graphs>x<nodes>        e.g. 64x256, 512x128, 1x256
+Diagnostic switches are read from the environment by the library (GNNCCA_WPS, GNNCCA_GEMM_NOPIPE, GNNCCA_GEMM_LDS_MIN, ...)."""
 import copy, json, sys, time, os
 sys.path.insert(0, os.getcwd())
 import numpy as np, torch, bench
