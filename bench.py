@@ -169,7 +169,23 @@ def cpu_baseline(params, model, n_nodes, n_graphs, budget_s=20.0):
     best = min(results, key=lambda c: results[c][0])
     med, n_runs = results[best]
     others = ", ".join(f"{c}thr {results[c][0] * 1e3:.1f}ms" for c in cands)
-    return {"value": E / med, "unit": "edges/s", "cores": best, "kind": "port",
+    # the same sample through the HIP path, checked against the oracle's logits (the parity metric next to the
+    # throughput): max |logit_gpu - logit_cpu| per classified step and the largest deviation relative to max |logit|
+    parity = None
+    try:
+        ref = orc.forward(d.x, d.edge_index, d.edge_attr)
+        dev = next(model.parameters()).device
+        dg = Data()
+        dg.x, dg.edge_index, dg.edge_attr = d.x.to(dev), d.edge_index.to(dev), d.edge_attr.to(dev)
+        with torch.no_grad():
+            got = model(dg)["classified_edges"]
+        errs = [float((g.cpu() - torch.as_tensor(r)).abs().max()) for g, r in zip(got, ref)]
+        scale = max(float(torch.as_tensor(r).abs().max()) for r in ref)
+        parity = {"max_abs_err": errs, "max_rel_err": max(errs) / max(scale, 1e-30), "max_abs_logit": scale, "tolerance_abs": 1e-4,
+                  "ok": bool(max(errs) <= 1e-4), "against": "oracle.TorchOracle (fp32, CPU) on the cpu_baseline sample"}
+    except Exception as exc:  # noqa: BLE001
+        parity = {"error": f"{type(exc).__name__}: {exc}"}
+    return {"value": E / med, "unit": "edges/s", "cores": best, "kind": "port", "parity": parity,
             "sample": f"{n_runs} forwards of {g_sample} x dense{n_nodes} (E={E}), median {med * 1e3:.2f} ms at {best} "
                       f"threads (host has {ncpu}; medians: {others}); torch CPU op-for-op restatement "
                       f"(oracle.TorchOracle), fp32"}
@@ -510,6 +526,7 @@ def main():
             res["roofline_at_scale"] = scale_probe(params, device, args)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(params, model, args.nodes, args.graphs)
+            res["parity"] = res["cpu_baseline"].pop("parity", None)
             res["config"]["gpu_over_cpu"] = res["value"] / res["cpu_baseline"]["value"]
             try:   # informational second flavour; the >= 50x target is stated against `cpu_baseline` (the reference-shaped path)
                 res["cpu_baseline_fused"] = cpu_baseline_fused(params, model, args.nodes, args.graphs)
