@@ -139,6 +139,17 @@ def scale_probe(params, device, args, graphs=64):
             "algorithmic_bytes_per_launch": alg, "kernel": "mpn_step_fast_kernel (same kernel as `roofline`)"}
 
 
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown CPU"
+
+
 def cpu_baseline(params, model, n_nodes, n_graphs, budget_s=20.0):
     """The reference-shaped CPU path (oracle.TorchOracle: index/cat/addmm/relu/index_add_, the torch CPU kernels the
     reference itself runs) on a bounded sample of the same workload."""
@@ -153,7 +164,7 @@ def cpu_baseline(params, model, n_nodes, n_graphs, budget_s=20.0):
     # torch's CPU kernels do not scale to every core of a big host on this small problem: time a few thread counts
     # inside the budget and report the FASTEST (most favourable to the CPU), naming the others in `sample`.
     ncpu = os.cpu_count() or 1
-    cands = sorted({c for c in (8, 16, 32, 64) if c <= ncpu} | ({ncpu} if ncpu <= 64 else set()))
+    cands = sorted({c for c in (1, 8, 16, 32, 64) if c <= ncpu} | ({ncpu} if ncpu <= 64 else set()))   # k = 1 and many
     results = {}
     for c in cands:
         torch.set_num_threads(c)
@@ -187,8 +198,8 @@ def cpu_baseline(params, model, n_nodes, n_graphs, budget_s=20.0):
         parity = {"error": f"{type(exc).__name__}: {exc}"}
     return {"value": E / med, "unit": "edges/s", "cores": best, "kind": "port", "parity": parity,
             "sample": f"{n_runs} forwards of {g_sample} x dense{n_nodes} (E={E}), median {med * 1e3:.2f} ms at {best} "
-                      f"threads (host has {ncpu}; medians: {others}); torch CPU op-for-op restatement "
-                      f"(oracle.TorchOracle), fp32"}
+                      f"threads (host: {_cpu_model()}, {ncpu} hardware threads; medians: {others}); torch CPU op-for-op "
+                      f"restatement (oracle.TorchOracle), fp32"}
 
 
 class LazyDenseGraphs:
