@@ -48,9 +48,9 @@ __device__ unsigned long long* g_stamps = nullptr;
 #define PHASE_T_FLUSH(slot)                                                                                                   \
     do {                                                                                                                      \
  pt_acc[7] = __builtin_amdgcn_s_memrealtime() - pt_real0; /* 100 MHz */                                              \
-        if (g_stamps && (threadIdx.x & 63) == 0 && blockIdx.x < 4096 && (threadIdx.x >> 6) < 4)                               \
+        if (g_stamps && (threadIdx.x & 63) == 0 && blockIdx.x < 2048 && (threadIdx.x >> 6) < 8)   /* waves 4-7: block + 2048 */  \
             for (int q = 0; q < 8; ++q)                                                                                       \
-                g_stamps[((((size_t)(slot)) * 4096 + blockIdx.x) * 4 + (threadIdx.x >> 6)) * 16 + q] = pt_acc[q];             \
+                g_stamps[((((size_t)(slot)) * 4096 + blockIdx.x + 2048 * (threadIdx.x >> 8)) * 4 + ((threadIdx.x >> 6) & 3)) * 16 + q] = pt_acc[q]; \
     } while (0)
 #else
 #define PHASE_T_DECL do { } while (0)

@@ -28,12 +28,15 @@ with torch.no_grad():
     model(data)
     torch.cuda.synchronize()
     lib.gnncca_debug_set_stamps(None)
-st = buf.cpu().numpy().reshape(8, 4096, 4, 16).astype(np.float64)[6].reshape(-1, 16)
-st = st[st[:, :4].sum(1) > 0]
+raw = buf.cpu().numpy().reshape(8, 4096, 4, 16).astype(np.float64)[6]
 names = ["phase 1 (12 fragment reads + 24 MFMA)", "barrier wait", "phase 2 (convert + store + loads + 12 reads + 24 MFMA)", "loop overhead"]
-tot = np.median(st[:, :4].sum(1))
-print(f"{len(st)} waves (waves 0-3 of each workgroup); total per wave {tot:.0f} ticks of s_memtime")
-for i, n in enumerate(names):
-    print(f"   {n:58s} median {np.median(st[:, i]):10.0f}  ({100 * np.median(st[:, i]) / tot:5.1f} %)")
-real = np.median(st[:, 7])
-print(f"   loop wall time (s_memrealtime, 100 MHz): {real / 100:.1f} us -> s_memtime rate {tot / (real / 100) / 1e3:.2f} GHz")
+for label, st in (("waves 0-3", raw[:2048].reshape(-1, 16)), ("waves 4-7", raw[2048:].reshape(-1, 16))):
+    st = st[st[:, :4].sum(1) > 0]
+    if len(st) == 0:
+        continue
+    tot = np.median(st[:, :4].sum(1))
+    print(f"{label}: {len(st)} waves; total per wave {tot:.0f} ticks of s_memtime")
+    for i, n in enumerate(names):
+        print(f"   {n:58s} median {np.median(st[:, i]):10.0f}  ({100 * np.median(st[:, i]) / tot:5.1f} %)")
+    real = np.median(st[:, 7])
+    print(f"   loop wall time (s_memrealtime, 100 MHz): {real / 100:.1f} us -> s_memtime rate {tot / (real / 100) / 1e3:.2f} GHz")
