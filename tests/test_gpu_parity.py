@@ -218,12 +218,12 @@ def test_big_batch_split_bf16_encoder_vs_oracle():
         assert np.abs(o.cpu().numpy() - r).max() <= TOL_TIGHT * 2
 
 
-@pytest.mark.parametrize("n_nodes", [8192 + 5, 16384, 16384 + 77, 40000, 51200 + 33])
+@pytest.mark.parametrize("n_nodes", [4096 + 3, 6144, 6144 + 9, 8192 + 5, 16384, 16384 + 77, 40000, 51200 + 33])
 def test_lds_staged_split_gemm_vs_fp64_oracle(n_nodes):
-    """N >= 16 384 nodes: the first encoder layer runs on the 256-row, both-operands-through-LDS split-bf16 GEMM
-    (ragged N exercises the clamped loads / masked stores; 16 384 / 40 000 split K four ways and finish in the MFMA tail
-    kernel, 51 233 runs un-split -- 201 row blocks, one round of workgroups -- with the rest of the encoder and the step-1
-    projections in the GEMM's fused epilogue; 8 197 takes the 128-row GEMM + the MFMA tail over eight slabs).  A sparse ring
+    """N >= 6144 nodes: the first encoder layer runs on the 256-row, both-operands-through-LDS split-bf16 GEMM, software-pipelined by
+    k-half (ragged N exercises the clamped loads / masked stores; 6144 ... 40 000 split K and finish in the MFMA tail kernel over 8 or 4
+    slabs, 51 233 runs un-split -- 201 row blocks, one round of workgroups -- with the rest of the encoder and the step-1
+    projections in the GEMM's fused epilogue; 4 099 takes the 128-row GEMM and the wave-per-node tail).  A sparse ring
     graph keeps the oracle cheap; the encoder output is judged against an fp64 evaluation, the logits against the fp32
     oracle."""
     params, arch, sd = _default_model(1.0)
