@@ -4,8 +4,8 @@ python3 tools/pmc_kernel.py "enc_gemm_split_lds_kernel<true" "$G" -- --graphs 51
 cp gpurun_out/pmc_kernel/summary.json gpurun_out/r02_encgemm_lds_fused_512x128.json
 python3 tools/pmc_kernel.py "enc_gemm_split_lds_kernel<false" "$G" -- --graphs 64 --nodes 256 > gpurun_out/r2_pmc_enc_b.log 2>&1
 cp gpurun_out/pmc_kernel/summary.json gpurun_out/r02_encgemm_lds_split4_64x256.json
-python3 tools/pmc_kernel.py "enc_gemm_split_direct_kernel" "$G" -- --graphs 64 --nodes 128 > gpurun_out/r2_pmc_enc_c.log 2>&1
-cp gpurun_out/pmc_kernel/summary.json gpurun_out/r02_encgemm_direct_64x128.json
+python3 tools/pmc_kernel.py "enc_gemm_split_lds_kernel<false" "$G" -- --graphs 64 --nodes 128 > gpurun_out/r2_pmc_enc_c.log 2>&1
+cp gpurun_out/pmc_kernel/summary.json gpurun_out/r02_encgemm_lds_split8_64x128.json
 python3 tools/pmc_kernel.py "enc_tail_mfma_kernel" "$G" -- --graphs 64 --nodes 128 > gpurun_out/r2_pmc_enc_d.log 2>&1
 cp gpurun_out/pmc_kernel/summary.json gpurun_out/r02_enctail_mfma_64x128.json
 rm -rf gpurun_out/pmc_kernel
