@@ -444,19 +444,27 @@ __global__ __launch_bounds__(512) void enc_gemm_split_lds_kernel(const float* __
             __bf16* b = sb + (size_t)stage * 3 * RB * BK;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                bf16x4 p0, p1, p2;
+                // the same three roundings as store_stage, two elements at a time: v_cvt_pk_bf16_f32 rounds a pair, the pair's
+                // float images are one shift and one mask of that word, the remainders one packed subtract (exact: a value minus
+                // its own 8-bit rounding fits fp32) -- 9 VALU per pair instead of 13
+                typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+                unsigned w[3][2];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float v = src[u][q];
-                    const __bf16 h0 = (__bf16)v;
-                    const float r1 = v - (float)h0;
-                    const __bf16 h1 = (__bf16)r1;
-                    const float r2 = r1 - (float)h1;
-                    p0[q] = h0, p1[q] = h1, p2[q] = (__bf16)r2;
+                for (int pr = 0; pr < 2; ++pr) {
+                    f32x2 v = {src[u][2 * pr], src[u][2 * pr + 1]};
+#pragma unroll
+                    for (int lev = 0; lev < 3; ++lev) {
+                        const unsigned word = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+                        w[lev][pr] = word;
+                        if (lev < 2)
+                            v = __builtin_elementwise_fma(f32x2{-1.f, -1.f},
+                                                          f32x2{__uint_as_float(word << 16), __uint_as_float(word & 0xffff0000u)}, v);
+                    }
                 }
-                *reinterpret_cast<bf16x4*>(a + xdst[u]) = p0;
-                *reinterpret_cast<bf16x4*>(a + RA * BK + xdst[u]) = p1;
-                *reinterpret_cast<bf16x4*>(a + 2 * RA * BK + xdst[u]) = p2;
+                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                *reinterpret_cast<u32x2*>(a + xdst[u]) = u32x2{w[0][0], w[0][1]};
+                *reinterpret_cast<u32x2*>(a + RA * BK + xdst[u]) = u32x2{w[1][0], w[1][1]};
+                *reinterpret_cast<u32x2*>(a + 2 * RA * BK + xdst[u]) = u32x2{w[2][0], w[2][1]};
             }
 #pragma unroll
             for (int u = 0; u < 3; ++u) *reinterpret_cast<bf16x8*>(b + wdst[u]) = wreg[u];
