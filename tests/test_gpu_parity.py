@@ -594,3 +594,38 @@ def test_submodules_called_on_their_own(name):
         m.encoder.node_mlp(d.x.cpu())
     with pytest.raises(RuntimeError):                            # wrong dtype raises like the reference's Linear
         m.encoder.node_mlp(d.x.double())
+
+
+@pytest.mark.parametrize("node_in,n_nodes", [(512, 8192 + 7), (512, 20000), (96, 7000), (64, 6144)])
+def test_pipelined_gemm_short_k(node_in, n_nodes):
+    """Narrow node features on a batch (arch 'bdnet_market' has node_in 512): the pipelined 256-row GEMM then runs very few 32-deep
+    chunks per workgroup (K / split-K / 32 = 8 ... 1) -- its prologue, its single-chunk tail and the clamped duplicate loads."""
+    from gnn_cca_amd import MOTMPNet
+    params, arch, _ = _default_model(1.0)
+    params = copy.deepcopy(params)
+    params["encoder_feats_dict"]["nodes"][arch]["node_in_dim"] = node_in
+    torch.manual_seed(node_in + n_nodes)
+    ref_m = MOTMPNet(copy.deepcopy(params), None, arch)
+    sd = {k: v.detach().clone().numpy() for k, v in ref_m.state_dict().items()}
+    rng = np.random.default_rng(n_nodes)
+    x = rng.standard_normal((n_nodes, node_in)).astype(np.float32)
+    src = np.repeat(np.arange(n_nodes), 2)
+    dst = (src + np.tile([1, 5], n_nodes)) % n_nodes
+    ei = np.stack([src, dst]).astype(np.int64)
+    ea = rng.random((ei.shape[1], 4)).astype(np.float32)
+    orc = NumpyOracle(params, arch, sd, np.float32)
+    tr = {}
+    ref = orc.forward(x, ei, ea, tr)
+    m = build(params, arch, sd)
+    d = Data(torch.from_numpy(x).cuda(), torch.from_numpy(ei).cuda(), torch.from_numpy(ea).cuda())
+    trace = {}
+    with torch.no_grad():
+        out = [t.clone() for t in m(d)["classified_edges"]]
+        m(d, trace=trace)
+    h64 = NumpyOracle(params, arch, sd, np.float64)._mlp("encoder.node_mlp", x.astype(np.float64))
+    err_gpu = np.abs(trace["h_enc"].cpu().numpy() - h64).max()
+    err_ref = np.abs(tr["h_enc"] - h64).max()
+    assert err_gpu <= max(4 * err_ref, 2e-7 * max(1.0, float(np.abs(h64).max()))), (err_gpu, err_ref)
+    for o, r in zip(out, ref):
+        scale = max(1.0, float(np.abs(r).max()))
+        assert np.abs(o.cpu().numpy() - r).max() <= TOL_TIGHT * 2 * scale
