@@ -68,17 +68,6 @@ __global__ __launch_bounds__(256) GNNCCA_FAST_ATTR void mpn_step_fast_kernel(con
 #pragma unroll
         for (int i = 0; i < 8; ++i) stage_pd[i] = g4[min(tid + i * 256, pd_n4 - 1)];
     }
-    if (MSG) {
-        f32x4* l4 = reinterpret_cast<f32x4*>(s_proj);
-        l4[tid] = stage_proj[0];
-        if (tid + 256 < kH * kProjOut / 4) l4[tid + 256] = stage_proj[1];
-    }
-    if (PD_LDS) {
-        f32x4* l4 = reinterpret_cast<f32x4*>(s_pd);
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-            if (tid + i * 256 < pd_n4) l4[tid + i * 256] = stage_pd[i];
-    }
     if (gflags & GNNCCA_GRAPH_BAD_INDEX) {
         if (CLS)
             for (size_t k = (size_t)blockIdx.x * 256 + tid; k < (size_t)p.E; k += (size_t)gridDim.x * 256)
@@ -86,9 +75,6 @@ __global__ __launch_bounds__(256) GNNCCA_FAST_ATTR void mpn_step_fast_kernel(con
         return;
     }
     const bool unsorted = (gflags & GNNCCA_GRAPH_UNSORTED) != 0;
-    GNNCCA_STAMP(p.stamp_slot, 1);
-    if (MSG || PD_LDS) __syncthreads();
-    GNNCCA_STAMP(p.stamp_slot, 2);
     if (!active) seg_s = seg_t = 0;
     // Edge-state slot of sorted edge kk: kk + eoff.  Padded layout (big, nearly regular batches): the node's segment starts at
     // node * ell_S, a multiple of 128 B in every feature plane, so no line of the state is shared by two segments (with the
@@ -96,7 +82,7 @@ __global__ __launch_bounds__(256) GNNCCA_FAST_ATTR void mpn_step_fast_kernel(con
     // more bytes than the algorithm needs).  The plan has checked every degree against ell_S; if one did not fit
     // (GNNCCA_GRAPH_IRREGULAR) or the rows were not sorted, every step of this forward uses the compact order.
     const long long eoff = (p.ell_S > 0 && !(gflags & (GNNCCA_GRAPH_UNSORTED | GNNCCA_GRAPH_IRREGULAR)))
-                               ? (long long)node * p.ell_S - seg_s : 0ll;
+                               ? (long long)nclamp * p.ell_S - seg_s : 0ll;   // (inactive waves: slot 0, loads only)
 
     // Cache policy of the streams (template NT: 0 none, 1 stores + edge_attr, 2 + loads of e; chosen by the host from the size of the
     // edge state; a RUN-TIME flag does not work: the compiler merges the two arms of the branch into one plain access): while the
@@ -117,12 +103,12 @@ __global__ __launch_bounds__(256) GNNCCA_FAST_ATTR void mpn_step_fast_kernel(con
     };
     // phase A: everything addressed by the edge slot itself (target id, permutation, edge state)
     auto load_index = [&](int base, Chunk& c) {
-        const int kk = min(base + lane, last);
+        const int kk = max(min(base + lane, last), 0);   // (an empty segment: slot 0, never used)
         c.ko = unsorted ? p.perm[kk] : kk;
         c.j = p.col32[kk];
     };
     auto load_state = [&](int base, Chunk& c) {
-        const int kk = min(base + lane, last);
+        const int kk = max(min(base + lane, last), 0);
         if (FIRST) {
             const f32x4* __restrict__ ap = reinterpret_cast<const f32x4*>(p.edge_attr + (size_t)c.ko * 4);
             const f32x4 a = nt_store ? __builtin_nontemporal_load(ap) : *ap;   // read once per forward
@@ -274,20 +260,47 @@ __global__ __launch_bounds__(256) GNNCCA_FAST_ATTR void mpn_step_fast_kernel(con
     // (addresses are clamped to the segment) so that they stay in one basic block and the compiler can wait for
     // them chunk by chunk: they return in order, chunk 0 is computed while chunk 1 is still in flight.
     // (Four chunks per round were measured too: +5 % on 64 x dense256, -5 % on 512 x dense128, 143 VGPRs; not kept.)
+    // The FIRST round's target ids and edge state are requested BEFORE the LDS staging stores and the workgroup barrier (they
+    // need the CSR offsets only): their round trip runs under the staging wait and the barrier instead of after them.
     const int stride = 64 * wps;
-    for (int base = seg_s + 64 * sub; base < seg_t; base += 2 * stride) {
-        Chunk c0, c1;
-        const bool two = base + stride < seg_t;
+    int base = seg_s + 64 * sub;
+    Chunk c0, c1;
+    load_index(base, c0);
+    load_index(base + stride, c1);
+    load_state(base, c0);
+    load_state(base + stride, c1);
+    if (MSG) {
+        f32x4* l4 = reinterpret_cast<f32x4*>(s_proj);
+        l4[tid] = stage_proj[0];
+        if (tid + 256 < kH * kProjOut / 4) l4[tid + 256] = stage_proj[1];
+    }
+    if (PD_LDS) {
+        f32x4* l4 = reinterpret_cast<f32x4*>(s_pd);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (tid + i * 256 < pd_n4) l4[tid + i * 256] = stage_pd[i];
+    }
+    GNNCCA_STAMP(p.stamp_slot, 1);
+    if (MSG || PD_LDS) __syncthreads();
+    GNNCCA_STAMP(p.stamp_slot, 2);
+    auto round_body = [&](int rb) {
+        load_target(c0);
+        load_target(c1);
+        GNNCCA_STAMP(p.stamp_slot, 3);
+        compute_chunk(rb, c0);
+        if (rb + stride < seg_t) compute_chunk(rb + stride, c1);
+        GNNCCA_STAMP(p.stamp_slot, 4);
+    };
+    if (base < seg_t) {
+        round_body(base);
+        base += 2 * stride;
+    }
+    for (; base < seg_t; base += 2 * stride) {
         load_index(base, c0);
         load_index(base + stride, c1);
         load_state(base, c0);
         load_state(base + stride, c1);
-        load_target(c0);
-        load_target(c1);
-        GNNCCA_STAMP(p.stamp_slot, 3);
-        compute_chunk(base, c0);
-        if (two) compute_chunk(base + stride, c1);
-        GNNCCA_STAMP(p.stamp_slot, 4);
+        round_body(base);
     }
     GNNCCA_STAMP(p.stamp_slot, 5);
 
