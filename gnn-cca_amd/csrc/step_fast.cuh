@@ -283,24 +283,42 @@ __global__ __launch_bounds__(256) GNNCCA_FAST_ATTR void mpn_step_fast_kernel(con
     GNNCCA_STAMP(p.stamp_slot, 1);
     if (MSG || PD_LDS) __syncthreads();
     GNNCCA_STAMP(p.stamp_slot, 2);
-    auto round_body = [&](int rb) {
-        load_target(c0);
-        load_target(c1);
+    auto round_body = [&](int rb, Chunk& a, Chunk& b) {
+        load_target(a);
+        load_target(b);
         GNNCCA_STAMP(p.stamp_slot, 3);
-        compute_chunk(rb, c0);
-        if (rb + stride < seg_t) compute_chunk(rb + stride, c1);
+        compute_chunk(rb, a);
+        if (rb + stride < seg_t) compute_chunk(rb + stride, b);
         GNNCCA_STAMP(p.stamp_slot, 4);
     };
     if (base < seg_t) {
-        round_body(base);
-        base += 2 * stride;
+        // the SECOND round's target ids (2 registers) are requested before the first round is computed: when that round comes,
+        // its edge state and its P_dst gather go out together -- one round trip instead of two (a 255-edge segment owned by one
+        // wave has exactly two rounds)
+        const int base2 = base + 2 * stride;
+        Chunk d0, d1;
+        if (!PD_LDS) {
+            load_index(base2, d0);
+            load_index(base2 + stride, d1);
+        }
+        round_body(base, c0, c1);
+        if (base2 < seg_t) {
+            if (PD_LDS) {
+                load_index(base2, d0);
+                load_index(base2 + stride, d1);
+            }
+            load_state(base2, d0);
+            load_state(base2 + stride, d1);
+            round_body(base2, d0, d1);
+        }
+        base += 4 * stride;
     }
     for (; base < seg_t; base += 2 * stride) {
         load_index(base, c0);
         load_index(base + stride, c1);
         load_state(base, c0);
         load_state(base + stride, c1);
-        round_body(base);
+        round_body(base, c0, c1);
     }
     GNNCCA_STAMP(p.stamp_slot, 5);
 
