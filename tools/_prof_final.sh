@@ -1,5 +1,3 @@
-# GPU box: profiles of the FINAL round-2 build (the encoder GEMM changed late in the round): the three batch workloads it affects and
-# the headline with the driver's own command line; summaries under gpurun_out/r02f_*
 set -x
 python3 tools/collect_profiles.py r02f_dense256 -- --steps 20 --warmup 5
 python3 tools/collect_profiles.py r02f_64x256 -- --graphs 64 --nodes 256 --steps 40 --warmup 5 --mode eager
