@@ -10,6 +10,11 @@ namespace gnncca {
 
 extern thread_local int g_last_hip_error;  // hipError_t of the last failed HIP call on this thread
 
+// Diagnostic switches (the A/B experiments of DESIGN.md 5; listed in DESIGN.md 11).  They change kernel SELECTION, hence
+// summation order, so the shipped library ignores every one of them unless GNNCCA_DIAG=1 is set in the same environment:
+// a stray variable in one rank's environment cannot silently change its numerics.
+const char* diag_env(const char* name);
+
 constexpr uint32_t kBlobMagic = 0x4D504E33u;  // "MPN3": bumped with every change of the blob layout (a blob is only
                                               // valid for the library build that packed it; load_packed_blob checks)
 constexpr int kH = 32;        // node latent width the MFMA step kernel is built for (node_out_dim)

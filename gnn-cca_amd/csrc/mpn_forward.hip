@@ -22,8 +22,10 @@
 #include "wave_reduce.cuh"
 #include "plan.cuh"
 #include "encoder.cuh"
+#include "msg_bf16.cuh"
 #include "step_general.cuh"
 #include "step_fast.cuh"
+#include "step_pipe.cuh"
 #include "generic.cuh"
 #include "postprocess.cuh"
 #include "backward.cuh"
@@ -153,9 +155,9 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
         int ks_split = 1;
         if (split) {  // big batches: split-bf16 MFMA GEMM; the plan gets its own launch
             const unsigned short* w3 = reinterpret_cast<const unsigned short*>(blob + hdr.enc_w3);
-            static const bool force_direct = std::getenv("GNNCCA_GEMM_DIRECT") != nullptr;  // diagnostics: A/B the GEMMs
-            static const bool no_fuse = std::getenv("GNNCCA_NO_FUSE") != nullptr;             // A/B against GEMM + tail launch
-            static const int lds_min = std::getenv("GNNCCA_GEMM_LDS_MIN") ? std::atoi(std::getenv("GNNCCA_GEMM_LDS_MIN")) : 6144;
+            static const bool force_direct = diag_env("GNNCCA_GEMM_DIRECT") != nullptr;  // diagnostics: A/B the GEMMs
+            static const bool no_fuse = diag_env("GNNCCA_NO_FUSE") != nullptr;             // A/B against GEMM + tail launch
+            static const int lds_min = diag_env("GNNCCA_GEMM_LDS_MIN") ? std::atoi(diag_env("GNNCCA_GEMM_LDS_MIN")) : 6144;
             const bool fusable = !no_fuse && !dropping && nl == 2 && d->enc_node.layers[1].in_dim == 128 && d->enc_node.layers[1].out_dim == kH &&
                                  !d->reattach_nodes && hdr.proj_wT != 0;
             const bool use_lds = N >= lds_min && O == 128 && !force_direct;
@@ -213,7 +215,7 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
                 // 256-row workgroups, both operands through LDS (144 KB: one workgroup per CU, 8 waves); split-K by whole
                 // rounds of 256 workgroups (internal.h: enc_lds_ksplit)
                 const dim3 fgrid((N + 255) / 256 + 1, 1), sgrid((N + 255) / 256, ks_split);
-                static const bool gemm_pipe = std::getenv("GNNCCA_GEMM_NOPIPE") == nullptr;   // diagnostics: A/B against the barrier-per-chunk form (encoder.cuh: PIPE)
+                static const bool gemm_pipe = diag_env("GNNCCA_GEMM_NOPIPE") == nullptr;   // diagnostics: A/B against the barrier-per-chunk form (encoder.cuh: PIPE)
                 if (gemm_pipe && fused_tail && split3)
                     GNNCCA_LAUNCH((enc_gemm_split_lds_kernel<true, true, true>), fgrid, dim3(512), kLdsGemmBytes, st, cur_in, w3, part, N, K, O, K, fp);
                 else if (gemm_pipe && fused_tail)
@@ -307,8 +309,8 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
         const bool tail_fast = !dropping && N < 4096 && tp.F == 128 && tp.has_last && !tp.reatt_n && tp.trace_h == nullptr && tp.vec_reduce &&
                                (reinterpret_cast<uintptr_t>(part) & 15) == 0;
         // batches whose GEMM ran split-K: the tail on the matrix pipe, 32 nodes per workgroup
-        static const bool no_mfma_tail = std::getenv("GNNCCA_NO_MFMA_TAIL") != nullptr;  // diagnostics: A/B the two tails
-        static const int kTailMfmaMin = std::getenv("GNNCCA_TAIL_MFMA_MIN") ? std::atoi(std::getenv("GNNCCA_TAIL_MFMA_MIN")) : 6144;
+        static const bool no_mfma_tail = diag_env("GNNCCA_NO_MFMA_TAIL") != nullptr;  // diagnostics: A/B the two tails
+        static const int kTailMfmaMin = diag_env("GNNCCA_TAIL_MFMA_MIN") ? std::atoi(diag_env("GNNCCA_TAIL_MFMA_MIN")) : 6144;
         const bool tail_mfma = !dropping && !fused_tail && !no_mfma_tail && N >= kTailMfmaMin && tp.F == 128 && tp.has_last && nl == 2 && !tp.reatt_n &&
                                (reinterpret_cast<uintptr_t>(part) & 15) == 0;
         if (fused_tail) {
@@ -367,7 +369,7 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
         const long long want = 4096 / (long long)N;  // waves per node that would fill the chip
         int wps = chunks >= 4 ? 4 : (chunks >= 2 ? 2 : 1);
         while (wps > 1 && wps > want) wps >>= 1;
-        static const int force_wps = std::getenv("GNNCCA_WPS") ? std::atoi(std::getenv("GNNCCA_WPS")) : 0;  // diagnostics
+        static const int force_wps = diag_env("GNNCCA_WPS") ? std::atoi(diag_env("GNNCCA_WPS")) : 0;  // diagnostics
         if (force_wps == 1 || force_wps == 2 || force_wps == 4) wps = std::min(force_wps, chunks >= 4 ? 4 : (chunks >= 2 ? 2 : 1));
         sp.wps = wps;
     }
@@ -377,7 +379,7 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
     sp.ell_S = use_ell ? ws.ell_S : 0;
     sp.drop = drop;
     {
-        static const bool no_nt = std::getenv("GNNCCA_NO_NT") != nullptr;  // diagnostics: A/B the cache policy
+        static const bool no_nt = diag_env("GNNCCA_NO_NT") != nullptr;  // diagnostics: A/B the cache policy
         const double state_bytes = (double)(sp.e_bf16 ? kEF / 2 : kEF) * (double)ws.e_stride * 4.0;
         sp.nt_store = !no_nt && state_bytes > 150e6;
         sp.nt_load = !no_nt && state_bytes > 256e6;
@@ -414,7 +416,12 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
         sp.trace_h = want_h ? trace->h_steps + (size_t)(step - 1) * N * kH : nullptr;
         hipError_t err;
         const bool fast = hdr.fast_consts != 0 && sp.attr_vec && !trace && d->agg != GNNCCA_AGG_MAX;
-        if (fast)
+        static const bool step_nomem = diag_env("GNNCCA_STEP_NOMEM") != nullptr;   // diagnostics: arithmetic-only timing of the step kernel
+        sp.diag = step_nomem ? 1 : 0;
+        static const bool step_r2 = diag_env("GNNCCA_STEP_R2") != nullptr;   // diagnostics: A/B against round 2's step kernel
+        if (fast && !step_r2 && step_pipe_fits(N, E, ws.e_stride))
+            err = launch_pipe_dispatch(sp, msg, st);
+        else if (fast)
             err = launch_fast_dispatch(sp, msg, st);
         else if (re)
             err = msg ? launch_step<true, true>(sp, st) : launch_step<true, false>(sp, st);

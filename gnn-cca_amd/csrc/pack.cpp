@@ -548,8 +548,16 @@ GenWorkspace carve_generic(const gnncca_mpn_dims* d, int64_t n, int64_t e) {
     return w;
 }
 
+const char* diag_env(const char* name) {
+    static const bool on = [] {
+        const char* v = std::getenv("GNNCCA_DIAG");
+        return v != nullptr && v[0] == '1' && v[1] == '\0';
+    }();
+    return on ? std::getenv(name) : nullptr;
+}
+
 int ell_stride(const gnncca_mpn_dims* d, int64_t n, int64_t e) {
-    static const bool disabled = std::getenv("GNNCCA_NO_PAD") != nullptr;  // diagnostics: A/B against the compact layout
+    static const bool disabled = diag_env("GNNCCA_NO_PAD") != nullptr;  // diagnostics: A/B against the compact layout
     if (disabled) return 0;
     if (!fast_consts_ok(d) || d->agg == GNNCCA_AGG_MAX || d->num_enc_steps < 1 || n <= 0) return 0;
     if (e < (1 << 19)) return 0;                           // small graphs are cache-resident and latency-bound: nothing to gain

@@ -241,7 +241,7 @@ __global__ __launch_bounds__(256) GNNCCA_FAST_ATTR void mpn_step_fast_kernel(con
             }
             if (base + 64 <= seg_t) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) acc[i] += relu_bits(d0[i]) + relu_bits(d1[i]);
+                for (int i = 0; i < 16; ++i) acc[i] = (acc[i] + relu_bits(d0[i])) + relu_bits(d1[i]);
             } else {
                 const int rem = seg_t - base - 4 * half;
 #pragma unroll
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(256) GNNCCA_FAST_ATTR void mpn_step_fast_kernel(con
                     const int eo = (i & 3) + 8 * (i >> 2);
                     const float m0 = (eo < rem) ? relu_bits(d0[i]) : 0.f;
                     const float m1 = (eo + 32 < rem) ? relu_bits(d1[i]) : 0.f;
-                    acc[i] += m0 + m1;
+                    acc[i] = (acc[i] + m0) + m1;
                 }
             }
         }

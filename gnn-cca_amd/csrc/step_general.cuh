@@ -49,6 +49,8 @@ struct StepParams {
     int nt_store, nt_load;   // non-temporal policy of the specialised step kernel's streams (see step_fast.cuh)
     DropCfg drop;            // train-mode Dropout (general kernel only); all p == 0 in eval
     int step_no, cls_no;     // 1-based step, 0-based index of this classified step: the dropout streams
+    int diag;                // GNNCCA_DIAG experiments (0 in production): bit 0 = timing-only run of mpn_step_pipe_kernel with
+                             // zero-record stream descriptors (no HBM traffic: what the arithmetic alone costs)
 };
 
 template <bool REATT_E, bool MSG, bool AGG_MAX>
@@ -75,6 +77,7 @@ __global__ __launch_bounds__(256) void mpn_step_kernel(const StepParams p) {
     float psrc[kEF];
     float cinit = 0.f;
     float bw[3] = {0.f, 0.f, 0.f};
+    MsgB mb;   // 'sum' / 'mean': the message on the bf16 matrix pipe in split form (msg_bf16.cuh), the arithmetic of the fast kernel
     {
         const float* __restrict__ psq = p.psq_in + (size_t)nclamp * kPsQStride;
 #pragma unroll
@@ -83,6 +86,10 @@ __global__ __launch_bounds__(256) void mpn_step_kernel(const StepParams p) {
             cinit = psq[8 + ch];
 #pragma unroll
             for (int s = 0; s < 3; ++s) bw[s] = blob[p.off_wneb + s * 64 + lane];
+            if (!AGG_MAX) {
+                msg_b_weights(blob + p.off_wneb, lane, mb);
+                msg_b_bias(cinit, lane, mb);
+            }
         }
     }
     if (MSG) {
@@ -222,15 +229,22 @@ __global__ __launch_bounds__(256) void mpn_step_kernel(const StepParams p) {
         if (MSG) {
             // node message: ReLU(W_n . cat(x[row], e') + b_n)   (models/mpn.py:97-98), 64 edges x 32 channels
             f32x16 d0, d1;
+            if (!AGG_MAX) {
+                MsgA oa;
+                msg_a_operands(en, base, seg_t, lane, oa);
+                d0 = msg_tile(oa, mb, 0);
+                d1 = msg_tile(oa, mb, 1);
+            } else {   // 'max': an ordered fp32 FMA chain, which the backward's arg-max pass recomputes bit for bit (backward.cuh)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) d0[i] = d1[i] = cinit;
+                for (int i = 0; i < 16; ++i) d0[i] = d1[i] = cinit;
 #pragma unroll
-            for (int s = 0; s < 3; ++s) {
-                // lanes = edges.  After the swap: r[0] = A operand of tile 0 (edges 0..31), r[1] = of tile 1.
-                const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(en[2 * s]), __float_as_uint(en[2 * s + 1]),
-                                                                false, false);
-                d0 = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(r[0]), bw[s], d0, 0, 0, 0);
-                d1 = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(r[1]), bw[s], d1, 0, 0, 0);
+                for (int s = 0; s < 3; ++s) {
+                    // lanes = edges.  After the swap: r[0] = A operand of tile 0 (edges 0..31), r[1] = of tile 1.
+                    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(en[2 * s]), __float_as_uint(en[2 * s + 1]),
+                                                                    false, false);
+                    d0 = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(r[0]), bw[s], d0, 0, 0, 0);
+                    d1 = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(r[1]), bw[s], d1, 0, 0, 0);
+                }
             }
             // accumulator register i of lane (ch, half) is edge (i&3) + 8*(i>>2) + 4*half of the tile
             if (p.drop.p_node > 0.f) {
@@ -246,13 +260,13 @@ __global__ __launch_bounds__(256) void mpn_step_kernel(const StepParams p) {
                     float m1 = fmaxf(d1[i], 0.f) * drop_scale(seed, kDropNodeStep + p.step_no, (unsigned long long)ko1 * kH + ch, p.drop.p_node);
                     if (eo >= rem) m0 = ident;
                     if (eo + 32 >= rem) m1 = ident;
-                    acc[i] = agg_max ? fmaxf(acc[i], fmaxf(m0, m1)) : acc[i] + (m0 + m1);
+                    acc[i] = agg_max ? fmaxf(acc[i], fmaxf(m0, m1)) : (acc[i] + m0) + m1;
                 }
             } else if (base + 64 <= seg_t) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const float m0 = fmaxf(d0[i], 0.f), m1 = fmaxf(d1[i], 0.f);
-                    acc[i] = agg_max ? fmaxf(acc[i], fmaxf(m0, m1)) : acc[i] + (m0 + m1);
+                    acc[i] = agg_max ? fmaxf(acc[i], fmaxf(m0, m1)) : (acc[i] + m0) + m1;
                 }
             } else {
                 const int rem = seg_t - base - 4 * half;
@@ -262,7 +276,7 @@ __global__ __launch_bounds__(256) void mpn_step_kernel(const StepParams p) {
                     const int eo = (i & 3) + 8 * (i >> 2);
                     const float m0 = (eo < rem) ? fmaxf(d0[i], 0.f) : ident;
                     const float m1 = (eo + 32 < rem) ? fmaxf(d1[i], 0.f) : ident;
-                    acc[i] = agg_max ? fmaxf(acc[i], fmaxf(m0, m1)) : acc[i] + (m0 + m1);
+                    acc[i] = agg_max ? fmaxf(acc[i], fmaxf(m0, m1)) : (acc[i] + m0) + m1;
                 }
             }
         }

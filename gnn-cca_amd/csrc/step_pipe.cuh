@@ -1,0 +1,261 @@
+#pragma once
+// Part of the single translation unit mpn_forward.hip (kernels share device helpers and the launch code below
+// instantiates their templates); see that file for the overall picture.
+namespace gnncca {
+
+// ------------------------------------------------------------------------------------------------------------
+// Step kernel of the shipped GRAPH_NET_PARAMS shape, round 3: the algorithm of mpn_step_kernel (step_general.cuh) with
+//   * the node message on the bf16 matrix pipe in split form (msg_bf16.cuh) -- the f32-input MFMAs of rounds 1-2 turned
+//     out to serialise with the VALU of the whole SIMD and were 40 % of the kernel's issue time;
+//   * all streams through BUFFER instructions (raw buffer resource + 32-bit offsets): a lane beyond the segment gets
+//     the out-of-range offset 2^31 -- its loads return 0 and its stores are dropped by the address unit: no exec mask,
+//     no branch inside a round, and the feature-plane offset rides in an SGPR (no 64-bit VALU address arithmetic:
+//     -25 VALU per chunk); the tail mask of the aggregation rides in a k-slot of the MFMA (msg_bf16.cuh);
+//   * the body of a ROUND (two 64-edge chunks of a wave) as ONE basic block whose program order alternates one MFMA with
+//     6-10 VALU instructions of another dependency chain (edge update / classifier of the other chunk, ReLU +
+//     accumulate of a finished tile); three accumulator tiles rotate.  __builtin_amdgcn_sched_barrier keeps hipcc from
+//     regrouping; the empty asm statements in `ra` pin pure arithmetic that instruction selection would otherwise sink.
+// Work split, LDS tables, prefetch of the first two rounds, cross-wave combine, projection epilogue and cache policies
+// are mpn_step_fast_kernel's of round 2 (step_fast.cuh, kept as the A/B reference behind GNNCCA_DIAG).
+// ------------------------------------------------------------------------------------------------------------
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned kOobOffset = 0x80000000u;   // >= every buffer's num_records (all <= 2^31, checked on the host)
+
+__device__ __forceinline__ rsrc_t make_rsrc(const void* base, unsigned long long bytes) {
+    // raw buffer (stride 0), 32-bit data format word of gfx9 (0x00020000), range-checked against `bytes`
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)(unsigned)bytes, 0x00020000);
+}
+template <int AUX>
+__device__ __forceinline__ float buf_load_f32(rsrc_t r, unsigned voff, unsigned soff) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, AUX));
+}
+
+// host-side eligibility: every buffer this kernel addresses with 32-bit offsets stays below 2^31 bytes
+static inline bool step_pipe_fits(long long N, long long E, long long e_stride) {
+    const long long lim = 1ll << 31;
+    return 6 * e_stride * 4 <= lim && E * 16 <= lim && N * 32 <= lim;
+}
+
+#define GNNCCA_SB() __builtin_amdgcn_sched_barrier(0)
+
+template <bool FIRST, bool CLS, bool MSG, bool PD_LDS, bool EBF16, int NT>
+__global__ __launch_bounds__(256) GNNCCA_FAST_ATTR void mpn_step_pipe_kernel(const StepParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* s_proj = smem;                                   // [32][48]   (MSG)
+    float* s_part = s_proj + (MSG ? kH * kProjOut : 0);     // [4][32]
+    float* s_pd = s_part + 4 * kH;                          // [N][8]     (PD_LDS)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const float* __restrict__ blob = p.blob;
+    typedef const float __attribute__((address_space(4))) cfloat;
+    cfloat* cw = (cfloat*)(unsigned long long)(blob + p.off_fast);
+    constexpr int AUX_ST = NT >= 1 ? 2 : 0;    // nt: streams written / read once (see mpn_step_fast_kernel on the policy)
+    constexpr int AUX_LD = NT >= 2 ? 2 : 0;
+
+    GNNCCA_STAMP(p.stamp_slot, 0);
+    // ---- prologue: every independent load is issued before the first wait ----------------------------------
+    const unsigned gflags = p.flags[0];
+    const int wps = p.wps;
+    const int node = blockIdx.x * (4 / wps) + wave / wps;
+    const int sub = wave % wps;
+    const bool active = node < p.N;
+    const int nclamp = active ? node : 0;
+    int seg_s = p.seg_ptr[nclamp];
+    int seg_t = p.seg_ptr[nclamp + 1];
+    const int half = lane >> 5, ch = lane & 31;
+    const float* __restrict__ psq = p.psq_in + (size_t)nclamp * kPsQStride;
+    float psrc[kEF];
+#pragma unroll
+    for (int f = 0; f < kEF; ++f) psrc[f] = psq[f];
+    MsgB mb;                // B operands of the message MFMAs (msg_bf16.cuh)
+    float cinit = 0.f;
+    f32x4 stage_proj[2];
+    f32x4 stage_pd[8];
+    float projb_l = 0.f;
+    if (MSG) {
+        cinit = psq[8 + ch];
+        projb_l = blob[p.off_projb + min(lane, kProjOut - 1)];
+        msg_b_weights(blob + p.off_wneb, lane, mb);
+        const f32x4* __restrict__ g4 = reinterpret_cast<const f32x4*>(blob + p.off_projwT);
+        stage_proj[0] = g4[tid];                                   // 384 float4 in all
+        stage_proj[1] = g4[min(tid + 256, kH * kProjOut / 4 - 1)];
+    }
+    const int pd_n4 = p.N * (kPdStride / 4);
+    if (PD_LDS) {  // N <= 1024: at most 8 float4 per thread
+        const f32x4* __restrict__ g4 = reinterpret_cast<const f32x4*>(p.pd_in);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) stage_pd[i] = g4[min(tid + i * 256, pd_n4 - 1)];
+    }
+    if (gflags & GNNCCA_GRAPH_BAD_INDEX) {
+        if (CLS)
+            for (size_t k = (size_t)blockIdx.x * 256 + tid; k < (size_t)p.E; k += (size_t)gridDim.x * 256)
+                p.logits[k] = __builtin_nanf("");
+        return;
+    }
+    const bool unsorted = (gflags & GNNCCA_GRAPH_UNSORTED) != 0;
+    if (!active) seg_s = seg_t = 0;
+    if (MSG) msg_b_bias(cinit, lane, mb);
+    // padded layout: see mpn_step_fast_kernel
+    const int eoff = (p.ell_S > 0 && !(gflags & (GNNCCA_GRAPH_UNSORTED | GNNCCA_GRAPH_IRREGULAR))) ? nclamp * p.ell_S - seg_s : 0;
+    const unsigned plane_b = (unsigned)p.e_stride * 4u;                       // bytes between two feature planes
+    const unsigned long long live = (p.diag & 1) ? 0ull : 1ull;               // timing-only diagnostic: every stream descriptor empty
+    const rsrc_t r_e = make_rsrc(p.e, live * (EBF16 ? 3 : 6) * plane_b);
+    const rsrc_t r_col = make_rsrc(p.col32, live * (unsigned long long)p.E * 4);
+    const rsrc_t r_perm = make_rsrc(p.perm, unsorted ? (unsigned long long)p.E * 4 : 0ull);   // sorted: every load returns 0, no traffic
+    const rsrc_t r_attr = make_rsrc(p.edge_attr, live * (unsigned long long)p.E * 16);
+    const rsrc_t r_pd = make_rsrc(p.pd_in, (unsigned long long)p.N * (kPdStride * 4));
+    const rsrc_t r_log = make_rsrc(p.logits, CLS ? live * (unsigned long long)p.E * 4 : 0ull);
+    // the last step stores no edge state: a resource with 0 records drops every store (no branch inside the round)
+    const rsrc_t r_est = make_rsrc(p.e, p.store_e ? live * (EBF16 ? 3 : 6) * plane_b : 0ull);
+
+    f32x16 acc;  // 'sum' / 'mean' only: 'max' takes the general kernel
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+
+#include "step_pieces.inc"
+    const int stride = 64 * wps;
+    int base = seg_s + 64 * sub;
+    Chunk c0, c1;
+    load_index(base, c0);
+    load_index(base + stride, c1);
+    load_state(c0);
+    load_state(c1);
+    if (MSG) {
+        f32x4* l4 = reinterpret_cast<f32x4*>(s_proj);
+        l4[tid] = stage_proj[0];
+        if (tid + 256 < kH * kProjOut / 4) l4[tid + 256] = stage_proj[1];
+    }
+    if (PD_LDS) {
+        f32x4* l4 = reinterpret_cast<f32x4*>(s_pd);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (tid + i * 256 < pd_n4) l4[tid + i * 256] = stage_pd[i];
+    }
+    GNNCCA_STAMP(p.stamp_slot, 1);
+    if (MSG || PD_LDS) __syncthreads();
+    GNNCCA_STAMP(p.stamp_slot, 2);
+    auto round_body = [&](int rb, Chunk& a, Chunk& b, int sid, int sland, int sdone) {
+        load_target(a);
+        load_target(b);
+        GNNCCA_STAMP(p.stamp_slot, sid);
+#ifdef GNNCCA_STAMPS   // diagnostic build: when did the round's operands arrive?
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        GNNCCA_STAMP(p.stamp_slot, sland);
+#endif
+        if (rb + stride < seg_t)
+            compute2(rb, a, rb + stride, b);
+        else
+            compute1(rb, a);
+        GNNCCA_STAMP(p.stamp_slot, sdone);
+    };
+    if (base < seg_t) {
+        // the SECOND round's target ids are requested before the first round is computed (see mpn_step_fast_kernel)
+        const int base2 = base + 2 * stride;
+        Chunk n0, n1;
+        if (!PD_LDS) {
+            load_index(base2, n0);
+            load_index(base2 + stride, n1);
+        }
+        round_body(base, c0, c1, 3, 15, 4);
+        if (base2 < seg_t) {
+            if (PD_LDS) {
+                load_index(base2, n0);
+                load_index(base2 + stride, n1);
+            }
+            load_state(n0);
+            load_state(n1);
+            round_body(base2, n0, n1, 8, 10, 9);
+        }
+        base += 4 * stride;
+    }
+    for (; base < seg_t; base += 2 * stride) {
+        load_index(base, c0);
+        load_index(base + stride, c1);
+        load_state(c0);
+        load_state(c1);
+        round_body(base, c0, c1, 11, 13, 12);
+    }
+    GNNCCA_STAMP(p.stamp_slot, 5);
+
+    if (MSG) {
+        float v = acc[0];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) v += acc[i];
+        v += __shfl_xor(v, 32);
+        if (wps > 1) {
+            if (lane < kH) s_part[wave * kH + lane] = v;
+            __syncthreads();
+            if (sub == 0) {
+                v = s_part[wave * kH + ch];
+                for (int u = 1; u < wps; ++u) v += s_part[(wave + u) * kH + ch];
+            }
+        }
+        GNNCCA_STAMP(p.stamp_slot, 6);
+        if (active && sub == 0) {
+            const int deg = seg_t - seg_s;
+            if (p.agg == GNNCCA_AGG_MEAN) v = v / (float)max(deg, 1);
+            if (deg == 0) v = 0.f;
+            // projection epilogue (project_node with the bias read through the constant address space)
+            const int o = min(lane, kProjOut - 1);
+            float pr = projb_l;
+            const float* w = s_proj + o;
+#pragma unroll
+            for (int c = 0; c < kH; ++c)
+                pr = fmaf(w[c * kProjOut], __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), c)), pr);
+            if (lane < kPdStride)
+                p.pd_out[(size_t)node * kPdStride + lane] = pr;
+            else if (lane < kProjOut)
+                p.psq_out[(size_t)node * kPsQStride + lane - kPdStride] = pr;
+        }
+    }
+    GNNCCA_STAMP(p.stamp_slot, 7);
+}
+
+template <bool FIRST, bool CLS, bool MSG, bool PDL, bool EB, int NT>
+static hipError_t launch_pipe_t(const StepParams& sp, hipStream_t st) {
+    const int npg = 4 / sp.wps;
+    const unsigned blocks = (unsigned)((sp.N + npg - 1) / npg);
+    const size_t lds = ((MSG ? (size_t)kH * kProjOut : 0) + 4 * kH + (PDL ? (size_t)sp.N * kPdStride : 0)) * sizeof(float);
+    GNNCCA_LAUNCH((mpn_step_pipe_kernel<FIRST, CLS, MSG, PDL, EB, NT>), dim3(blocks), dim3(256), lds, st, sp);
+    return hipGetLastError();
+}
+
+template <bool FIRST, bool CLS, bool MSG, bool PDL>
+static hipError_t launch_pipe(const StepParams& sp, hipStream_t st) {
+    if (!PDL) {   // the non-temporal variants only exist beyond the LDS-resident gather table (N > 1024): big batches
+        const int nt = sp.nt_load ? 2 : (sp.nt_store ? 1 : 0);
+        if (nt == 2) return sp.e_bf16 ? launch_pipe_t<FIRST, CLS, MSG, false, true, 2>(sp, st) : launch_pipe_t<FIRST, CLS, MSG, false, false, 2>(sp, st);
+        if (nt == 1) return sp.e_bf16 ? launch_pipe_t<FIRST, CLS, MSG, false, true, 1>(sp, st) : launch_pipe_t<FIRST, CLS, MSG, false, false, 1>(sp, st);
+    }
+    return sp.e_bf16 ? launch_pipe_t<FIRST, CLS, MSG, PDL, true, 0>(sp, st) : launch_pipe_t<FIRST, CLS, MSG, PDL, false, 0>(sp, st);
+}
+
+static hipError_t launch_pipe_dispatch(const StepParams& sp, bool msg, hipStream_t st) {
+    const int key = (sp.first ? 8 : 0) | (sp.cls_layers ? 4 : 0) | (msg ? 2 : 0) | (sp.pd_lds ? 1 : 0);
+    switch (key) {
+#define GNNCCA_PIPE_CASE(K, A, B, C, D) \
+    case K: return launch_pipe<A, B, C, D>(sp, st);
+        GNNCCA_PIPE_CASE(0, false, false, false, false)
+        GNNCCA_PIPE_CASE(1, false, false, false, true)
+        GNNCCA_PIPE_CASE(2, false, false, true, false)
+        GNNCCA_PIPE_CASE(3, false, false, true, true)
+        GNNCCA_PIPE_CASE(4, false, true, false, false)
+        GNNCCA_PIPE_CASE(5, false, true, false, true)
+        GNNCCA_PIPE_CASE(6, false, true, true, false)
+        GNNCCA_PIPE_CASE(7, false, true, true, true)
+        GNNCCA_PIPE_CASE(8, true, false, false, false)
+        GNNCCA_PIPE_CASE(9, true, false, false, true)
+        GNNCCA_PIPE_CASE(10, true, false, true, false)
+        GNNCCA_PIPE_CASE(11, true, false, true, true)
+        GNNCCA_PIPE_CASE(12, true, true, false, false)
+        GNNCCA_PIPE_CASE(13, true, true, false, true)
+        GNNCCA_PIPE_CASE(14, true, true, true, false)
+        GNNCCA_PIPE_CASE(15, true, true, true, true)
+#undef GNNCCA_PIPE_CASE
+    }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace gnncca

@@ -35,7 +35,8 @@ st = buf.cpu().numpy().reshape(8, 4096 * 4, 16).astype(np.float64)
 names = {0: "enc_tail", 1: "enc_gemm_plan", 2: "step1", 3: "step2", 4: "step3", 5: "step4"}
 labels = {0: ["start", "partials issued", "weights staged", "after sync", "row reduced", "after sync2", "layer2 done", "projected", "end"],
           1: ["start", "end"],
-          2: ["start", "prologue issued", "after sync", "chunk loads issued", "chunk computed", "loop done", "combined", "end"]}
+          2: ["start", "prologue issued", "after sync", "r1 gathers issued", "r1 computed", "loop done", "combined", "end",
+              "r2 gathers issued", "r2 computed", "r2 operands landed", "r3+ gathers issued", "r3+ computed", "r3+ operands landed"]}
 CLK_GHZ = 2.1  # s_memtime counts shader cycles (per-XCD counters with different bases: only per-wave deltas mean anything)
 for k in range(6):
     a = st[k]
@@ -45,7 +46,12 @@ for k in range(6):
     lab = labels[min(k, 2)]
     print(f"{names[k]}: {len(rows)} waves; per-wave time since the wave's own first stamp, ns at {CLK_GHZ} GHz")
     prev = None
-    for i, l in enumerate(lab):
+    order = list(range(len(lab))) if min(k, 2) != 2 else [0, 1, 2, 3, 5 + 0 * 0, 4, 8, 10, 9, 11, 13, 12, 5, 6, 7]
+    if min(k, 2) == 2:
+        order = [0, 1, 2, 3, 15, 4, 8, 10, 9, 11, 13, 12, 5, 6, 7]
+        lab = lab + ["", "r1 operands landed"]
+    for i in order:
+        l = lab[i]
         ok = rows[:, i] > 0
         if not ok.any():
             continue
