@@ -136,7 +136,7 @@ def scale_probe(params, device, args, graphs=64):
     achieved = alg / (step_ms * 1e-3) / 1e9
     return {"workload": f"{graphs} x dense{args.nodes} graphs in one forward (E={E})", "bound": "hbm", "achieved": achieved,
             "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "avg_launch_us": step_ms * 1e3,
-            "algorithmic_bytes_per_launch": alg, "kernel": "mpn_step_fast_kernel (same kernel as `roofline`)"}
+            "algorithmic_bytes_per_launch": alg, "kernel": "mpn_step_persist_kernel (the batch form of the `roofline` kernel)"}
 
 
 def _cpu_model():
@@ -256,6 +256,37 @@ def timed_blocks(run, steps, warmup, dist, device, backend, min_blocks=10, min_t
             t = float(tt.item())
         blocks.append(t)
     return sorted(blocks), out
+
+
+def state_hash(model):
+    """64-bit hash of the module's whole state_dict (bytes of every tensor in key order), computed on the host."""
+    import hashlib
+    h = hashlib.blake2b(digest_size=8)
+    for k, v in model.state_dict().items():
+        h.update(k.encode())
+        h.update(v.detach().cpu().contiguous().numpy().tobytes())
+    return int.from_bytes(h.digest(), "little", signed=True)
+
+
+def broadcast_and_verify(model, dist, device, backend, rank, world):
+    """The ONE collective of the path: rank 0's state_dict to every rank (RCCL over xGMI for backend nccl), timed; then every rank's
+    state_dict hash is all-gathered and compared with rank 0's -- a rank that kept its own weights fails the job loudly instead
+    of producing plausible numbers.  Returns (broadcast milliseconds on this rank, this rank's hash)."""
+    from gnn_cca_amd.sharding import broadcast_weights
+    torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    broadcast_weights(model, src=0)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3
+    mine = state_hash(model)
+    dev = device if backend == "nccl" else "cpu"
+    hashes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(hashes, torch.tensor([mine], dtype=torch.int64, device=dev))
+    got = [int(h.item()) for h in hashes]
+    if any(h != got[0] for h in got):
+        raise SystemExit(f"bench.py: rank {rank}: state_dict hashes differ after the weight broadcast: {got}")
+    return ms, mine
 
 
 def launch_ranks(args):
@@ -388,9 +419,9 @@ def main():
     model.edge_state_dtype = args.edge_state
     model.encoder_products = args.enc_products
     # shared weights: ONE RCCL broadcast of rank 0's parameters over xGMI (no other collective on the path)
+    broadcast_ms, weights_hash = None, None
     if world > 1:
-        from gnn_cca_amd.sharding import broadcast_weights
-        broadcast_weights(model, src=0)
+        broadcast_ms, weights_hash = broadcast_and_verify(model, dist, device, args.backend, rank, world)
     data = make_data(args.nodes, args.graphs, 1 + rank, device)
     E = data.edge_index.shape[1]
     N = data.x.shape[0]
@@ -439,6 +470,20 @@ def main():
 
         blocks, out = timed_blocks(run, args.steps, args.warmup, dist, device, args.backend, min_blocks=args.min_blocks)
         t = blocks[len(blocks) // 2]      # median block of K steps (max over ranks inside every block)
+        # every rank's OWN time per step (no barrier inside), gathered: how evenly the ranks run
+        rank_ms = None
+        if world > 1:
+            torch.cuda.synchronize()
+            dist.barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                run()
+            torch.cuda.synchronize()
+            own = (time.perf_counter() - t0) / args.steps * 1e3
+            dev_ = device if args.backend == "nccl" else "cpu"
+            all_ms = [torch.zeros(1, dtype=torch.float64, device=dev_) for _ in range(world)]
+            dist.all_gather(all_ms, torch.tensor([own], dtype=torch.float64, device=dev_))
+            rank_ms = [float(v.item()) for v in all_ms]
         if static_out is not None:
             out = static_out
         ok = all(torch.isfinite(o).all().item() for o in out["classified_edges"])
@@ -451,7 +496,7 @@ def main():
             m4.edge_state_dtype = args.edge_state
             m4.encoder_products = args.enc_products
             if world > 1:
-                broadcast_weights(m4, src=0)
+                broadcast_and_verify(m4, dist, device, args.backend, rank, world)
             graphs4 = LazyDenseGraphs(args.config4_graphs, 128, device)
             lo4, hi4, batch4 = shard_batch(graphs4, rank, world)       # this rank's union, resident in HBM
             e4_local = batch4.edge_index.shape[1] if batch4 is not None else 0
@@ -461,11 +506,18 @@ def main():
                                          min(args.warmup, 10), dist, device, args.backend, min_blocks=5, min_total_s=0.1)
             t4 = blocks4[len(blocks4) // 2]
             ok4 = all(torch.isfinite(o).all().item() for g in res4[2][:2] for o in g)
+            k4 = {}
+            if batch4 is not None:   # this rank's share, kernel by kernel (events attached to every dispatch)
+                for _ in range(5):
+                    _, times4 = m4.forward_profiled(batch4)
+                    for kind, ms in times4:
+                        k4.setdefault(kind, []).append(ms)
             cfg4 = {"workload": f"{args.config4_graphs} x dense128 graphs (E={e4_total}), sharded {hi4 - lo4} per rank "
                                 f"through sharding.forward_sharded, L=4, 3 classified steps, fp32, eval",
                     "value": e4_total * steps4 / t4, "unit": "edges/s", "scaling": "strong", "n_gpus": world,
                     "graphs_per_rank": hi4 - lo4, "edges_rank0": e4_local, "steps": steps4, "blocks": len(blocks4),
-                    "ms_per_step": t4 / steps4 * 1e3, "outputs_finite": bool(ok4)}
+                    "ms_per_step": t4 / steps4 * 1e3, "outputs_finite": bool(ok4),
+                    "kernels_us_rank0": {k: float(np.mean(v)) * 1e3 for k, v in k4.items()}}
             del m4, graphs4, batch4, res4
 
         # per-kernel durations (HIP events attached to every dispatch; separate pass so the timed region is undisturbed)
@@ -489,8 +541,9 @@ def main():
         try:
             with open(os.path.join(ROOT, "profiles", "pmc_index.json")) as f:
                 ent = json.load(f).get(f"{args.graphs}x{args.nodes}_L{args.L}" + ("_bf16" if args.edge_state == "bf16" else ""))
-            if ent:
-                traffic, rocprof_us = ent["hbm_bytes_per_launch"], ent["rocprof_avg_us"]
+            if ent:   # like for like: the call-weighted mean over the message variants, the mix `algorithmic_bytes_per_launch` averages
+                traffic = ent.get("hbm_bytes_per_launch_msg_mean", ent["hbm_bytes_per_launch"])
+                rocprof_us = ent.get("rocprof_avg_us_msg_mean", ent["rocprof_avg_us"])
         except OSError:
             pass
         # the edge state of one step (read + write) against the 8 x 4 MB of L2: below that the launch is bounded by its
@@ -508,22 +561,26 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32",   # the arithmetic type of the path (every product and sum is fp32-accurate; see config.edge_state for storage)
             "data": "synthetic",
             "config": {"workload": f"{args.graphs} x dense{args.nodes} graph(s) per GPU per step "
                                    f"(N={N}, E={E}), feat 2048, L={args.L}, 3 classified steps, fp32 arithmetic, "
                                    f"{args.edge_state} edge state, eval",
-                       "mode": mode_used, "edge_state": args.edge_state, "encoder_products": args.enc_products,
+                       "mode": mode_used, "edge_state": args.edge_state, "edge_state_storage": "bf16" if args.edge_state == "bf16" else "f32",
+                       "encoder_products": args.enc_products,
                        "outputs_finite": bool(ok),
                        "edge_steps_per_s": world * E * args.L * args.steps / t,
                        "timing": f"median of {len(blocks)} blocks of {args.steps} steps (each: barrier + synchronize on both "
                                  f"sides, MAX over ranks)",
                        "block_ms": {"min": blocks[0] * 1e3, "median": t * 1e3, "max": blocks[-1] * 1e3},
                        "launcher": "single process" if world == 1 else "torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ
-                       else "bench.py (self-launched rank processes)", "backend": args.backend if world > 1 else None},
+                       else "bench.py (self-launched rank processes)", "backend": args.backend if world > 1 else None,
+                       "ranks_seen": dist.get_world_size() if dist else 1, "broadcast_ms": broadcast_ms,
+                       "weights_hash": f"{weights_hash & 0xFFFFFFFFFFFFFFFF:016x}" if weights_hash is not None else None,
+                       "rank_ms_per_step": ({"min": min(rank_ms), "max": max(rank_ms), "all": rank_ms} if rank_ms else None)},
             "roofline": {"bound": "latency" if cache_resident else "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": "mpn_step_fast_kernel<FIRST|CLS,MSG> (message-passing step, L-1 launches/forward)",
+                         "kernel": "mpn_step_pipe_kernel / mpn_step_persist_kernel <FIRST|CLS, MSG> (message-passing step, L-1 launches/forward)",
                          "avg_launch_us": step_ms * 1e3, "rocprof_avg_launch_us": rocprof_us,
                          "algorithmic_bytes_per_launch": alg,
                          "note": "edge state is L2/Infinity-Cache resident at this size: the launch is bounded by its dependent "

@@ -73,6 +73,7 @@ struct EncPlanParams {
     unsigned* blockflags;
     int M, K, O, kslice, vec_ok, nrt, nks, gemm_blocks, E, N;
     int ell_S;  // slots per node of the padded step layout to validate the degrees against (0: none)
+    int plan_span;  // 1024-edge plan blocks per plan workgroup (plan.cuh: 1, or kPlanSpan on a plan-only launch of a big batch)
 };
 
 __global__ __launch_bounds__(256) void enc_gemm_plan_kernel(const EncPlanParams p) {
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(256) void enc_gemm_plan_kernel(const EncPlanParams 
         const int rt = b % p.nrt, t = b / p.nrt;
         gemm_tile(rt, t % p.nks, t / p.nks, p.in, p.W, p.part, p.M, p.K, p.O, p.kslice, p.vec_ok);
     } else {
-        plan_block(b - p.gemm_blocks, p.ei, p.E, p.N, p.seg_ptr, p.col32, p.blockflags, &s_fl, p.ell_S);
+        plan_block(b - p.gemm_blocks, p.ei, p.E, p.N, p.seg_ptr, p.col32, p.blockflags, &s_fl, p.ell_S, p.plan_span);
     }
     GNNCCA_STAMP(1, 1);
 }

@@ -15,7 +15,7 @@ extern thread_local int g_last_hip_error;  // hipError_t of the last failed HIP 
 // a stray variable in one rank's environment cannot silently change its numerics.
 const char* diag_env(const char* name);
 
-constexpr uint32_t kBlobMagic = 0x4D504E33u;  // "MPN3": bumped with every change of the blob layout (a blob is only
+constexpr uint32_t kBlobMagic = 0x4D504E34u;  // "MPN4": bumped with every change of the blob layout (a blob is only
                                               // valid for the library build that packed it; load_packed_blob checks)
 constexpr int kH = 32;        // node latent width the MFMA step kernel is built for (node_out_dim)
 constexpr int kEF = 6;        // edge latent width (edge_out_dim): 3 k-steps of v_mfma_f32_32x32x2_f32
@@ -49,7 +49,8 @@ struct BlobHeader {
     int32_t cls_w1, cls_b1, cls_w2, cls_b2;
     int32_t fast_consts;                    // [kFastConsts] contiguous copy of the per-step scalars (see below), or 0
     int32_t enc_w3;                         // first encoder weight as 3 bf16 pieces, [in/32][3][out][32], or 0
-    int32_t pad[6];
+    int32_t wne_bf16;                       // [9][64] dwords: W_ne as packed bf16 piece pairs, the B operands of msg_bf16.cuh
+    int32_t pad[5];
 };
 
 // Layout of the `fast_consts` block (floats): the per-step scalars mpn_step_fast_kernel reads into SGPRs.
@@ -71,7 +72,8 @@ bool fast_consts_ok(const gnncca_mpn_dims* d);
 // tensors, built once per GRAPH_NET_PARAMS by pack_program() and interpreted by pack_device_kernel -- the same
 // folding / splitting as gnncca_pack_weights, bit for bit, without the parameters ever visiting the host.
 struct PackSeg {
-    int32_t kind;               // 0: weight element, 1: bias element, 2: weight element split into 3 bf16 planes
+    int32_t kind;               // 0: weight element, 1: bias element, 2: weight element split into 3 bf16 planes,
+                                // 3: W_ne element (row = channel, column = k < 6) as bf16 pieces in the MsgB lane layout
     int32_t dst;                // float offset in the blob (kind 2: offset of plane 0)
     int32_t param;              // index of the Linear's weight (kind 0, 2) or bias (kind 1) in the parameter list
     int32_t bn;                 // index of the BatchNorm weight (gamma; beta, mean, var follow), or -1

@@ -202,6 +202,8 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
                 fp.blockflags = blockflags;
                 fp.E = E;
                 if (plan_blocks > 0) {
+                    ep.plan_span = plan_span(edge_index, E);
+                    if (ep.plan_span > 1) plan_blocks = (plan_blocks + ep.plan_span - 1) / ep.plan_span;
                     GNNCCA_LAUNCH(enc_gemm_plan_kernel, dim3(plan_blocks), dim3(256), 0, st, ep);
                     HIP_TRY(hipGetLastError());
                     PROF_MARK(GNNCCA_K_PLAN_ROWS);
@@ -263,6 +265,10 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
             PROF_MARK(GNNCCA_K_ENC_GEMM);
         }
         if (ep.gemm_blocks + plan_blocks > 0 && !plan_launched) {
+            if (ep.gemm_blocks == 0 && plan_blocks > 0) {   // a plan-only launch (big batches): several blocks per workgroup
+                ep.plan_span = plan_span(edge_index, E);
+                if (ep.plan_span > 1) plan_blocks = (plan_blocks + ep.plan_span - 1) / ep.plan_span;
+            }
             GNNCCA_LAUNCH(enc_gemm_plan_kernel, dim3(ep.gemm_blocks + plan_blocks), dim3(256), 0, st, ep);
             HIP_TRY(hipGetLastError());
             PROF_MARK(split ? GNNCCA_K_PLAN_ROWS : GNNCCA_K_ENC_GEMM);
@@ -368,6 +374,7 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
     sp.off_cw2 = hdr.cls_w2;
     sp.off_cb2 = hdr.cls_b2;
     sp.off_fast = hdr.fast_consts;
+    sp.off_wnebf = hdr.wne_bf16;
     sp.cls_hidden = hdr.cls_hidden;
     sp.N = N;
     sp.E = E;

@@ -51,16 +51,14 @@ struct MsgB {            // B operands (lane: channel = lane & 31, k half = lane
     unsigned b2[3];      // lanes < 32: b2 pieces; lanes >= 32: b0 pieces                            (M3)
     unsigned bq;         // lanes < 32: (q0, q1) of Q[node][ch]; lanes >= 32: (q2, -3e38)            (M1, fourth register)
 };
-// W_ne as stored for the f32 MFMA (BlobHeader::wne_b: [3][64], element s * 64 + h * 32 + ch = W_ne[ch][2s + h])
-__device__ __forceinline__ void msg_b_weights(const float* __restrict__ wneb, int lane, MsgB& B) {
-    const int half = lane >> 5, ch = lane & 31;
+// W_ne pieces as packed at weight-pack time (BlobHeader::wne_bf16: [9][64] dwords in exactly this lane layout)
+__device__ __forceinline__ void msg_b_weights(const float* __restrict__ wne_bf16, int lane, MsgB& B) {
+    const unsigned* __restrict__ w = reinterpret_cast<const unsigned*>(wne_bf16);
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-        unsigned p0, p1, p2;
-        split3_pair(wneb[j * 64 + ch], wneb[j * 64 + 32 + ch], p0, p1, p2);
-        B.b0[j] = p0;
-        B.b1[j] = p1;
-        B.b2[j] = half ? p0 : p2;
+        B.b0[j] = w[j * 64 + lane];
+        B.b1[j] = w[(3 + j) * 64 + lane];
+        B.b2[j] = w[(6 + j) * 64 + lane];
     }
 }
 __device__ __forceinline__ void msg_b_bias(float q, int lane, MsgB& B) {   // q = Q[node][lane & 31]

@@ -176,6 +176,7 @@ static BlobPlan plan_blob(const gnncca_mpn_dims* d) {
     p.h.enc_edge_b = take(kEF);
     p.h.wee = take((size_t)kEF * ef * kEF);
     p.h.wne_b = take(3 * 64);
+    p.h.wne_bf16 = take(9 * 64);
     p.h.proj_wT = take((size_t)nf * kH * kProjOut);
     p.h.proj_b = take(kProjOut);
     p.h.cls_layers = d->cls_edge.n_layers;
@@ -303,6 +304,12 @@ bool pack_program(const gnncca_mpn_dims* d, PackProgram* out) {
     bias(Ln, p.h.proj_b + 16, kH);
     for (int s = 0; s < 3; ++s)
         for (int h = 0; h < 2; ++h) weight(Ln, p.h.wne_b + s * 64 + h * 32, hin + 2 * s + h, kH, 1, 0, 1, 0, Ln.in, 0);
+    {   // the same six columns as bf16 pieces in the lane layout of the message MFMAs' B operands (kind 3)
+        if (n >= kMaxPackSegs) return false;
+        PackSeg& g = out->segs[n++];
+        g.kind = 3, g.dst = p.h.wne_bf16, g.param = Ln.w, g.bn = Ln.bn, g.src_off = hin, g.rows = kH, g.cols = kEF, g.unit0 = 0;
+        g.drs = 0, g.dcs = 0, g.srs = Ln.in, g.scs = 1;
+    }
     // classifier.edge_mlp
     const Lin Lc1 = next(d->cls_edge.layers[0]);
     weight(Lc1, p.h.cls_w1, 0, Lc1.out, kEF, 0, kEF, 1, kEF, 1);
@@ -456,6 +463,24 @@ int gnncca_pack_weights(const gnncca_mpn_dims* d, const float* const* params, in
         // B operand of v_mfma_f32_32x32x2_f32, k-step s: lane l holds B[k = l>>5][j = l&31] = Wne[j][2s + k]
         for (int s = 0; s < 3; ++s)
             for (int l = 0; l < 64; ++l) blob[p.h.wne_b + s * 64 + l] = f.w[(size_t)(l & 31) * in + hin + 2 * s + (l >> 5)];
+        // B operands of the split-bf16 message (msg_bf16.cuh: MsgB): dword [plane * 3 + j][lane] = the pieces of
+        // (W_ne[ch][2j], W_ne[ch][2j + 1]), ch = lane & 31; plane 0 = first pieces in both halves, plane 1 = second pieces,
+        // plane 2 = third pieces in lanes < 32 and FIRST pieces in lanes >= 32
+        uint16_t* wb = reinterpret_cast<uint16_t*>(blob + p.h.wne_bf16);
+        for (int ch = 0; ch < kH; ++ch)
+            for (int k = 0; k < kEF; ++k) {
+                const float v = f.w[(size_t)ch * in + hin + k];
+                const uint16_t h0 = bf16_rne(v);
+                const float r1 = v - bf16_to_float(h0);
+                const uint16_t h1 = bf16_rne(r1);
+                const float r2 = r1 - bf16_to_float(h1);
+                const uint16_t h2 = bf16_rne(r2);
+                auto at = [&](int plane, int lane) { return ((size_t)(plane * 3 + k / 2) * 64 + lane) * 2 + (k & 1); };
+                wb[at(0, ch)] = wb[at(0, ch + 32)] = h0;
+                wb[at(1, ch)] = wb[at(1, ch + 32)] = h1;
+                wb[at(2, ch)] = h2;
+                wb[at(2, ch + 32)] = h0;
+            }
     }
     // classifier.edge_mlp
     {

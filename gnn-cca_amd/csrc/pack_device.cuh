@@ -44,7 +44,19 @@ __global__ __launch_bounds__(256) void pack_device_kernel(const PackProgram* __r
         }
         size_t k = (size_t)r * g.drs + (size_t)c * g.dcs;
         if (g.kind == 2) k = (size_t)(c / 32) * 3 * (size_t)g.plane + (size_t)r * 32 + (size_t)(c % 32);  // [in/32][3][out][32]
-        if (g.kind == 2) {
+        if (g.kind == 3) {   // W_ne[ch = r][k = c] as bf16 pieces in the MsgB lane layout (see gnncca_pack_weights)
+            unsigned short* wb = reinterpret_cast<unsigned short*>(blob + g.dst);
+            const unsigned short h0 = pack_bf16_rne(v);
+            const float r1 = v - __uint_as_float((unsigned)h0 << 16);
+            const unsigned short h1 = pack_bf16_rne(r1);
+            const float r2 = r1 - __uint_as_float((unsigned)h1 << 16);
+            const unsigned short h2 = pack_bf16_rne(r2);
+            const size_t j2 = (size_t)(c / 2) * 128 + (c & 1);
+            wb[j2 + 2 * r] = wb[j2 + 2 * (r + 32)] = h0;
+            wb[384 + j2 + 2 * r] = wb[384 + j2 + 2 * (r + 32)] = h1;
+            wb[768 + j2 + 2 * r] = h2;
+            wb[768 + j2 + 2 * (r + 32)] = h0;
+        } else if (g.kind == 2) {
             unsigned short* w3 = reinterpret_cast<unsigned short*>(blob + g.dst);
             const unsigned short h0 = pack_bf16_rne(v);
             const float r1 = v - __uint_as_float((unsigned)h0 << 16);

@@ -66,53 +66,112 @@ __device__ void plan_sort_fallback(const long long* __restrict__ ei, int E, int 
 // quarter of the workgroups: the thread-per-edge form was bound by per-workgroup latency, 2.8 TB/s).
 __host__ __device__ inline int plan_edges_per_block(int E) { return E >= (1 << 20) ? 1024 : 256; }
 __host__ __device__ inline int plan_num_blocks(int E) { return (E + plan_edges_per_block(E) - 1) / plan_edges_per_block(E); }
+// The plan launch of big batches takes plan_block's pair form when the index rows allow 16-byte loads: kPlanSpan 1024-edge blocks
+// per workgroup.  (Measured with 4 blocks = 4096 edges per workgroup, every load in flight before the first use: 64 x dense256
+// 19.5 -> 20.7 us, 512 x dense128 39.2 -> 42.7, 64 x dense128 6.9 -> 8.5, profiles/r03_logs/r3_plan_ab2.log; one block it is.)
+constexpr int kPlanSpan = 1;
+inline int plan_span(const void* ei, int E) {   // 0: the narrow form
+    return (plan_edges_per_block(E) == 1024 && (E & 1) == 0 && (reinterpret_cast<unsigned long long>(ei) & 15) == 0) ? kPlanSpan : 0;
+}
+
+// One edge of the plan (shared by both forms below): bounds, int32 target id, CSR offsets at row boundaries, padded-layout check.
+__device__ __forceinline__ unsigned plan_edge(int k, long long r, long long c, long long rp, const long long* __restrict__ ei, int E, int N,
+                                              int* __restrict__ seg_ptr, int& col_out, int ell_S) {
+    if (r < 0 || r >= N || c < 0 || c >= N) return GNNCCA_GRAPH_BAD_INDEX;
+    unsigned fl = 0u;
+    col_out = (int)c;
+    const bool prev_ok = k == 0 || (rp >= 0 && rp < N);  // otherwise its owner raises the flag
+    if (prev_ok) {
+        if (r < rp) {
+            fl |= GNNCCA_GRAPH_UNSORTED;
+        } else {
+            for (long long n = rp + 1; n <= r; ++n) seg_ptr[n] = k;
+            // padded layout of the step kernels (ell_S slots per node, chosen from E/N): a row that still continues
+            // ell_S edges after its start does not fit (rows are sorted here, or UNSORTED is raised elsewhere)
+            if (ell_S > 0 && r > rp && (long long)k + ell_S < E && ei[(size_t)k + ell_S] == r) fl |= GNNCCA_GRAPH_IRREGULAR;
+        }
+        if (k == E - 1)
+            for (long long n = r + 1; n <= N; ++n) seg_ptr[n] = E;
+    }
+    return fl;
+}
 
 // Per-edge part of the plan.  Every workgroup reports its findings in its OWN word (`blockflags[b]`, always
 // written, so there is no state to clear between forwards); the tail launch ORs them into flags[0].
 __device__ __forceinline__ void plan_block(int pb, const long long* __restrict__ ei, int E, int N,
                                            int* __restrict__ seg_ptr, int* __restrict__ col32,
-                                           unsigned* __restrict__ blockflags, unsigned* s_fl, int ell_S = 0) {
+                                           unsigned* __restrict__ blockflags, unsigned* s_fl, int ell_S = 0, int span = 0) {
     if (threadIdx.x == 0) *s_fl = 0u;
     __syncthreads();
     const int per = plan_edges_per_block(E) / 256;
-    const int k0 = pb * 256 * per + threadIdx.x;
-    long long r[4], c[4], rp[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {  // all loads first
-        const int k = k0 + u * 256;
-        const bool on = u < per && k < E;
-        r[u] = on ? ei[k] : 0;
-        c[u] = on ? ei[(size_t)E + k] : 0;
-        rp[u] = (on && k > 0) ? ei[k - 1] : -1;
-    }
     unsigned fl = 0u;
+    // Batches (1024 edges per workgroup), both index rows 16-byte aligned: a thread owns PAIRS of consecutive edges -- one 16-byte
+    // non-temporal load per row and pair (edge_index is read once per forward), all four in flight before the first use, the
+    // previous edge's row id from the neighbouring lane instead of a third load, the two narrowed ids as one 8-byte store.
+    // (Round 2's form read every row id twice, 8 bytes at a time: 3.7-4.2 TB/s of the 20 B / edge.)
+    typedef long long ll2 __attribute__((ext_vector_type(2)));
+    typedef int i32x2 __attribute__((ext_vector_type(2)));
+    if (span == kPlanSpan) {   // (the host checked: per == 4, E even, both index rows 16-byte aligned)
+        const int lane = threadIdx.x & 63;
+        constexpr int U = 2 * kPlanSpan;
+        ll2 r2[U], c2[U];
+        long long rlast[U];
+        int kk[U];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int k = k0 + u * 256;
-        if (!(u < per && k < E)) continue;
-        if (r[u] < 0 || r[u] >= N || c[u] < 0 || c[u] >= N) {
-            fl |= GNNCCA_GRAPH_BAD_INDEX;
-            continue;
+        for (int u = 0; u < U; ++u) {
+            const int k = pb * (1024 * kPlanSpan) + u * 512 + 2 * (int)threadIdx.x;
+            kk[u] = k;
+            const bool on = k < E;   // E is even: a pair is inside or outside as a whole
+            const int kl = on ? k : 0;
+            r2[u] = __builtin_nontemporal_load(reinterpret_cast<const ll2*>(ei + kl));
+            c2[u] = __builtin_nontemporal_load(reinterpret_cast<const ll2*>(ei + (size_t)E + kl));
+            // the edge before a wave's first pair belongs to another wave (or workgroup): lane 0 fetches it
+            rlast[u] = (lane == 0 && on && k > 0) ? ei[k - 1] : -1;
         }
-        col32[k] = (int)c[u];
-        const bool prev_ok = k == 0 || (rp[u] >= 0 && rp[u] < N);  // otherwise its owner raises the flag
-        if (prev_ok) {
-            if (r[u] < rp[u]) {
-                fl |= GNNCCA_GRAPH_UNSORTED;
-            } else {
-                for (long long n = rp[u] + 1; n <= r[u]; ++n) seg_ptr[n] = k;
-                // padded layout of the step kernels (ell_S slots per node, chosen from E/N): a row that still continues
-                // ell_S edges after its start does not fit (rows are sorted here, or UNSORTED is raised elsewhere)
-                if (ell_S > 0 && r[u] > rp[u] && (long long)k + ell_S < E && ei[(size_t)k + ell_S] == r[u])
-                    fl |= GNNCCA_GRAPH_IRREGULAR;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = kk[u];
+            const long long up = __shfl_up(r2[u][1], 1);
+            const long long rp0 = lane == 0 ? rlast[u] : up;
+            if (k < E) {
+                int j0 = 0, j1 = 0;
+                const unsigned f0 = plan_edge(k, r2[u][0], c2[u][0], rp0, ei, E, N, seg_ptr, j0, ell_S);
+                const unsigned f1 = plan_edge(k + 1, r2[u][1], c2[u][1], r2[u][0], ei, E, N, seg_ptr, j1, ell_S);
+                fl |= f0 | f1;
+                if (!((f0 | f1) & GNNCCA_GRAPH_BAD_INDEX)) {
+                    *reinterpret_cast<i32x2*>(col32 + k) = i32x2{j0, j1};
+                } else {   // the forward is poisoned anyway; keep what is valid as the narrow form does
+                    if (!(f0 & GNNCCA_GRAPH_BAD_INDEX)) col32[k] = j0;
+                    if (!(f1 & GNNCCA_GRAPH_BAD_INDEX)) col32[k + 1] = j1;
+                }
             }
-            if (k == E - 1)
-                for (long long n = r[u] + 1; n <= N; ++n) seg_ptr[n] = E;
+        }
+    } else {
+        const int k0 = pb * 256 * per + threadIdx.x;
+        long long r[4], c[4], rp[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {  // all loads first
+            const int k = k0 + u * 256;
+            const bool on = u < per && k < E;
+            r[u] = on ? ei[k] : 0;
+            c[u] = on ? ei[(size_t)E + k] : 0;
+            rp[u] = (on && k > 0) ? ei[k - 1] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = k0 + u * 256;
+            if (!(u < per && k < E)) continue;
+            int j = 0;
+            const unsigned f = plan_edge(k, r[u], c[u], rp[u], ei, E, N, seg_ptr, j, ell_S);
+            fl |= f;
+            if (!(f & GNNCCA_GRAPH_BAD_INDEX)) col32[k] = j;
         }
     }
     if (fl) atomicOr(s_fl, fl);
     __syncthreads();
-    if (threadIdx.x == 0) blockflags[pb] = *s_fl;
+    // one word per 1024-edge (or 256-edge) block, always written: a wide workgroup reports its findings in each of its blocks' words
+    const int nb = plan_num_blocks(E), wspan = span > 1 ? span : 1;
+    if ((int)threadIdx.x < wspan && pb * wspan + (int)threadIdx.x < nb) blockflags[pb * wspan + threadIdx.x] = *s_fl;
 }
 
 // OR of the per-block findings -> flags[0]; stable counting sort if the rows were not sorted.  `smem` >= 3 KB.

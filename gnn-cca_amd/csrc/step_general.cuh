@@ -39,6 +39,7 @@ struct StepParams {
     long long e_stride;
     int off_wee, off_wneb, off_projwT, off_projb, off_encw, off_encb, off_cw1, off_cb1, off_cw2, off_cb2;
     int off_fast;
+    int off_wnebf;   // BlobHeader::wne_bf16
     int cls_layers, cls_hidden;  // cls_layers == 0: this step does not classify
     int N, E, edge_in, attr_vec, first, update, agg, reatt_n, wps, store_e, hin, pd_lds, stamp_slot, e_bf16;
     // padded edge-state layout of big, nearly regular batches: node i owns the slots [i * ell_S, (i + 1) * ell_S) of every
@@ -87,7 +88,7 @@ __global__ __launch_bounds__(256) void mpn_step_kernel(const StepParams p) {
 #pragma unroll
             for (int s = 0; s < 3; ++s) bw[s] = blob[p.off_wneb + s * 64 + lane];
             if (!AGG_MAX) {
-                msg_b_weights(blob + p.off_wneb, lane, mb);
+                msg_b_weights(blob + p.off_wnebf, lane, mb);
                 msg_b_bias(cinit, lane, mb);
             }
         }

@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) GNNCCA_FAST_ATTR void mpn_step_pipe_kernel(con
     if (MSG) {
         cinit = psq[8 + ch];
         projb_l = blob[p.off_projb + min(lane, kProjOut - 1)];
-        msg_b_weights(blob + p.off_wneb, lane, mb);
+        msg_b_weights(blob + p.off_wnebf, lane, mb);
         const f32x4* __restrict__ g4 = reinterpret_cast<const f32x4*>(blob + p.off_projwT);
         stage_proj[0] = g4[tid];                                   // 384 float4 in all
         stage_proj[1] = g4[min(tid + 256, kH * kProjOut / 4 - 1)];
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         f32x4* l4 = reinterpret_cast<f32x4*>(s_proj);
         for (int i = tid; i < kH * kProjOut / 4; i += 256) l4[i] = g4[i];
         projb_l = blob[p.off_projb + min(lane, kProjOut - 1)];
-        msg_b_weights(blob + p.off_wneb, lane, mb);
+        msg_b_weights(blob + p.off_wnebf, lane, mb);
     }
     if (gflags & GNNCCA_GRAPH_BAD_INDEX) {
         if (CLS)

@@ -87,7 +87,8 @@ class _Replayed(nn.Module):
     MOTMPNet forward runs fused inside libgnncca_mpn.so.  When a caller has registered forward hooks on one of them (the way
     per-step latents are usually tapped from the reference), MOTMPNet.forward runs the traced native forward and then
     REPLAYS the reference's call sequence (models/mpn.py:266-297) through ``__call__`` of these containers: each call returns
-    the tensors the fused kernels produced for it, so hooks see the same inputs and outputs as on the reference.  A
+    the tensors the fused kernels produced for it, so hooks see the same inputs and outputs as on the reference (EVAL MODE
+    ONLY: a train-mode forward does not replay, hooks on these containers then do not fire and MOTMPNet.forward warns once).  A
     container called on its own, outside MOTMPNet.forward, evaluates itself with the stand-alone entry points (eval mode)."""
 
     def _take_replayed(self):
@@ -584,6 +585,12 @@ class MOTMPNet(nn.Module):
         """See class docstring.  ``trace`` (optional dict) receives the intermediate latents for debugging.
         In train mode the outputs carry an autograd graph to the parameters (row N3)."""
         if self.training:
+            if self._containers_hooked() and not getattr(self, '_warned_train_hooks', False):
+                # the replay of the container calls exists for eval mode only (the training tape keeps other tensors)
+                import warnings
+                warnings.warn("forward hooks on encoder / MPNet / classifier do not fire in train mode on gnn_cca_amd.MOTMPNet "
+                              "(the fused training forward has no such calls); tap the latents in eval mode", RuntimeWarning)
+                self._warned_train_hooks = True
             return self._forward_train(data)
         if trace is None and self._containers_hooked():
             return self._forward_replayed(data)
@@ -657,10 +664,12 @@ class MOTMPNet(nn.Module):
         self._trainable_checked = True
 
     def _check_batchnorm_rows(self, n, e):
-        """torch.nn.BatchNorm1d in train mode refuses a batch of one row (and an empty one): so does this module, with torch's words."""
+        """torch.nn.BatchNorm1d in train mode refuses a batch of exactly ONE row (its _verify_batch_size rejects one value per
+        channel): so does this module, with torch's words.  Zero rows are not refused: a frame without edges skips the edge MLPs'
+        BatchNorm calls (both engines do) and returns empty logits."""
         for mlp, rows in ((self.encoder.node_mlp, n), (self.encoder.edge_mlp, e), (self.MPNet.edge_model.edge_mlp, e),
                           (self.MPNet.node_model.node_mlp, e), (self.classifier.edge_mlp, e)):
-            if mlp is None or rows > 1:
+            if mlp is None or rows != 1:
                 continue
             if mlp is not self.encoder.node_mlp and mlp is not self.encoder.edge_mlp and mlp is not self.classifier.edge_mlp \
                     and int(self.num_enc_steps) == 0:

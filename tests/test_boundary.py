@@ -124,14 +124,14 @@ class BlobHeader(C.Structure):  # mirror of csrc/internal.h: BlobHeader
                 ("enc_edge_b", C.c_int32), ("wee", C.c_int32), ("wne_b", C.c_int32), ("proj_wT", C.c_int32),
                 ("proj_b", C.c_int32), ("cls_layers", C.c_int32), ("cls_hidden", C.c_int32), ("cls_w1", C.c_int32),
                 ("cls_b1", C.c_int32), ("cls_w2", C.c_int32), ("cls_b2", C.c_int32), ("fast_consts", C.c_int32),
-                ("pad", C.c_int32 * 7)]
+                ("enc_w3", C.c_int32), ("wne_bf16", C.c_int32), ("pad", C.c_int32 * 5)]
 
 
 def blob_forward(blob_u8, params, arch, x, edge_index, edge_attr):
     raw = blob_u8.numpy().tobytes()
     h = BlobHeader.from_buffer_copy(raw[:C.sizeof(BlobHeader)])
     f = np.frombuffer(raw, dtype=np.float32)
-    assert h.magic == 0x4D504E33 and h.total_floats * 4 == len(raw)
+    assert h.magic == 0x4D504E34 and h.total_floats * 4 == len(raw)
     enc = params["encoder_feats_dict"]["nodes"][arch]
     dims = [enc["node_in_dim"]] + list(enc["node_fc_dims"]) + [enc["node_out_dim"]]
     nf = 2 if params["reattach_initial_nodes"] else 1
@@ -245,7 +245,17 @@ def run_pack_program(prog, params, nbytes):
             else:
                 v = (v.astype(np.float64) * s).astype(np.float32)
         k = r * g.drs + c * g.dcs
-        if g.kind == 2:
+        if g.kind == 3:   # W_ne[ch = r][k = c] as bf16 pieces in the lane layout of the message MFMAs' B operands
+            h0 = _bf16_rne(v)
+            r1 = v - (h0.astype(np.uint32) << 16).view(np.float32)
+            h1 = _bf16_rne(r1)
+            r2 = r1 - (h1.astype(np.uint32) << 16).view(np.float32)
+            h2 = _bf16_rne(r2)
+            j2 = 2 * g.dst + (c // 2) * 128 + (c & 1)
+            u16[j2 + 2 * r], u16[j2 + 2 * (r + 32)] = h0, h0
+            u16[384 + j2 + 2 * r], u16[384 + j2 + 2 * (r + 32)] = h1, h1
+            u16[768 + j2 + 2 * r], u16[768 + j2 + 2 * (r + 32)] = h2, h0
+        elif g.kind == 2:
             k = (c // 32) * 3 * g.plane + r * 32 + (c % 32)   # [in/32][3 pieces][out][32]
             h0 = _bf16_rne(v)
             r1 = v - (h0.astype(np.uint32) << 16).view(np.float32)

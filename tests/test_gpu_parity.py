@@ -629,3 +629,33 @@ def test_pipelined_gemm_short_k(node_in, n_nodes):
     for o, r in zip(out, ref):
         scale = max(1.0, float(np.abs(r).max()))
         assert np.abs(o.cpu().numpy() - r).max() <= TOL_TIGHT * 2 * scale
+
+
+def test_non_finite_inputs_stay_inside_their_graph():
+    """Non-finite node features are outside the contract of the fast kernels (their ReLU is an integer max on the float's bits:
+    a positive NaN propagates, a negative one becomes 0; torch propagates both) -- what IS pinned: they do not leak.  A NaN / Inf
+    graph in a batch affects its own logits only; every other graph's logits are bit for bit what they are next to a clean
+    neighbour (lanes beyond a segment read zeros through the range-checked buffer descriptors, never a neighbour's values)."""
+    params, arch, sd = _default_model(1.0 / 63)
+    rng = np.random.default_rng(21)
+    n, g = 64, 3
+    x = rng.standard_normal((g * n, 2048)).astype(np.float32)
+    x /= np.linalg.norm(x, axis=0, keepdims=True)
+    ei = np.concatenate([_dense_graph(n, k * n) for k in range(g)], axis=1)
+    ea = rng.random((ei.shape[1], 4)).astype(np.float32)
+    m = build(params, arch, sd)
+    e_per = n * (n - 1)
+
+    def run(xx, aa):
+        with torch.no_grad():
+            return [t.clone() for t in m(Data(torch.from_numpy(xx).cuda(), torch.from_numpy(ei).cuda(), torch.from_numpy(aa).cuda()))["classified_edges"]]
+
+    clean = run(x, ea)
+    bad_x, bad_a = x.copy(), ea.copy()
+    bad_x[n + 3, 17] = np.nan            # graph 1: a NaN feature, an infinite one, a NaN edge attribute
+    bad_x[n + 9, 5] = np.inf
+    bad_a[e_per + 11, 2] = np.nan
+    dirty = run(bad_x, bad_a)
+    for c, d in zip(clean, dirty):
+        assert torch.equal(c[:e_per], d[:e_per]) and torch.equal(c[2 * e_per:], d[2 * e_per:])   # graphs 0 and 2: untouched
+    # (graph 1 itself: unspecified -- the kernels' fmaxf / integer-max ReLUs swallow some NaNs that torch would propagate)
