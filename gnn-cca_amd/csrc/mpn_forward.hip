@@ -375,6 +375,9 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
     sp.off_cb2 = hdr.cls_b2;
     sp.off_fast = hdr.fast_consts;
     sp.off_wnebf = hdr.wne_bf16;
+    static const bool step_r2 = diag_env("GNNCCA_STEP_R2") != nullptr;   // diagnostics: A/B against round 2's step kernel
+    // which arithmetic the node message uses (StepParams::msg_f32): the traced (general) and the fast kernels follow ONE rule
+    sp.msg_f32 = (N <= 512 || step_r2 || !step_pipe_fits(N, E, ws.e_stride)) ? 1 : 0;
     sp.cls_hidden = hdr.cls_hidden;
     sp.N = N;
     sp.E = E;
@@ -438,9 +441,8 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
         const bool fast = hdr.fast_consts != 0 && sp.attr_vec && !trace && d->agg != GNNCCA_AGG_MAX;
         static const bool step_nomem = diag_env("GNNCCA_STEP_NOMEM") != nullptr;   // diagnostics: arithmetic-only timing of the step kernel
         sp.diag = step_nomem ? 1 : 0;
-        static const bool step_r2 = diag_env("GNNCCA_STEP_R2") != nullptr;   // diagnostics: A/B against round 2's step kernel
         static const bool no_persist = diag_env("GNNCCA_STEP_NOPERSIST") != nullptr;   // diagnostics: A/B against one node per wave
-        const bool pipe_ok = fast && !step_r2 && step_pipe_fits(N, E, ws.e_stride);
+        const bool pipe_ok = fast && !sp.msg_f32;
         // at least four segments per resident wave (4 workgroups x 4 waves on every CU) and a message block to amortise the per-wave
         // set-up over: persistent waves (same-box A/B in profiles/r03_logs/r3_abc1.log: -6 % at 64 x dense256 and 512 x dense128 on top
         // of the one-node-per-wave form, nothing at 2 nodes per wave, +5 % on the message-less last step, which therefore stays as it was)

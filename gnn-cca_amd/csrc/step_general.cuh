@@ -50,6 +50,10 @@ struct StepParams {
     int nt_store, nt_load;   // non-temporal policy of the specialised step kernel's streams (see step_fast.cuh)
     DropCfg drop;            // train-mode Dropout (general kernel only); all p == 0 in eval
     int step_no, cls_no;     // 1-based step, 0-based index of this classified step: the dropout streams
+    int msg_f32;             // 1: the node message on f32-input MFMAs (an ordered fp32 FMA chain), the arithmetic of rounds 1-2: graphs of
+                             // <= 512 nodes, where a launch is a chain of dependent latencies and the split-bf16 form's operand
+                             // construction costs more than its matrix-pipe overlap returns (1 x dense256: 4.6 vs 4.8 us per step);
+                             // 0: split-bf16 (msg_bf16.cuh).  One rule for the traced and the fast kernels: same bits either way
     int diag;                // GNNCCA_DIAG experiments (0 in production): bit 0 = timing-only run of mpn_step_pipe_kernel with
                              // zero-record stream descriptors (no HBM traffic: what the arithmetic alone costs)
 };
@@ -87,7 +91,7 @@ __global__ __launch_bounds__(256) void mpn_step_kernel(const StepParams p) {
             cinit = psq[8 + ch];
 #pragma unroll
             for (int s = 0; s < 3; ++s) bw[s] = blob[p.off_wneb + s * 64 + lane];
-            if (!AGG_MAX) {
+            if (!AGG_MAX && !p.msg_f32) {
                 msg_b_weights(blob + p.off_wnebf, lane, mb);
                 msg_b_bias(cinit, lane, mb);
             }
@@ -230,12 +234,12 @@ __global__ __launch_bounds__(256) void mpn_step_kernel(const StepParams p) {
         if (MSG) {
             // node message: ReLU(W_n . cat(x[row], e') + b_n)   (models/mpn.py:97-98), 64 edges x 32 channels
             f32x16 d0, d1;
-            if (!AGG_MAX) {
+            if (!AGG_MAX && !p.msg_f32) {
                 MsgA oa;
                 msg_a_operands(en, base, seg_t, lane, oa);
                 d0 = msg_tile(oa, mb, 0);
                 d1 = msg_tile(oa, mb, 1);
-            } else {   // 'max': an ordered fp32 FMA chain, which the backward's arg-max pass recomputes bit for bit (backward.cuh)
+            } else {   // small graphs (msg_f32) and 'max': an ordered fp32 FMA chain, which the backward's arg-max pass recomputes bit for bit (backward.cuh)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) d0[i] = d1[i] = cinit;
 #pragma unroll

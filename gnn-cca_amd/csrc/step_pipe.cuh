@@ -107,8 +107,6 @@ __global__ __launch_bounds__(256) GNNCCA_FAST_ATTR void mpn_step_pipe_kernel(con
     const rsrc_t r_attr = make_rsrc(p.edge_attr, live * (unsigned long long)p.E * 16);
     const rsrc_t r_pd = make_rsrc(p.pd_in, (unsigned long long)p.N * (kPdStride * 4));
     const rsrc_t r_log = make_rsrc(p.logits, CLS ? live * (unsigned long long)p.E * 4 : 0ull);
-    // the last step stores no edge state: a resource with 0 records drops every store (no branch inside the round)
-    const rsrc_t r_est = make_rsrc(p.e, p.store_e ? live * (EBF16 ? 3 : 6) * plane_b : 0ull);
 
     f32x16 acc;  // 'sum' / 'mean' only: 'max' takes the general kernel
 #pragma unroll
@@ -278,7 +276,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const rsrc_t r_attr = make_rsrc(p.edge_attr, live * (unsigned long long)p.E * 16);
     const rsrc_t r_pd = make_rsrc(p.pd_in, (unsigned long long)p.N * (kPdStride * 4));
     const rsrc_t r_log = make_rsrc(p.logits, CLS ? live * (unsigned long long)p.E * 4 : 0ull);
-    const rsrc_t r_est = make_rsrc(p.e, p.store_e ? live * (EBF16 ? 3 : 6) * plane_b : 0ull);
 
     // per-node state the shared pieces read (by reference)
     int seg_s = seg_c[node], seg_t = seg_c[node + 1];
