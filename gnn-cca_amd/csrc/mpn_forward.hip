@@ -56,19 +56,6 @@ int gnncca_read_graph_flags(const void* workspace, uint32_t* flags_out, gnncca_s
 
 }  // extern "C"
 
-// compute units of the current device (cached per thread and device)
-static int device_cu_count() {
-    static thread_local int cached_dev = -1, cached_cus = 256;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return cached_cus;
-    if (dev != cached_dev) {
-        int n = 0;
-        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cached_cus = n;
-        cached_dev = dev;
-    }
-    return cached_cus;
-}
-
 static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const float* x, const int64_t* edge_index,
                         const float* edge_attr, int64_t n_nodes, int64_t n_edges, void* workspace, size_t workspace_bytes,
                         float* logits_out, const gnncca_trace* trace, gnncca_stream_t stream, Profiler* prof,
@@ -441,14 +428,8 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
         const bool fast = hdr.fast_consts != 0 && sp.attr_vec && !trace && d->agg != GNNCCA_AGG_MAX;
         static const bool step_nomem = diag_env("GNNCCA_STEP_NOMEM") != nullptr;   // diagnostics: arithmetic-only timing of the step kernel
         sp.diag = step_nomem ? 1 : 0;
-        static const bool no_persist = diag_env("GNNCCA_STEP_NOPERSIST") != nullptr;   // diagnostics: A/B against one node per wave
         const bool pipe_ok = fast && !sp.msg_f32;
-        // at least four segments per resident wave (4 workgroups x 4 waves on every CU) and a message block to amortise the per-wave
-        // set-up over: persistent waves (same-box A/B in profiles/r03_logs/r3_abc1.log: -6 % at 64 x dense256 and 512 x dense128 on top
-        // of the one-node-per-wave form, nothing at 2 nodes per wave, +5 % on the message-less last step, which therefore stays as it was)
-        if (pipe_ok && !sp.pd_lds && !no_persist && msg && (long long)N >= 16ll * kPersistWgPerCu * device_cu_count())
-            err = launch_persist_dispatch(sp, msg, st, device_cu_count());
-        else if (pipe_ok)
+        if (pipe_ok)
             err = launch_pipe_dispatch(sp, msg, st);
         else if (fast)
             err = launch_fast_dispatch(sp, msg, st);
