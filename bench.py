@@ -136,7 +136,7 @@ def scale_probe(params, device, args, graphs=64):
     achieved = alg / (step_ms * 1e-3) / 1e9
     return {"workload": f"{graphs} x dense{args.nodes} graphs in one forward (E={E})", "bound": "hbm", "achieved": achieved,
             "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "avg_launch_us": step_ms * 1e3,
-            "algorithmic_bytes_per_launch": alg, "kernel": "mpn_step_persist_kernel (the batch form of the `roofline` kernel)"}
+            "algorithmic_bytes_per_launch": alg, "kernel": "mpn_step_pipe_kernel (the step kernel of graphs / batches beyond 512 nodes; the headline graph runs mpn_step_fast_kernel)"}
 
 
 def _cpu_model():
@@ -580,7 +580,7 @@ def main():
                        "rank_ms_per_step": ({"min": min(rank_ms), "max": max(rank_ms), "all": rank_ms} if rank_ms else None)},
             "roofline": {"bound": "latency" if cache_resident else "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": "mpn_step_pipe_kernel / mpn_step_persist_kernel <FIRST|CLS, MSG> (message-passing step, L-1 launches/forward)",
+                         "kernel": ("mpn_step_fast_kernel" if N <= 512 else "mpn_step_pipe_kernel") + "<FIRST|CLS, MSG> (message-passing step, L-1 launches/forward)",
                          "avg_launch_us": step_ms * 1e3, "rocprof_avg_launch_us": rocprof_us,
                          "algorithmic_bytes_per_launch": alg,
                          "note": "edge state is L2/Infinity-Cache resident at this size: the launch is bounded by its dependent "
