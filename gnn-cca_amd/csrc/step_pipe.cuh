@@ -198,13 +198,21 @@ __global__ __launch_bounds__(256) GNNCCA_FAST_ATTR void mpn_step_pipe_kernel(con
             const int deg = seg_t - seg_s;
             if (p.agg == GNNCCA_AGG_MEAN) v = v / (float)max(deg, 1);
             if (deg == 0) v = 0.f;
-            // projection epilogue (project_node with the bias read through the constant address space)
+            // projection epilogue: project_node's ordered FMA chain (same bits), with h' broadcast through 128 B of LDS -- one
+            // ds_write + eight broadcast ds_read_b128 on the LDS pipe instead of 32 v_readlane on the VALU, which is the unit this
+            // kernel is short of (the row of s_part is this wave's own; LDS operations of a wave execute in order)
             const int o = min(lane, kProjOut - 1);
             float pr = projb_l;
             const float* w = s_proj + o;
+            float* hrow = s_part + wave * kH;
+            if (lane < kH) hrow[lane] = v;
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int c = 0; c < kH; ++c)
-                pr = fmaf(w[c * kProjOut], __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), c)), pr);
+            for (int c4 = 0; c4 < kH / 4; ++c4) {
+                const f32x4 hv = *reinterpret_cast<const f32x4*>(hrow + 4 * c4);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) pr = fmaf(w[(4 * c4 + q) * kProjOut], hv[q], pr);
+            }
             if (lane < kPdStride)
                 p.pd_out[(size_t)node * kPdStride + lane] = pr;
             else if (lane < kProjOut)
