@@ -142,6 +142,7 @@ __global__ __launch_bounds__(256) GNNCCA_FAST_ATTR void mpn_step_pipe_kernel(con
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         GNNCCA_STAMP(p.stamp_slot, sland);
 #endif
+        if (!MSG) hook_fire();   // the message-less last step has registers to spare: its second round's state goes out right away
         if (rb + stride < seg_t)
             compute2(rb, a, rb + stride, b);
         else
@@ -150,14 +151,19 @@ __global__ __launch_bounds__(256) GNNCCA_FAST_ATTR void mpn_step_pipe_kernel(con
     };
     if (base < seg_t) {
         // the SECOND round's target ids are requested before the first round is computed (see mpn_step_fast_kernel)
-        // (Requesting the second round's edge state from INSIDE the first round's arithmetic -- after the edge updates, when the first
-        // pair's operands are dead -- was measured: 133 registers, or 128 with spills at four waves per SIMD, 64 x dense256
-        // 46-47 -> 49-52 us per launch; profiles/r03_logs/r3_ab_hook1.log.)
+        // The second round's edge state is requested from INSIDE the first round's arithmetic (hook_fire in compute2, right after the
+        // edge updates, when the first pair's loaded operands are dead): its HBM round trip runs under the message block instead
+        // of after it.  (First attempt, with three accumulator tiles: 133 registers, 46-47 -> 49-52 us, r3_ab_hook1.log; with two
+        // tiles it fits 127 registers: -1...-5 % on the message steps of 64 x dense256 / 200 x dense256, r3_ab_hook3.log.)
         const int base2 = base + 2 * stride;
-        Chunk n0, n1;
+        Chunk& n0 = hook_a;
+        Chunk& n1 = hook_b;
+        hook_stride = stride;
+        const bool use_hook = !PD_LDS && base2 < seg_t && base + stride < seg_t && !(p.diag & 4);   // (diag bit 2: A/B without it)
         if (!PD_LDS) {
             load_index(base2, n0);
             load_index(base2 + stride, n1);
+            if (use_hook) hook_base = base2;
         }
         round_body(base, c0, c1, 3, 15, 4);
         if (base2 < seg_t) {
@@ -165,8 +171,10 @@ __global__ __launch_bounds__(256) GNNCCA_FAST_ATTR void mpn_step_pipe_kernel(con
                 load_index(base2, n0);
                 load_index(base2 + stride, n1);
             }
-            load_state(base2, n0);
-            load_state(base2 + stride, n1);
+            if (!use_hook) {
+                load_state(base2, n0);
+                load_state(base2 + stride, n1);
+            }
             round_body(base2, n0, n1, 8, 10, 9);
         }
         base += 4 * stride;
@@ -194,7 +202,7 @@ __global__ __launch_bounds__(256) GNNCCA_FAST_ATTR void mpn_step_pipe_kernel(con
             }
         }
         GNNCCA_STAMP(p.stamp_slot, 6);
-        if (active && sub == 0) {
+        if (active && sub == 0 && !(p.diag & 2)) {   // (diag bit 1: timing-only run without the projection epilogue)
             const int deg = seg_t - seg_s;
             if (p.agg == GNNCCA_AGG_MEAN) v = v / (float)max(deg, 1);
             if (deg == 0) v = 0.f;
