@@ -659,3 +659,41 @@ def test_non_finite_inputs_stay_inside_their_graph():
     for c, d in zip(clean, dirty):
         assert torch.equal(c[:e_per], d[:e_per]) and torch.equal(c[2 * e_per:], d[2 * e_per:])   # graphs 0 and 2: untouched
     # (graph 1 itself: unspecified -- the kernels' fmaxf / integer-max ReLUs swallow some NaNs that torch would propagate)
+
+
+@pytest.mark.parametrize("kind", ["ragged", "ragged_unsorted", "regular", "empty_tail"])
+def test_ragged_batches_whose_edge_count_is_a_multiple_of_the_node_count(kind):
+    """Batches beyond 1024 nodes (gather table in HBM, buffer-addressed step kernel) with E = 20 N but out-degrees 10 and 30 (and a
+    shuffled edge list; and trailing nodes without edges; and the truly regular case): nothing may be inferred from E / N.  (A form
+    of the step kernel that requested its first round on the assumption "every degree = E / N" and checked it afterwards was
+    built against this test and measured: no gain, profiles/r03_logs/r3_ab_spec1.log; not kept.)  Against the traced forward
+    (general kernel) bit for bit, and against the oracle."""
+    params, arch, sd = _default_model(1.0 / 20)
+    rng = np.random.default_rng(31)
+    n = 2048
+    if kind == "regular":
+        deg = np.full(n, 20)
+    elif kind == "empty_tail":
+        deg = np.concatenate([np.full(n // 2, 40), np.zeros(n - n // 2, dtype=np.int64)])
+    else:
+        deg = np.where(np.arange(n) % 2 == 0, 10, 30)
+    rows = np.repeat(np.arange(n), deg)
+    cols = rng.integers(0, n, size=rows.size)
+    assert rows.size % n == 0
+    ei = np.stack([rows, cols]).astype(np.int64)
+    if kind == "ragged_unsorted":
+        ei = ei[:, rng.permutation(ei.shape[1])]
+    x = rng.standard_normal((n, 2048)).astype(np.float32)
+    x /= np.linalg.norm(x, axis=0, keepdims=True)
+    ea = rng.random((ei.shape[1], 4)).astype(np.float32)
+    m = build(params, arch, sd)
+    d = Data(torch.from_numpy(x).cuda(), torch.from_numpy(ei).cuda(), torch.from_numpy(ea).cuda())
+    with torch.no_grad():
+        fast = [t.clone() for t in m(d)["classified_edges"]]
+        traced = m(d, trace={})["classified_edges"]
+    for a, b in zip(fast, traced):
+        assert torch.equal(a, b), kind
+    ref = NumpyOracle(params, arch, sd, np.float32).forward(x, ei, ea)
+    for a, r in zip(fast, ref):
+        assert np.abs(a.cpu().numpy() - r).max() <= TOL_TIGHT * 2, kind
+    assert m.graph_flags() == (1 if kind == "ragged_unsorted" else 0)
