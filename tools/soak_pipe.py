@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Soak of the round-3 step kernel (mpn_step_pipe_kernel: graphs and batches beyond 512 nodes) against the CPU oracle on the GPU box:
+random RAGGED graphs with 513...6000 nodes -- out-degrees from 0 to several hundred (chunk boundaries 63/64/65, 127/128/129, 255...257
+included), sorted and shuffled edge lists, sum and mean aggregation, fp32 and bf16 edge state, L = 1...4 -- plus the bitwise
+traced == untraced property on every third graph.   usage: python3 tools/soak_pipe.py [n_graphs]"""
+import copy, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, torch
+from conftest import GOLDEN_DIR
+from oracle.mpn_oracle import NumpyOracle, load_case
+from gnn_cca_amd import MOTMPNet
+
+class D: pass
+params, arch, sd, _ = load_case(os.path.join(GOLDEN_DIR, "n8_sum.npz"))
+n_graphs = int(sys.argv[1]) if len(sys.argv) > 1 else 240
+rng = np.random.default_rng(2026)
+t0 = time.time(); worst = {"fp32": 0.0, "bf16": 0.0}; checked = 0; bitwise = 0
+models = {}
+for it in range(n_graphs):
+    agg = ["sum", "mean"][it % 2]; L = 1 + it % 4; ncls = min(L, 1 + it % 3); bf16 = it % 5 == 4
+    key = (agg, L, ncls)
+    if key not in models:
+        p = copy.deepcopy(params); p.update(node_agg_fn=agg, num_enc_steps=L, num_class_steps=ncls)
+        s = dict(sd)
+        for k in list(s):
+            if k.startswith("MPNet.node_model"): s[k] = (s[k] * np.float32(0.05 if agg == "sum" else 4.0)).astype(np.float32)
+        m = MOTMPNet(copy.deepcopy(p), None, arch); m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in s.items()})
+        models[key] = (m.cuda().eval(), NumpyOracle(p, arch, s, np.float32))
+    m, orc = models[key]
+    m.edge_state_dtype = "bf16" if bf16 else "fp32"
+    n = int(rng.integers(513, 6000))
+    special = np.array([0, 1, 63, 64, 65, 127, 128, 129, 255, 256, 257, 300, 511, 513])
+    deg = np.where(rng.random(n) < 0.15, rng.choice(special, size=n), rng.integers(0, 40, size=n))
+    if it % 7 == 0: deg[rng.integers(0, n)] = 3000          # one hub
+    if it % 11 == 0: deg[n // 2:] = 0                       # trailing nodes without edges
+    rows = np.repeat(np.arange(n), deg); cols = rng.integers(0, n, size=rows.size)
+    ei = np.stack([rows, cols]).astype(np.int64)
+    if it % 4 == 3: ei = ei[:, rng.permutation(ei.shape[1])]
+    x = (rng.standard_normal((n, 64)) * 0.3).astype(np.float32); ea = rng.random((ei.shape[1], 4)).astype(np.float32)
+    ref = orc.forward(x, ei, ea)
+    d = D(); d.x, d.edge_index, d.edge_attr = torch.from_numpy(x).cuda(), torch.from_numpy(ei).cuda(), torch.from_numpy(ea).cuda()
+    with torch.no_grad():
+        out = [t.clone() for t in m(d)["classified_edges"]]
+        if it % 3 == 0 and not bf16:
+            tr = m(d, trace={})["classified_edges"]
+            assert all(torch.equal(a, b) for a, b in zip(out, tr)), ("traced != untraced", it, n, ei.shape[1])
+            bitwise += 1
+    scale = max(1.0, max(float(np.abs(r).max()) for r in ref))
+    err = max(float(np.abs(o.cpu().numpy() - r).max()) for o, r in zip(out, ref)) / scale
+    tol = 2e-4 if bf16 else 2e-5
+    assert np.isfinite(err) and err <= tol, (it, agg, L, bf16, n, ei.shape[1], err)
+    worst["bf16" if bf16 else "fp32"] = max(worst["bf16" if bf16 else "fp32"], err)
+    checked += 1
+    if it % 40 == 39: print(f"{checked} graphs, worst rel err fp32 {worst['fp32']:.2e} bf16-state {worst['bf16']:.2e}, {time.time() - t0:.0f} s", flush=True)
+print(f"soak_pipe: {checked} graphs ok ({bitwise} also bitwise traced == untraced), worst rel err fp32 {worst['fp32']:.2e}, bf16 edge state {worst['bf16']:.2e}, {time.time() - t0:.0f} s")
