@@ -62,9 +62,10 @@ __device__ void plan_sort_fallback(const long long* __restrict__ ei, int E, int 
 }
 
 // Edges one plan workgroup (256 threads) covers: one per thread on small graphs (the plan rides in the latency-bound
-// GEMM launch there), four per thread from 2^20 edges on (four independent 8-byte loads in flight per thread and a
-// quarter of the workgroups: the thread-per-edge form was bound by per-workgroup latency, 2.8 TB/s).
-__host__ __device__ inline int plan_edges_per_block(int E) { return E >= (1 << 20) ? 1024 : 256; }
+// GEMM launch there), four per thread from 2^19 edges on (a quarter of the workgroups and, with aligned rows, the pair form of
+// plan_block: the thread-per-edge form was bound by per-workgroup latency, 2.8 TB/s).  Round 3 lowered the threshold from 2^20:
+// the per-GPU share of BASELINE config 4 (64 x dense128, E = 1 040 384) sat just below it.
+__host__ __device__ inline int plan_edges_per_block(int E) { return E >= (1 << 19) ? 1024 : 256; }
 __host__ __device__ inline int plan_num_blocks(int E) { return (E + plan_edges_per_block(E) - 1) / plan_edges_per_block(E); }
 // The plan launch of big batches takes plan_block's pair form when the index rows allow 16-byte loads: kPlanSpan 1024-edge blocks
 // per workgroup.  (Measured with 4 blocks = 4096 edges per workgroup, every load in flight before the first use: 64 x dense256
