@@ -126,7 +126,11 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
         const int ks = g == 0 ? ws.ksplit : 1;
         int kslice = (K + ks - 1) / ks;
         kslice = (kslice + 63) / 64 * 64;
-        const bool split = g == 0 && hdr.enc_w3 != 0 && N >= 4096 && (reinterpret_cast<uintptr_t>(cur_in) & 15) == 0;
+        // From 1024 nodes on the first encoder layer runs on the split-bf16 MFMA GEMM (round 3 lowered this from 4096: the f32 MFMA
+        // GEMM with the plan riding along took 19.5 us at dense1024 and 43 us at dense2048, the 128-row split kernel + a plan launch
+        // 11.0 + 5.8 and 17.4 + 17.1; profiles/r03_logs/r3_gemm_split_min.log)
+        static const int split_min = diag_env("GNNCCA_GEMM_SPLIT_MIN") ? std::atoi(diag_env("GNNCCA_GEMM_SPLIT_MIN")) : 1024;   // diagnostics
+        const bool split = g == 0 && hdr.enc_w3 != 0 && N >= split_min && (reinterpret_cast<uintptr_t>(cur_in) & 15) == 0;
         EncPlanParams ep;
         std::memset(&ep, 0, sizeof(ep));
         ep.in = cur_in;

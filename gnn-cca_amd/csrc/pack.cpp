@@ -624,8 +624,8 @@ Workspace carve(const gnncca_mpn_dims* d, int64_t n, int64_t e) {
     const size_t row_tiles = (N + 31) / 32;
     int ks = 1;
     while (ks < 32 && row_tiles * (size_t)ks < 512 && k0 / (ks * 2) >= 64) ks *= 2;
-    // batches run the split-bf16 GEMM with 128-row workgroups: room for its split-K factor too
-    if (N >= 4096)
+    // from 1024 nodes on the split-bf16 GEMM runs with 128-row workgroups: room for its split-K factor too
+    if (N >= 1024)
         while (ks < 8 && ((N + 127) / 128) * (size_t)ks < 512 && k0 / (ks * 2) >= 64) ks *= 2;
     if (N >= 4096) ks = std::max(ks, enc_lds_ksplit((int64_t)N, k0));  // room for the slabs of the 256-row GEMM's choice
     w.ksplit = ks;
