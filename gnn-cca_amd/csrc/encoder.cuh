@@ -113,15 +113,26 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 //   bottom           : next W -> the other LDS stage, next x -> A fragments (loads had the whole middle to land)
 // Workgroup = 4 waves = 128 rows.  Split-K over blockIdx.y for mid-size batches.
 // ------------------------------------------------------------------------------------------------------------
+// Grid: 1-D.  Workgroup b < rb * ks is GEMM tile (row block b % rb, k slice b / rb); the workgroups beyond run the graph plan
+// (plan.cuh) when `plan.E > 0`: on graphs of 1024...4095 nodes the plan rides in this launch as it does in enc_gemm_plan_kernel's
+// below 1024 (a launch of its own cost 4.5-17 us there).
 template <bool P3>
 __global__ __launch_bounds__(256) void enc_gemm_split_direct_kernel(const float* __restrict__ x,
                                                                     const unsigned short* __restrict__ w3,
-                                                                    float* __restrict__ out, int M, int K, int O, int kslice) {
+                                                                    float* __restrict__ out, int M, int K, int O, int kslice, int rb, int ks_n,
+                                                                    const EncPlanParams plan) {
     constexpr int BN = 128, BK = 32, LDK = 40;
     __shared__ __attribute__((aligned(16))) __bf16 wsm[2][3][BN][LDK];
+    __shared__ unsigned s_plan_fl;
+    if ((int)blockIdx.x >= rb * ks_n) {
+        plan_block((int)blockIdx.x - rb * ks_n, plan.ei, plan.E, plan.N, plan.seg_ptr, plan.col32, plan.blockflags, &s_plan_fl, plan.ell_S,
+                   plan.plan_span);
+        return;
+    }
+    const int bx = (int)blockIdx.x % rb, by = (int)blockIdx.x / rb;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int row0 = blockIdx.x * 128 + wave * 32;
-    const int kbeg = blockIdx.y * kslice;
+    const int row0 = bx * 128 + wave * 32;
+    const int kbeg = by * kslice;
     const size_t plane = (size_t)O * BK;  // w3 is [K/32][3 pieces][O][32]: a chunk's 24 KB are contiguous
     const int h = lane >> 5;
     const float* __restrict__ xrow = x + (size_t)min(row0 + (lane & 31), M - 1) * K + kbeg + 8 * h;
@@ -204,7 +215,7 @@ __global__ __launch_bounds__(256) void enc_gemm_split_direct_kernel(const float*
         }
         __syncthreads();
     }
-    float* __restrict__ dst = out + (size_t)blockIdx.y * M * O;
+    float* __restrict__ dst = out + (size_t)by * M * O;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         const int col = c * 32 + (lane & 31);

@@ -245,12 +245,23 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
             } else {
                 // 128-row workgroups (a wave = 32 rows x 128 columns); split-K until >= 512 workgroups are in flight
                 while (ks_split < ws.ksplit && ((N + 127) / 128) * ks_split < 512 && (K / (ks_split * 2)) % 32 == 0) ks_split *= 2;
+                const int rb = (N + 127) / 128;
+                // graphs below 4096 nodes: the plan rides in this launch (extra workgroups beyond the GEMM tiles)
+                EncPlanParams pl = ep;
+                int ride = 0;
+                if (N < 4096 && plan_blocks > 0) {
+                    pl.plan_span = 0;   // one flag word per plan block, narrow or pair form by the edge count and alignment
+                    if (plan_span(edge_index, E) == 1) pl.plan_span = 1;
+                    ride = plan_blocks;
+                    plan_launched = true;
+                } else {
+                    pl.E = 0;
+                }
+                const dim3 dgrid((unsigned)(rb * ks_split + ride));
                 if (split3)
-                    GNNCCA_LAUNCH(enc_gemm_split_direct_kernel<true>, dim3((N + 127) / 128, ks_split), dim3(256), 0, st, cur_in, w3, part,
-                                  N, K, O, K / ks_split);
+                    GNNCCA_LAUNCH(enc_gemm_split_direct_kernel<true>, dgrid, dim3(256), 0, st, cur_in, w3, part, N, K, O, K / ks_split, rb, ks_split, pl);
                 else
-                    GNNCCA_LAUNCH(enc_gemm_split_direct_kernel<false>, dim3((N + 127) / 128, ks_split), dim3(256), 0, st, cur_in, w3, part,
-                                  N, K, O, K / ks_split);
+                    GNNCCA_LAUNCH(enc_gemm_split_direct_kernel<false>, dgrid, dim3(256), 0, st, cur_in, w3, part, N, K, O, K / ks_split, rb, ks_split, pl);
             }
             HIP_TRY(hipGetLastError());
             PROF_MARK(GNNCCA_K_ENC_GEMM);
