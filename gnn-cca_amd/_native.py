@@ -53,6 +53,7 @@ class Dropout(C.Structure):
 
 OPT_EDGE_STATE_BF16 = 1
 OPT_ENC_SPLIT3 = 2
+OPT_ENC_UNSPLIT = 4
 BWD_GRADS_ZEROED = 1
 
 

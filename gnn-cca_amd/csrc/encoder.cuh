@@ -568,27 +568,32 @@ __global__ __launch_bounds__(512) void enc_gemm_split_lds_kernel(const float* __
             }
         }
     __syncthreads();
-    // layer 2: wave w owns rows [32 w, 32 w + 32); lane (m, h) feeds k = 64 c + 32 h + s at step s of chunk c to BOTH operands
+    // layer 2: wave w owns rows [32 w, 32 w + 32).  The arithmetic of enc_finish_32rows, written for a wave that has its 32 rows to
+    // itself: four partial tiles d_q over k in [32 q, 32 q + 32) (lane (m, h) feeds k = 32 q + 16 h + s at step s to both operands),
+    // summed ((d0 + d1) + d2) + d3 -- so that a node's h0 is bit for bit what the 32-row kernel and the split-K tail give it
     float* hblk = H1 + (size_t)wave * 32 * LD1;
     f32x16 d;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) d[i] = 0.f;
     {
-        const float* hrow = hblk + l32 * LD1 + 32 * h;
-        const float* w2row = fp.W2 + (size_t)l32 * 128 + 32 * h;
+        f32x16 dq[4];
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            float av[32], bv[32];
+        for (int q = 0; q < 4; ++q) {
+            const float* hrow = hblk + l32 * LD1 + 32 * q + 16 * h;
+            const float* w2row = fp.W2 + (size_t)l32 * 128 + 32 * q + 16 * h;
+            float av[16], bv[16];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const f32x4 a4 = *reinterpret_cast<const f32x4*>(hrow + 64 * c + 4 * j);
-                const f32x4 b4 = *reinterpret_cast<const f32x4*>(w2row + 64 * c + 4 * j);
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 a4 = *reinterpret_cast<const f32x4*>(hrow + 4 * j);
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(w2row + 4 * j);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) av[4 * j + q] = a4[q], bv[4 * j + q] = b4[q];
+                for (int t = 0; t < 4; ++t) av[4 * j + t] = a4[t], bv[4 * j + t] = b4[t];
             }
 #pragma unroll
-            for (int s = 0; s < 32; ++s) d = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[s], d, 0, 0, 0);
+            for (int i = 0; i < 16; ++i) dq[q][i] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) dq[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[s], dq[q], 0, 0, 0);
         }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) d[i] = ((dq[0][i] + dq[1][i]) + dq[2][i]) + dq[3][i];
     }
     // h0 in accumulator layout: lane = channel n, register i = row (i & 3) + 8 (i >> 2) + 4 h of the wave's 32
     const float bias2 = fp.b2[l32];
@@ -916,6 +921,107 @@ __global__ __launch_bounds__(256) void enc_tail_fast_kernel(const TailParams p) 
 
 
 // ------------------------------------------------------------------------------------------------------------
+// The rest of encoder.node_mlp for 32 nodes whose first-layer activations h1 = [ReLU](x W1^T + b1) sit in LDS
+// ([32][132] floats): layer 2 (128 -> 32) and the step-1 projections (32 -> 48) on v_mfma_f32_32x32x2_f32 (exact
+// fp32 FMA chains).  256 threads; the caller's barrier has published s_h1.
+//   layer 2 : wave w takes k in [32 w, 32 w + 32) (lane (m, h) feeds k = 32 w + 16 h + s at step s to both
+//             operands), the four partial tiles are summed in the fixed order ((d0 + d1) + d2) + d3;
+//   project : waves 0 and 1, column tile = wave, lane (m, h) feeds k = 16 h + s.
+// ONE definition for the split-K tail (enc_tail_mfma_kernel), the 32-row fused GEMM below and -- as the same
+// arithmetic written for a wave that owns its 32 rows alone -- the 256-row GEMM's epilogue: a node's h0 and
+// projections are a function of its h1 row only, bit for bit, whichever of the three produced it.
+// Replaces the second nn.Linear of encoder.node_mlp (models/mpn.py:131) and the x[row] / x[col] gathers of step 1.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int kFinLD1 = 132, kFinLDP = 33, kFinLD0 = 36;
+
+struct EncFinishOut {
+    const float* W2rm;     // [32][128] row-major [out][in]
+    const float* b2;       // [32]
+    const float* projwT;   // [32][48] k-major
+    const float* projb;    // [48]
+    float* h0;             // [N][32]
+    float* trace_h;        // [N][32] or null
+    float* pd_out;         // [N][8]
+    float* psq_out;        // [N][40]
+};
+
+__device__ __forceinline__ void enc_finish_32rows(const float* s_h1, float* s_dp, float* s_h0, const EncFinishOut& o, int node0, int N) {
+    constexpr int F = 128, LD1 = kFinLD1, LDP = kFinLDP, LD0 = kFinLD0;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l32 = lane & 31, h = lane >> 5;
+    {
+        const float* hr = s_h1 + l32 * LD1 + 32 * wave + 16 * h;
+        const float* wr = o.W2rm + (size_t)l32 * F + 32 * wave + 16 * h;
+        float av[16], bv[16];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 a4 = *reinterpret_cast<const f32x4*>(hr + 4 * j);
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(wr + 4 * j);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) av[4 * j + q] = a4[q], bv[4 * j + q] = b4[q];
+        }
+        f32x16 d;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) d[i] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) d = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[s], d, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s_dp[(wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * h) * LDP + l32] = d[i];
+    }
+    __syncthreads();
+    {
+        const int r = tid >> 3, c4 = (tid & 7) * 4;
+        const int node = node0 + r;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c = c4 + q;
+            float v = s_dp[r * LDP + c];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) v += s_dp[(w * 32 + r) * LDP + c];
+            v = fmaxf(v + o.b2[c], 0.f);
+            s_h0[r * LD0 + c] = v;
+            if (node < N) {
+                o.h0[(size_t)node * kH + c] = v;
+                if (o.trace_h) o.trace_h[(size_t)node * kH + c] = v;
+            }
+        }
+    }
+    __syncthreads();
+    if (wave < 2) {
+        const int slot = 32 * wave + l32;
+        const bool on = slot < kProjOut;
+        float a2[16], b2[16];
+        const float* hr = s_h0 + l32 * LD0 + 16 * h;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 a4 = *reinterpret_cast<const f32x4*>(hr + 4 * j);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a2[4 * j + q] = a4[q];
+        }
+#pragma unroll
+        for (int s = 0; s < 16; ++s) b2[s] = on ? o.projwT[(16 * h + s) * kProjOut + slot] : 0.f;
+        f32x16 pacc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) pacc[i] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[s], b2[s], pacc, 0, 0, 0);
+        const float pb = on ? o.projb[slot] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int node = node0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+            if (node < N && on) {
+                const float v = pacc[i] + pb;
+                if (slot < kPdStride)
+                    o.pd_out[(size_t)node * kPdStride + slot] = v;
+                else
+                    o.psq_out[(size_t)node * kPsQStride + slot - kPdStride] = v;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // Encoder tail on the matrix pipe, for batches whose first GEMM ran split-K (4096 <= N, partial slabs in HBM): a
 // 256-thread workgroup finishes 32 nodes.
 //   1. every thread sums its 16 columns of one node over the ks slabs (whole 512-B rows, four 16-B loads per slab, all
@@ -932,8 +1038,7 @@ __global__ __launch_bounds__(256) void enc_tail_mfma_kernel(const TailParams p, 
     __shared__ __attribute__((aligned(16))) float s_h1[32 * LD1];
     __shared__ __attribute__((aligned(16))) float s_dp[4 * 32 * LDP];
     __shared__ __attribute__((aligned(16))) float s_h0[32 * LD0];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tid = threadIdx.x;
     const float* __restrict__ blob = p.blob;
     if (blockIdx.x == gridDim.x - 1) {  // the plan workgroup: fold the per-block findings, repair if needed
         __shared__ unsigned smem[1024];
@@ -941,7 +1046,6 @@ __global__ __launch_bounds__(256) void enc_tail_mfma_kernel(const TailParams p, 
         return;
     }
     const int node0 = blockIdx.x * 32;
-    const int l32 = lane & 31, h = lane >> 5;
     // ---- 1. slab sum + bias + ReLU -> LDS -------------------------------------------------------------------------------------
     {
         // thread (node nl, t = tid & 7) owns the columns 32 j + 4 t .. + 3, j = 0..3: for a fixed j the eight threads of a row read
@@ -976,77 +1080,11 @@ __global__ __launch_bounds__(256) void enc_tail_mfma_kernel(const TailParams p, 
         }
     }
     __syncthreads();
-    // ---- 2. layer 2, k split over the four waves: lane (m, h) feeds k = 32 w + 16 h + s at step s to both operands -----------
-    {
-        const float* hr = s_h1 + l32 * LD1 + 32 * wave + 16 * h;
-        const float* wr = W2rm + (size_t)l32 * F + 32 * wave + 16 * h;
-        float av[16], bv[16];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const f32x4 a4 = *reinterpret_cast<const f32x4*>(hr + 4 * j);
-            const f32x4 b4 = *reinterpret_cast<const f32x4*>(wr + 4 * j);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) av[4 * j + q] = a4[q], bv[4 * j + q] = b4[q];
-        }
-        f32x16 d;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) d[i] = 0.f;
-#pragma unroll
-        for (int s = 0; s < 16; ++s) d = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[s], d, 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) s_dp[(wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * h) * LDP + l32] = d[i];
-    }
-    __syncthreads();
-    {
-        const int r = tid >> 3, c4 = (tid & 7) * 4;
-        const int node = node0 + r;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int c = c4 + q;
-            float v = s_dp[r * LDP + c];
-#pragma unroll
-            for (int w = 1; w < 4; ++w) v += s_dp[(w * 32 + r) * LDP + c];
-            v = fmaxf(v + blob[p.off_last_b + c], 0.f);
-            s_h0[r * LD0 + c] = v;
-            if (node < p.N) {
-                p.h0[(size_t)node * kH + c] = v;
-                if (p.trace_h) p.trace_h[(size_t)node * kH + c] = v;
-            }
-        }
-    }
-    __syncthreads();
-    // ---- 3. projections: column tile t = wave (slots 32 t .. 32 t + 31), lane (m, h) feeds k = 16 h + s ---------------------------
-    if (wave < 2) {
-        const int slot = 32 * wave + l32;
-        const bool on = slot < kProjOut;
-        float a2[16], b2[16];
-        const float* hr = s_h0 + l32 * LD0 + 16 * h;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const f32x4 a4 = *reinterpret_cast<const f32x4*>(hr + 4 * j);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) a2[4 * j + q] = a4[q];
-        }
-#pragma unroll
-        for (int s = 0; s < 16; ++s) b2[s] = on ? blob[p.off_projwT + (16 * h + s) * kProjOut + slot] : 0.f;
-        f32x16 pacc;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) pacc[i] = 0.f;
-#pragma unroll
-        for (int s = 0; s < 16; ++s) pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[s], b2[s], pacc, 0, 0, 0);
-        const float pb = on ? blob[p.off_projb + slot] : 0.f;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int node = node0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-            if (node < p.N && on) {
-                const float v = pacc[i] + pb;
-                if (slot < kPdStride)
-                    p.pd_out[(size_t)node * kPdStride + slot] = v;
-                else
-                    p.psq_out[(size_t)node * kPsQStride + slot - kPdStride] = v;
-            }
-        }
-    }
+    // ---- 2. / 3. layer 2 with k split over the four waves, projections by waves 0 and 1 (enc_finish_32rows) -------------------------
+    EncFinishOut fo;
+    fo.W2rm = W2rm, fo.b2 = blob + p.off_last_b, fo.projwT = blob + p.off_projwT, fo.projb = blob + p.off_projb;
+    fo.h0 = p.h0, fo.trace_h = p.trace_h, fo.pd_out = p.pd_out, fo.psq_out = p.psq_out;
+    enc_finish_32rows(s_h1, s_dp, s_h0, fo, node0, p.N);
 }
 
 

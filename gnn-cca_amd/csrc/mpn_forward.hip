@@ -22,6 +22,7 @@
 #include "wave_reduce.cuh"
 #include "plan.cuh"
 #include "encoder.cuh"
+#include "enc_rows32.cuh"
 #include "msg_bf16.cuh"
 #include "step_general.cuh"
 #include "step_fast.cuh"
@@ -166,9 +167,18 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
                                  !d->reattach_nodes && hdr.proj_wT != 0;
             const bool use_lds = N >= lds_min && O == 128 && !force_direct;
             if (use_lds) ks_split = std::min(enc_lds_ksplit(N, K), ws.ksplit);
+            // mid-size batches, where the 256-row form would run split-K: 32-row workgroups, un-split, fused epilogue (enc_rows32.cuh)
+            // GNNCCA_OPT_ENC_UNSPLIT: batches of >= 4096 nodes never split K -- where the 256-row form would, 32-row workgroups run
+            // un-split with the same fused epilogue (enc_rows32.cuh), so a node's encoder output is bit for bit independent of the batch
+            // around it (a shard of a sharded batch reproduces the union's logits exactly).  Not the default: every 32-row workgroup
+            // streams all of W's pieces from L2 (N = 8192: 43.5 us against 29 + 11 for split-K + tail; profiles/r03_logs/r3_r32_ab1.log)
+            static const int r32_nst = diag_env("GNNCCA_GEMM_R32_NST") ? std::atoi(diag_env("GNNCCA_GEMM_R32_NST")) : 0;
+            const bool use_r32 = (options & GNNCCA_OPT_ENC_UNSPLIT) != 0 && fusable && O == 128 && K % 256 == 0 && !force_direct && N >= 4096 &&
+                                 !(use_lds && ks_split == 1);
+            if (use_r32) ks_split = 1;
             // un-split and the shipped encoder shape (2048 -> 128 -> 32, no reattach): the rest of the encoder, the step-1
             // projections and the plan fold run in the GEMM's epilogue, on the tile while it is on chip
-            fused_tail = use_lds && fusable && ks_split == 1;
+            fused_tail = (use_lds && fusable && ks_split == 1) || use_r32;
             EncFuseParams fp;
             std::memset(&fp, 0, sizeof(fp));
             if (fused_tail) {
@@ -217,9 +227,24 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
                     HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsGemmBytes));
                 attr_dev = dev;
             }
-            if (use_lds) {
+            if (use_r32) {
+                const dim3 rgrid((unsigned)((N + 31) / 32) + 1);
+                const int nst = r32_nst == 4 || r32_nst == 8 ? r32_nst : ((N + 31) / 32 <= 256 ? 8 : 4);
+                if (nst == 8 && split3)
+                    GNNCCA_LAUNCH((enc_gemm_rows32_fused_kernel<true, 8>), rgrid, dim3(256), 0, st, cur_in, w3, N, K, fp);
+                else if (nst == 8)
+                    GNNCCA_LAUNCH((enc_gemm_rows32_fused_kernel<false, 8>), rgrid, dim3(256), 0, st, cur_in, w3, N, K, fp);
+                else if (split3)
+                    GNNCCA_LAUNCH((enc_gemm_rows32_fused_kernel<true, 4>), rgrid, dim3(256), 0, st, cur_in, w3, N, K, fp);
+                else
+                    GNNCCA_LAUNCH((enc_gemm_rows32_fused_kernel<false, 4>), rgrid, dim3(256), 0, st, cur_in, w3, N, K, fp);
+            } else if (use_lds) {
                 // 256-row workgroups, both operands through LDS (144 KB: one workgroup per CU, 8 waves); split-K by whole
                 // rounds of 256 workgroups (internal.h: enc_lds_ksplit)
+                // (The plan does not ride in this launch.  As extra workgroups: every workgroup reserves the 144 KB of dynamic LDS, so the
+                // plan's queue one per CU behind the GEMM tiles, 29 -> 45 us at N = 8192.  Inside the GEMM waves, a 1024-edge block per wave
+                // under the first operands' round trip: the block's own two dependent round trips are then exposed in every workgroup,
+                // 29.5 + 6.4 -> 37.6 us.  profiles/r03_logs/r3_ride2.log, r3_ride4.log.)
                 const dim3 fgrid((N + 255) / 256 + 1, 1), sgrid((N + 255) / 256, ks_split);
                 static const bool gemm_pipe = diag_env("GNNCCA_GEMM_NOPIPE") == nullptr;   // diagnostics: A/B against the barrier-per-chunk form (encoder.cuh: PIPE)
                 if (gemm_pipe && fused_tail && split3)
@@ -246,10 +271,11 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
                 // 128-row workgroups (a wave = 32 rows x 128 columns); split-K until >= 512 workgroups are in flight
                 while (ks_split < ws.ksplit && ((N + 127) / 128) * ks_split < 512 && (K / (ks_split * 2)) % 32 == 0) ks_split *= 2;
                 const int rb = (N + 127) / 128;
-                // graphs below 4096 nodes: the plan rides in this launch (extra workgroups beyond the GEMM tiles)
+                // the plan rides in this launch (extra workgroups beyond the GEMM tiles)
                 EncPlanParams pl = ep;
                 int ride = 0;
-                if (N < 4096 && plan_blocks > 0) {
+                static const bool no_ride_d = diag_env("GNNCCA_NO_RIDE") != nullptr;   // diagnostics: A/B against a plan launch of its own
+                if (plan_blocks > 0 && (N < 4096 || !no_ride_d)) {
                     pl.plan_span = 0;   // one flag word per plan block, narrow or pair form by the edge count and alignment
                     if (plan_span(edge_index, E) == 1) pl.plan_span = 1;
                     ride = plan_blocks;

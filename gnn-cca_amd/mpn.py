@@ -358,6 +358,10 @@ class MOTMPNet(nn.Module):
         # split-bf16 products of the first encoder layer on batches of >= 4096 nodes: 6 (default, fp32-level accuracy) or 3
         # (GNNCCA_OPT_ENC_SPLIT3: ~2^-17 relative on that layer, logits measured 1.5e-7 off; the GEMM runs 19-28 % faster)
         self.encoder_products = 6
+        # True: forwards over >= 4096 nodes never split K in the first encoder layer (GNNCCA_OPT_ENC_UNSPLIT), so a graph's logits are
+        # bit for bit independent of the batch / shard it is computed in (default False: within rounding, <= 2e-6; the un-split kernel
+        # of mid-size batches is 4-20 % slower on the encoder)
+        self.encoder_unsplit = False
         # train mode: 'auto' = the fused kernels where they apply (the shipped shapes), else the layer-by-layer engine;
         # 'layerwise' / 'fused' force one (set it before the first training forward, or call .train() again)
         self.train_engine = 'auto'
@@ -368,7 +372,8 @@ class MOTMPNet(nn.Module):
         if self.encoder_products not in (3, 6):
             raise ValueError("encoder_products must be 6 or 3")
         return (nat.OPT_EDGE_STATE_BF16 if self.edge_state_dtype == 'bf16' else 0) | \
-               (nat.OPT_ENC_SPLIT3 if self.encoder_products == 3 else 0)
+               (nat.OPT_ENC_SPLIT3 if self.encoder_products == 3 else 0) | \
+               (nat.OPT_ENC_UNSPLIT if self.encoder_unsplit else 0)
 
     # -- construction --------------------------------------------------------------------------------------
     def _build_core_MPNet(self, model_params, encoder_feats_dict):

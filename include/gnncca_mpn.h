@@ -188,6 +188,14 @@ typedef struct gnncca_dropout {
  * leading ones (x0 w0 + x0 w1 + x1 w0): ~2^-17 relative on that layer's pre-activations (encoder output 5e-6 from fp64
  * instead of 3e-7 .. 1e-6), measured logit deviation 1.5e-7 (tolerance 1e-4), GEMM 19-28 % faster.  Off by default. */
 #define GNNCCA_OPT_ENC_SPLIT3 2u
+/* GNNCCA_OPT_ENC_UNSPLIT: a forward over >= 4096 nodes never splits K in that layer.  By default mid-size batches (a few thousand
+ * to a few ten thousand nodes) run it split-K (partial slabs + a tail launch) and the largest ones un-split, so a graph's logits
+ * agree across batch sizes within rounding only (<= 2e-6 asserted, 6e-8 measured).  With this option the mid-size batches take an
+ * un-split 32-row kernel whose per-element arithmetic is the big un-split kernel's: a graph's logits are then BIT FOR BIT
+ * independent of the batch (or the shard of a sharded batch) it is computed in, as long as that batch has >= 4096 nodes.
+ * Price: that kernel streams all of W's pieces from L2 per 32 rows -- encoder 43.5 instead of 40.5 us at 8192 nodes, 87 instead
+ * of 72 us at 16 384.  Off by default. */
+#define GNNCCA_OPT_ENC_UNSPLIT 4u
 GNNCCA_API int gnncca_mpn_forward_ex(const gnncca_mpn_dims* dims, const void* packed_dev, const float* x,
                                      const int64_t* edge_index, const float* edge_attr, int64_t n_nodes,
                                      int64_t n_edges, void* workspace, size_t workspace_bytes, float* logits_out,

@@ -251,6 +251,65 @@ def test_lds_staged_split_gemm_vs_fp64_oracle(n_nodes):
         assert np.abs(o.cpu().numpy() - r).max() <= TOL_TIGHT * 2
 
 
+@pytest.mark.parametrize("n_nodes,products", [(4096 + 3, 6), (8192, 6), (8192 + 5, 6), (16384 + 77, 6), (30000, 6), (8192 + 5, 3)])
+def test_unsplit_32_row_encoder_vs_fp64_oracle(n_nodes, products):
+    """`model.encoder_unsplit = True`: mid-size batches take the un-split 32-row split-bf16 GEMM with the fused epilogue
+    (csrc/enc_rows32.cuh; <= 256 workgroups: eight W stages per wave, more: four; ragged N exercises the clamped rows).  Encoder
+    output against an fp64 evaluation, logits against the fp32 oracle, as for the other GEMMs."""
+    params, arch, sd = _default_model(1.0)
+    rng = np.random.default_rng(n_nodes)
+    x = rng.standard_normal((n_nodes, 2048)).astype(np.float32)
+    x /= np.linalg.norm(x, axis=0, keepdims=True)
+    src = np.repeat(np.arange(n_nodes), 2)
+    dst = (src + np.tile([1, 5], n_nodes)) % n_nodes
+    ei = np.stack([src, dst]).astype(np.int64)
+    ea = rng.random((ei.shape[1], 4)).astype(np.float32)
+    orc = NumpyOracle(params, arch, sd, np.float32)
+    tr = {}
+    ref = orc.forward(x, ei, ea, tr)
+    m = build(params, arch, sd)
+    m.encoder_unsplit = True
+    m.encoder_products = products
+    d = Data(torch.from_numpy(x).cuda(), torch.from_numpy(ei).cuda(), torch.from_numpy(ea).cuda())
+    trace = {}
+    with torch.no_grad():
+        out = [t.clone() for t in m(d)["classified_edges"]]
+        m(d, trace=trace)
+    h64 = NumpyOracle(params, arch, sd, np.float64)._mlp("encoder.node_mlp", x.astype(np.float64))
+    err_gpu = np.abs(trace["h_enc"].cpu().numpy() - h64).max()
+    err_ref = np.abs(tr["h_enc"] - h64).max()
+    if products == 6:
+        assert err_gpu <= max(4 * err_ref, 2e-7), (err_gpu, err_ref)
+    else:
+        assert err_gpu <= 4e-5 * max(1.0, float(np.abs(h64).max())), err_gpu
+    for o, r in zip(out, ref):
+        assert np.abs(o.cpu().numpy() - r).max() <= TOL_TIGHT * 2
+
+
+def test_unsplit_encoder_launch_repairs_unsorted_plan():
+    """The 32-row un-split launch folds the plan's findings in its extra workgroup, as the 256-row fused launch does: a SHUFFLED
+    sparse edge list over 9000 nodes comes back in the caller's edge order."""
+    params, arch, sd = _default_model(1.0)
+    n_nodes = 9000
+    rng = np.random.default_rng(98)
+    x = rng.standard_normal((n_nodes, 2048)).astype(np.float32)
+    x /= np.linalg.norm(x, axis=0, keepdims=True)
+    src = np.repeat(np.arange(n_nodes), 2)
+    dst = (src + np.tile([1, 5], n_nodes)) % n_nodes
+    perm = rng.permutation(src.shape[0])
+    ei = np.ascontiguousarray(np.stack([src, dst])[:, perm]).astype(np.int64)
+    ea = rng.random((ei.shape[1], 4)).astype(np.float32)
+    ref = NumpyOracle(params, arch, sd, np.float32).forward(x, ei, ea)
+    m = build(params, arch, sd)
+    m.encoder_unsplit = True
+    with torch.no_grad():
+        out = m(Data(torch.from_numpy(x).cuda(), torch.from_numpy(ei).cuda(), torch.from_numpy(ea).cuda()))["classified_edges"]
+    torch.cuda.synchronize()
+    assert m.graph_flags() & 1
+    for o, r in zip(out, ref):
+        assert np.abs(o.cpu().numpy() - r).max() <= TOL_TIGHT * 2
+
+
 @pytest.mark.parametrize("name", ["dense64", "terrace32", "union3", "ragged_mean", "dense24_shuffled", "steps_L8", "bdnet512"])
 def test_bf16_edge_state_option(name):
     """GNNCCA_OPT_EDGE_STATE_BF16: edge latents stored as bf16 between steps, arithmetic fp32.  The logits must stay
@@ -399,6 +458,43 @@ def test_padded_layout_unsorted_rows_fall_back():
     assert m.graph_flags() & 1
     for o, r in zip(out, ref):
         assert np.abs(o.cpu().numpy() - r).max() <= TOL_TIGHT * 4
+
+
+@pytest.mark.parametrize("case", ["sorted", "shuffled", "odd_E", "bad_index", "ragged"])
+def test_plan_on_mid_size_batches(case):
+    """Batches of 6144 ... 38 399 nodes with >= 2^19 edges: the first encoder layer runs split-K on the 256-row GEMM, the graph plan
+    takes the pair form in a launch of its own and the tail launch folds its findings.  52 dense graphs (N = 6656, E = 845 312):
+    sorted; shuffled (UNSORTED -> stable device sort); one edge dropped (odd E: the narrow form); an index out of range (poisoned
+    logits); ragged sizes."""
+    params, arch, sd = _default_model(1.0 / 127)
+    rng = np.random.default_rng(21)
+    sizes = [128] * 52 if case != "ragged" else [100 + (13 * g) % 60 for g in range(56)]
+    x, ei, ea = _union(sizes, rng)
+    assert x.shape[0] >= 6144 and ei.shape[1] >= 1 << 19
+    if case == "shuffled":
+        perm = rng.permutation(ei.shape[1])
+        ei, ea = np.ascontiguousarray(ei[:, perm]), np.ascontiguousarray(ea[perm])
+    if case == "odd_E":
+        keep = np.ones(ei.shape[1], bool)
+        keep[12345] = False
+        ei, ea = np.ascontiguousarray(ei[:, keep]), np.ascontiguousarray(ea[keep])
+        assert ei.shape[1] % 2 == 1
+    m = build(params, arch, sd)
+    if case == "bad_index":
+        ei = ei.copy()
+        ei[1, 700001] = x.shape[0] + 5
+        with torch.no_grad():
+            out = m(Data(torch.from_numpy(x).cuda(), torch.from_numpy(ei).cuda(), torch.from_numpy(ea).cuda()))["classified_edges"]
+        assert m.graph_flags() & 2
+        assert all(torch.isnan(o).all() for o in out)
+        return
+    ref = NumpyOracle(params, arch, sd, np.float32).forward(x, ei, ea)
+    with torch.no_grad():
+        out = m(Data(torch.from_numpy(x).cuda(), torch.from_numpy(ei).cuda(), torch.from_numpy(ea).cuda()))["classified_edges"]
+    torch.cuda.synchronize()
+    assert (m.graph_flags() & 1) == (1 if case == "shuffled" else 0)
+    for o, r in zip(out, ref):
+        assert np.abs(o.cpu().numpy() - r).max() <= TOL_TIGHT * (4 if case == "shuffled" else 2)
 
 
 def test_fused_encoder_launch_repairs_unsorted_plan():

@@ -133,3 +133,30 @@ def test_shard_vs_union_across_dispatch_regimes_is_bounded():
         assert all(torch.equal(x, y) for x, y in zip(part, again))
     assert worst <= 2e-6, worst
     print(f"shard (64 of 512 x dense128) vs union: max |dlogit| = {worst:.3e}")
+
+
+def test_unsplit_encoder_option_makes_shards_bitwise_equal_to_the_union():
+    """`model.encoder_unsplit = True` (GNNCCA_OPT_ENC_UNSPLIT): forwards over >= 4096 nodes never split K in the first encoder
+    layer -- the 32-row un-split kernel (shares of 8192 / 16 384 / 4096 + nodes) and the 256-row un-split kernel (the 65 536-node
+    union) run the same per-element arithmetic, so a graph's logits are BIT FOR BIT what the union computes: the 8-, 4- and 16-rank
+    shares of BASELINE config 4 against the 512-graph union on one GPU."""
+    import bench
+    from gnn_cca_amd.sharding import shard_range
+    g_all, n = 512, 128
+    model = bench.build_model(bench.graph_net_params(), n).cuda()
+    model.encoder_unsplit = True
+    dev = torch.device("cuda", 0)
+    union = bench.make_data(n, g_all, 5, dev)
+    e_per = n * (n - 1)
+    with torch.no_grad():
+        full = [t.clone() for t in model(union)["classified_edges"]]
+    for world, rank in ((8, 0), (8, 5), (4, 3), (16, 9)):
+        lo, hi = shard_range(g_all, rank, world)
+        share = bench.Data()
+        share.x = union.x[lo * n:hi * n].contiguous()
+        share.edge_index = (union.edge_index[:, lo * e_per:hi * e_per] - lo * n).contiguous()
+        share.edge_attr = union.edge_attr[lo * e_per:hi * e_per].contiguous()
+        with torch.no_grad():
+            part = model(share)["classified_edges"]
+        for a, b in zip(part, full):
+            assert torch.equal(a, b[lo * e_per:hi * e_per]), (world, rank, float((a - b[lo * e_per:hi * e_per]).abs().max()))
