@@ -276,9 +276,8 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
                 int ride = 0;
                 static const bool no_ride_d = diag_env("GNNCCA_NO_RIDE") != nullptr;   // diagnostics: A/B against a plan launch of its own
                 if (plan_blocks > 0 && (N < 4096 || !no_ride_d)) {
-                    pl.plan_span = 0;   // one flag word per plan block, narrow or pair form by the edge count and alignment
-                    if (plan_span(edge_index, E) == 1) pl.plan_span = 1;
-                    ride = plan_blocks;
+                    pl.plan_span = plan_span(edge_index, E);   // narrow (0) or pair form by the edge count and alignment
+                    ride = pl.plan_span > 1 ? (plan_blocks + pl.plan_span - 1) / pl.plan_span : plan_blocks;
                     plan_launched = true;
                 } else {
                     pl.E = 0;

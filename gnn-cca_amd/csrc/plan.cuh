@@ -69,15 +69,20 @@ __host__ __device__ inline int plan_edges_per_block(int E) { return E >= (1 << 1
 __host__ __device__ inline int plan_num_blocks(int E) { return (E + plan_edges_per_block(E) - 1) / plan_edges_per_block(E); }
 // The plan launch of big batches takes plan_block's pair form when the index rows allow 16-byte loads: kPlanSpan 1024-edge blocks
 // per workgroup.  (Measured with 4 blocks = 4096 edges per workgroup, every load in flight before the first use: 64 x dense256
-// 19.5 -> 20.7 us, 512 x dense128 39.2 -> 42.7, 64 x dense128 6.9 -> 8.5, profiles/r03_logs/r3_plan_ab2.log; one block it is.)
+// 19.5 -> 20.7 us, 512 x dense128 39.2 -> 42.7, 64 x dense128 6.9 -> 8.5, profiles/r03_logs/r3_plan_ab2.log; with the padded-layout
+// check's row ids requested up front, two blocks: 5.7 / 18.6 / 34.7 / 51.3 -> 6.3 / 18.8 / 33.8 / 48 us at 64 x dense128 / 64 x dense256 /
+// 512 x dense128 / 200 x dense256 on a box 4 % slower, r3_plan_ahead1.log vs r3_plan_ahead2.log: a tie; one block it is.)
 constexpr int kPlanSpan = 1;
 inline int plan_span(const void* ei, int E) {   // 0: the narrow form
     return (plan_edges_per_block(E) == 1024 && (E & 1) == 0 && (reinterpret_cast<unsigned long long>(ei) & 15) == 0) ? kPlanSpan : 0;
 }
 
 // One edge of the plan (shared by both forms below): bounds, int32 target id, CSR offsets at row boundaries, padded-layout check.
+// `ahead`: the row id of edge k + ell_S when the caller has it in a register already (HAVE_AHEAD; the pair form requests it with
+// its other loads, so that a row start does not cost the workgroup a second, dependent round trip), else it is read here.
+template <bool HAVE_AHEAD = false>
 __device__ __forceinline__ unsigned plan_edge(int k, long long r, long long c, long long rp, const long long* __restrict__ ei, int E, int N,
-                                              int* __restrict__ seg_ptr, int& col_out, int ell_S) {
+                                              int* __restrict__ seg_ptr, int& col_out, int ell_S, long long ahead = 0) {
     if (r < 0 || r >= N || c < 0 || c >= N) return GNNCCA_GRAPH_BAD_INDEX;
     unsigned fl = 0u;
     col_out = (int)c;
@@ -89,7 +94,7 @@ __device__ __forceinline__ unsigned plan_edge(int k, long long r, long long c, l
             for (long long n = rp + 1; n <= r; ++n) seg_ptr[n] = k;
             // padded layout of the step kernels (ell_S slots per node, chosen from E/N): a row that still continues
             // ell_S edges after its start does not fit (rows are sorted here, or UNSORTED is raised elsewhere)
-            if (ell_S > 0 && r > rp && (long long)k + ell_S < E && ei[(size_t)k + ell_S] == r) fl |= GNNCCA_GRAPH_IRREGULAR;
+            if (ell_S > 0 && r > rp && (long long)k + ell_S < E && (HAVE_AHEAD ? ahead : ei[(size_t)k + ell_S]) == r) fl |= GNNCCA_GRAPH_IRREGULAR;
         }
         if (k == E - 1)
             for (long long n = r + 1; n <= N; ++n) seg_ptr[n] = E;
@@ -115,7 +120,7 @@ __device__ __forceinline__ void plan_block(int pb, const long long* __restrict__
     if (span == kPlanSpan) {   // (the host checked: per == 4, E even, both index rows 16-byte aligned)
         const int lane = threadIdx.x & 63;
         constexpr int U = 2 * kPlanSpan;
-        ll2 r2[U], c2[U];
+        ll2 r2[U], c2[U], a2[U];
         long long rlast[U];
         int kk[U];
 #pragma unroll
@@ -128,6 +133,11 @@ __device__ __forceinline__ void plan_block(int pb, const long long* __restrict__
             c2[u] = __builtin_nontemporal_load(reinterpret_cast<const ll2*>(ei + (size_t)E + kl));
             // the edge before a wave's first pair belongs to another wave (or workgroup): lane 0 fetches it
             rlast[u] = (lane == 0 && on && k > 0) ? ei[k - 1] : -1;
+            // padded-layout check (plan_edge): the row ids ell_S edges ahead, requested NOW with everything else -- ell_S is a multiple
+            // of 32, so this is an aligned pair too, and a line another wave streams anyway (L2, not HBM) -- instead of by the row-start
+            // lanes after the first round trip (a second, dependent one for the whole workgroup: 64 x dense256 19.5-20 -> 18.5 us, 512 x dense128 37-39 -> 34.7, 64 x dense128
+            // 6.4 -> 5.7; profiles/r03_logs/r3_plan_ahead1.log)
+            a2[u] = (ell_S > 0 && (long long)k + ell_S < E) ? *reinterpret_cast<const ll2*>(ei + (size_t)k + ell_S) : ll2{-1, -1};
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -136,8 +146,8 @@ __device__ __forceinline__ void plan_block(int pb, const long long* __restrict__
             const long long rp0 = lane == 0 ? rlast[u] : up;
             if (k < E) {
                 int j0 = 0, j1 = 0;
-                const unsigned f0 = plan_edge(k, r2[u][0], c2[u][0], rp0, ei, E, N, seg_ptr, j0, ell_S);
-                const unsigned f1 = plan_edge(k + 1, r2[u][1], c2[u][1], r2[u][0], ei, E, N, seg_ptr, j1, ell_S);
+                const unsigned f0 = plan_edge<true>(k, r2[u][0], c2[u][0], rp0, ei, E, N, seg_ptr, j0, ell_S, a2[u][0]);
+                const unsigned f1 = plan_edge<true>(k + 1, r2[u][1], c2[u][1], r2[u][0], ei, E, N, seg_ptr, j1, ell_S, a2[u][1]);
                 fl |= f0 | f1;
                 if (!((f0 | f1) & GNNCCA_GRAPH_BAD_INDEX)) {
                     *reinterpret_cast<i32x2*>(col32 + k) = i32x2{j0, j1};
