@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void enc_gemm_rows32_fused_kernel(const float*
     EncFinishOut fo;
     fo.W2rm = fp.W2, fo.b2 = fp.b2, fo.projwT = fp.projwT, fo.projb = fp.projb;
     fo.h0 = fp.h0, fo.trace_h = fp.trace_h, fo.pd_out = fp.pd_out, fo.psq_out = fp.psq_out;
-    enc_finish_32rows(H1, Dp, H0, fo, row0, M);
+    enc_finish_32rows(H1, Dp, H0, fo, enc_finish_preload(fo), row0, M);
 }
 
 }  // namespace gnncca

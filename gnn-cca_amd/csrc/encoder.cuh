@@ -451,7 +451,7 @@ __global__ __launch_bounds__(512) void enc_gemm_split_lds_kernel(const float* __
 #pragma unroll
             for (int u = 0; u < 4; ++u) dst[u] = *reinterpret_cast<const f32x4*>(xsrc[u] + kt * BK);
         };
-        auto store_stage2 = [&](int stage, const f32x4 (&src)[4]) {
+        auto store_stage2 = [&](int stage, const f32x4 (&src)[4], const bf16x8 (&wsrc)[3]) {
             __bf16* a = sa + (size_t)stage * 3 * RA * BK;
             __bf16* b = sb + (size_t)stage * 3 * RB * BK;
 #pragma unroll
@@ -479,19 +479,21 @@ __global__ __launch_bounds__(512) void enc_gemm_split_lds_kernel(const float* __
                 *reinterpret_cast<u32x2*>(a + 2 * RA * BK + xdst[u]) = u32x2{w[2][0], w[2][1]};
             }
 #pragma unroll
-            for (int u = 0; u < 3; ++u) *reinterpret_cast<bf16x8*>(b + wdst[u]) = wreg[u];
+            for (int u = 0; u < 3; ++u) *reinterpret_cast<bf16x8*>(b + wdst[u]) = wsrc[u];
         };
         Frag f0, f1;
         // chunk k lives in stage k & 1.  Phase 1 of chunk kt: MFMAs of its first half while its second half is read.  Barrier: every
         // wave has read all of chunk kt (its stage is free) and chunk kt + 1 -- stored a chunk ago -- is visible.  Phase 2: MFMAs of
         // the second half while chunk kt + 2 is converted and stored into the freed stage, the loads of chunk kt + 3 are issued (they
         // have a whole chunk to land: an HBM round trip under load is about one) and the first half of chunk kt + 1 is read.
+        // (Requesting chunks 0 and 1 together, chunk 1 in a register set of its own, changes nothing: 28.3 vs 27.7-29 us at N = 8192,
+        // r3_prol1.log -- the launch's 8.5 us of fixed cost are its 128 KB of slab stores per workgroup, not the prologue's round trips.)
         load_w(0);
         load_x2(0, xs[0]);
-        store_stage2(0, xs[0]);
+        store_stage2(0, xs[0], wreg);
         load_w(min(1, nk - 1));
         load_x2(min(1, nk - 1), xs[0]);
-        store_stage2(1, xs[0]);
+        store_stage2(1, xs[0], wreg);
         load_w(min(2, nk - 1));
         load_x2(min(2, nk - 1), xs[0]);
         __syncthreads();
@@ -512,7 +514,7 @@ __global__ __launch_bounds__(512) void enc_gemm_split_lds_kernel(const float* __
             PHASE_T(0);
             __syncthreads();
             PHASE_T(1);
-            store_stage2(stage, xs[0]);                  // chunk kt + 2 (for kt + 2 >= nk: a clamped duplicate nobody reads)
+            store_stage2(stage, xs[0], wreg);            // chunk kt + 2 (for kt + 2 >= nk: a clamped duplicate nobody reads)
             load_w(min(kt + 3, nk - 1));
             load_x2(min(kt + 3, nk - 1), xs[0]);
             read_frag(stage ^ 1, 0, f0);
@@ -945,27 +947,60 @@ struct EncFinishOut {
     float* psq_out;        // [N][40]
 };
 
-__device__ __forceinline__ void enc_finish_32rows(const float* s_h1, float* s_dp, float* s_h0, const EncFinishOut& o, int node0, int N) {
-    constexpr int F = 128, LD1 = kFinLD1, LDP = kFinLDP, LD0 = kFinLD0;
+// The weights a thread needs in enc_finish_32rows, in registers.  enc_finish_preload issues their loads: a caller that still waits for
+// its own operands (the split-K tail: eight slabs from HBM) calls it FIRST, so that the three L2 round trips -- W2 fragments, b2,
+// projection weights -- overlap that wait instead of following one barrier each.
+struct EncFinishRegs {
+    float w2[16];      // W2[l32][32 wave + 16 h + s]
+    float b2[4];       // b2[4 (tid & 7) + q]
+    float pw[16];      // projwT[16 h + s][32 wave + l32]   (waves 0, 1; 0 beyond slot 47)
+    float pb;          // projb[32 wave + l32]
+};
+
+__device__ __forceinline__ EncFinishRegs enc_finish_preload(const EncFinishOut& o) {
+    constexpr int F = 128;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l32 = lane & 31, h = lane >> 5;
+    EncFinishRegs r;
+    const float* wr = o.W2rm + (size_t)l32 * F + 32 * wave + 16 * h;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(wr + 4 * j);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) r.w2[4 * j + q] = b4[q];
+    }
+    const f32x4 bb = *reinterpret_cast<const f32x4*>(o.b2 + (tid & 7) * 4);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) r.b2[q] = bb[q];
+    const int slot = 32 * (wave & 1) + l32;
+    const bool on = slot < kProjOut;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) r.pw[s] = on ? o.projwT[(16 * h + s) * kProjOut + slot] : 0.f;
+    r.pb = on ? o.projb[slot] : 0.f;
+    return r;
+}
+
+__device__ __forceinline__ void enc_finish_32rows(const float* s_h1, float* s_dp, float* s_h0, const EncFinishOut& o, const EncFinishRegs& w,
+                                                  int node0, int N) {
+    constexpr int LD1 = kFinLD1, LDP = kFinLDP, LD0 = kFinLD0;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l32 = lane & 31, h = lane >> 5;
     {
         const float* hr = s_h1 + l32 * LD1 + 32 * wave + 16 * h;
-        const float* wr = o.W2rm + (size_t)l32 * F + 32 * wave + 16 * h;
-        float av[16], bv[16];
+        float av[16];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const f32x4 a4 = *reinterpret_cast<const f32x4*>(hr + 4 * j);
-            const f32x4 b4 = *reinterpret_cast<const f32x4*>(wr + 4 * j);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) av[4 * j + q] = a4[q], bv[4 * j + q] = b4[q];
+            for (int q = 0; q < 4; ++q) av[4 * j + q] = a4[q];
         }
         f32x16 d;
 #pragma unroll
         for (int i = 0; i < 16; ++i) d[i] = 0.f;
 #pragma unroll
-        for (int s = 0; s < 16; ++s) d = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[s], d, 0, 0, 0);
+        for (int s = 0; s < 16; ++s) d = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], w.w2[s], d, 0, 0, 0);
 #pragma unroll
         for (int i = 0; i < 16; ++i) s_dp[(wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * h) * LDP + l32] = d[i];
     }
@@ -978,8 +1013,8 @@ __device__ __forceinline__ void enc_finish_32rows(const float* s_h1, float* s_dp
             const int c = c4 + q;
             float v = s_dp[r * LDP + c];
 #pragma unroll
-            for (int w = 1; w < 4; ++w) v += s_dp[(w * 32 + r) * LDP + c];
-            v = fmaxf(v + o.b2[c], 0.f);
+            for (int ww = 1; ww < 4; ++ww) v += s_dp[(ww * 32 + r) * LDP + c];
+            v = fmaxf(v + w.b2[q], 0.f);
             s_h0[r * LD0 + c] = v;
             if (node < N) {
                 o.h0[(size_t)node * kH + c] = v;
@@ -991,7 +1026,7 @@ __device__ __forceinline__ void enc_finish_32rows(const float* s_h1, float* s_dp
     if (wave < 2) {
         const int slot = 32 * wave + l32;
         const bool on = slot < kProjOut;
-        float a2[16], b2[16];
+        float a2[16];
         const float* hr = s_h0 + l32 * LD0 + 16 * h;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -999,19 +1034,16 @@ __device__ __forceinline__ void enc_finish_32rows(const float* s_h1, float* s_dp
 #pragma unroll
             for (int q = 0; q < 4; ++q) a2[4 * j + q] = a4[q];
         }
-#pragma unroll
-        for (int s = 0; s < 16; ++s) b2[s] = on ? o.projwT[(16 * h + s) * kProjOut + slot] : 0.f;
         f32x16 pacc;
 #pragma unroll
         for (int i = 0; i < 16; ++i) pacc[i] = 0.f;
 #pragma unroll
-        for (int s = 0; s < 16; ++s) pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[s], b2[s], pacc, 0, 0, 0);
-        const float pb = on ? o.projb[slot] : 0.f;
+        for (int s = 0; s < 16; ++s) pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[s], w.pw[s], pacc, 0, 0, 0);
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int node = node0 + (i & 3) + 8 * (i >> 2) + 4 * h;
             if (node < N && on) {
-                const float v = pacc[i] + pb;
+                const float v = pacc[i] + w.pb;
                 if (slot < kPdStride)
                     o.pd_out[(size_t)node * kPdStride + slot] = v;
                 else
@@ -1046,6 +1078,10 @@ __global__ __launch_bounds__(256) void enc_tail_mfma_kernel(const TailParams p, 
         return;
     }
     const int node0 = blockIdx.x * 32;
+    EncFinishOut fo;
+    fo.W2rm = W2rm, fo.b2 = blob + p.off_last_b, fo.projwT = blob + p.off_projwT, fo.projb = blob + p.off_projb;
+    fo.h0 = p.h0, fo.trace_h = p.trace_h, fo.pd_out = p.pd_out, fo.psq_out = p.psq_out;
+    const EncFinishRegs fw = enc_finish_preload(fo);   // the weights of steps 2 and 3, requested before the slabs
     // ---- 1. slab sum + bias + ReLU -> LDS -------------------------------------------------------------------------------------
     {
         // thread (node nl, t = tid & 7) owns the columns 32 j + 4 t .. + 3, j = 0..3: for a fixed j the eight threads of a row read
@@ -1081,10 +1117,7 @@ __global__ __launch_bounds__(256) void enc_tail_mfma_kernel(const TailParams p, 
     }
     __syncthreads();
     // ---- 2. / 3. layer 2 with k split over the four waves, projections by waves 0 and 1 (enc_finish_32rows) -------------------------
-    EncFinishOut fo;
-    fo.W2rm = W2rm, fo.b2 = blob + p.off_last_b, fo.projwT = blob + p.off_projwT, fo.projb = blob + p.off_projb;
-    fo.h0 = p.h0, fo.trace_h = p.trace_h, fo.pd_out = p.pd_out, fo.psq_out = p.psq_out;
-    enc_finish_32rows(s_h1, s_dp, s_h0, fo, node0, p.N);
+    enc_finish_32rows(s_h1, s_dp, s_h0, fo, fw, node0, p.N);
 }
 
 
