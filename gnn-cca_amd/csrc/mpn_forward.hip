@@ -269,7 +269,8 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
                                   K / ks_split, fp);
             } else {
                 // 128-row workgroups (a wave = 32 rows x 128 columns); split-K until >= 512 workgroups are in flight
-                while (ks_split < ws.ksplit && ((N + 127) / 128) * ks_split < 512 && (K / (ks_split * 2)) % 32 == 0) ks_split *= 2;
+                static const int direct_wg = diag_env("GNNCCA_GEMM_DIRECT_WG") ? std::atoi(diag_env("GNNCCA_GEMM_DIRECT_WG")) : 512;   // diagnostics
+                while (ks_split < ws.ksplit && ((N + 127) / 128) * ks_split < direct_wg && (K / (ks_split * 2)) % 32 == 0) ks_split *= 2;
                 const int rb = (N + 127) / 128;
                 // the plan rides in this launch (extra workgroups beyond the GEMM tiles)
                 EncPlanParams pl = ep;
