@@ -373,6 +373,9 @@ def main():
     ap.add_argument("--enc-products", type=int, choices=[6, 3], default=6,
                     help="split-bf16 products of the first encoder layer on batches of >= 4096 nodes (3: GNNCCA_OPT_ENC_SPLIT3, "
                          "an accuracy/speed option; the default 6 keeps fp32-level accuracy)")
+    ap.add_argument("--enc-unsplit", action="store_true",
+                    help="GNNCCA_OPT_ENC_UNSPLIT: forwards over >= 4096 nodes never split K in the first encoder layer (a graph's logits "
+                         "are then bitwise independent of its batch / shard; off by default)")
     ap.add_argument("--no-scale-probe", action="store_true", help="skip the 64-graph batch probe of the step kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-config4", action="store_true", help="skip the sharded 512 x dense128 leg (BASELINE config 4)")
@@ -418,6 +421,7 @@ def main():
     model = build_model(params, args.nodes, seed=rank).to(device)
     model.edge_state_dtype = args.edge_state
     model.encoder_products = args.enc_products
+    model.encoder_unsplit = args.enc_unsplit
     # shared weights: ONE RCCL broadcast of rank 0's parameters over xGMI (no other collective on the path)
     broadcast_ms, weights_hash = None, None
     if world > 1:
@@ -495,6 +499,7 @@ def main():
             m4 = build_model(graph_net_params(L=4), 128, seed=rank).to(device)
             m4.edge_state_dtype = args.edge_state
             m4.encoder_products = args.enc_products
+            m4.encoder_unsplit = args.enc_unsplit
             if world > 1:
                 broadcast_and_verify(m4, dist, device, args.backend, rank, world)
             graphs4 = LazyDenseGraphs(args.config4_graphs, 128, device)
@@ -567,7 +572,7 @@ def main():
                                    f"(N={N}, E={E}), feat 2048, L={args.L}, 3 classified steps, fp32 arithmetic, "
                                    f"{args.edge_state} edge state, eval",
                        "mode": mode_used, "edge_state": args.edge_state, "edge_state_storage": "bf16" if args.edge_state == "bf16" else "f32",
-                       "encoder_products": args.enc_products,
+                       "encoder_products": args.enc_products, "encoder_unsplit": args.enc_unsplit,
                        "outputs_finite": bool(ok),
                        "edge_steps_per_s": world * E * args.L * args.steps / t,
                        "timing": f"median of {len(blocks)} blocks of {args.steps} steps (each: barrier + synchronize on both "

@@ -21,16 +21,24 @@ namespace gnncca {
 // is enc_finish_32rows: a node's encoder output does not depend on which of the two un-split kernels produced it, bit for bit
 // -- a 64-graph shard of config 4 (N = 8192, this kernel) reproduces its graphs' logits inside the 512-graph union
 // (N = 65 536, 256-row kernel) exactly.
-// The price: every workgroup streams all of W's pieces (1.5 MB) from L2: N / 32 x 1.5 MB of L2 -> CU traffic.
+// The price (measured, profiles/r03_logs/r3_r32_ab1.log, r3_r32_ab3.log, r3_r32_abl1.log, r3_r32_abl2.log, r3_pmc_r32.log): 35 us at N = 4096,
+// 41 us at N = 8192 (split-K + tail: 31 / 38), 76-84 us at N = 16 384.  At N <= 8192 there is ONE wave per SIMD and one dependent
+// accumulation chain per wave: with every load, LDS access and conversion removed the 768 MFMAs alone take 24 us (timing-only
+// ablation) -- a lone wave retires a v_mfma_f32_32x32x16_bf16 per 32 cycles where two / four waves on a SIMD get 24 / 20
+// (tools/ubench_mfma_chain.hip), at the ~1.3 GHz the chip sustains under this load -- and nothing hides its own waits: the W
+// fragments (every workgroup streams all 1.5 MB of pieces from L2, 515 MB of L2 requests per launch at N = 8192, 84 % hits) cost
+// 7.5 us, x and its conversion 3.5 us.  A bare sweep of a 1.5 MB L2-resident table reaches 106-135 GB/s per CU
+// (tools/ubench_l2_per_cu.hip: 64 B/clk, the L1's width), this kernel 42-50; reading the pieces in a fragment-ordered 1 KB-contiguous
+// pattern instead of 32 rows x 2 x 16 B: 43.5 -> 38.5 us (timing probe); fewer W stages (1-3 sub-chunks ahead): 43-50 us.
 // Replaces models/mpn.py:131 (encoder.node_mlp) on such batches.
 // ------------------------------------------------------------------------------------------------------------
 constexpr int kR32LdsBytes = 2 * 3 * 32 * 128 * 2;   // 49 152
 
-template <bool P3, int NST>
+template <bool P3, int NST, int DIST = NST - 1>
 __global__ __launch_bounds__(256) void enc_gemm_rows32_fused_kernel(const float* __restrict__ x, const unsigned short* __restrict__ w3, int M, int K,
                                                                     const EncFuseParams fp) {
     constexpr int KA = 128, BK = 32, O = 128;
-    static_assert(NST == 4 || NST == 8, "W stages rotate with the four sub-chunks of a super-chunk");
+    static_assert((NST == 2 || NST == 4 || NST == 8) && DIST >= 1 && DIST < NST, "W stages rotate with the four sub-chunks of a super-chunk");
     __shared__ __attribute__((aligned(16))) unsigned char lds_raw[kR32LdsBytes];
     __bf16* sa = reinterpret_cast<__bf16*>(lds_raw);   // [2][3][32][128]
     const int tid = threadIdx.x, lane = tid & 63;
@@ -116,7 +124,7 @@ __global__ __launch_bounds__(256) void enc_gemm_rows32_fused_kernel(const float*
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
             const int j = s >> 1;
-            if ((s & 1) == 0) load_w(min(4 * c + j + NST - 1, nchunk - 1), wb[(WS0 + j + NST - 1) % NST]);
+            if ((s & 1) == 0) load_w(min(4 * c + j + DIST, nchunk - 1), wb[(WS0 + j + DIST) % NST]);
             if (s == 7) {
                 __syncthreads();   // every wave holds its last fragments of stage PAR; the image of x(c + 1) is complete
                 read_a(PAR ^ 1, 0, af[0]);
@@ -142,7 +150,7 @@ __global__ __launch_bounds__(256) void enc_gemm_rows32_fused_kernel(const float*
     load_x_granule(min(2, nsc - 1), 0, xs[0]);
     load_x_granule(min(2, nsc - 1), 1, xs[0]);
 #pragma unroll
-    for (int q = 0; q < NST - 1; ++q) load_w(min(q, nchunk - 1), wb[q]);
+    for (int q = 0; q < DIST; ++q) load_w(min(q, nchunk - 1), wb[q]);
     convert_store(0, 0, x0);
     convert_store(0, 1, x0);
     __syncthreads();

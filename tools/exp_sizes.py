@@ -14,7 +14,7 @@ import bench  # noqa: E402
 
 
 def main():
-    L, es, specs = 4, "fp32", []
+    L, es, specs, unsplit = 4, "fp32", [], False
     a = sys.argv[1:]
     while a:
         t = a.pop(0)
@@ -22,6 +22,8 @@ def main():
             L = int(a.pop(0))
         elif t == "--edge-state":
             es = a.pop(0)
+        elif t == "--unsplit":
+            unsplit = True
         else:
             specs.append(tuple(int(v) for v in t.split("x")))
     dev = torch.device("cuda", 0)
@@ -29,6 +31,7 @@ def main():
         params = bench.graph_net_params(L=L)
         model = bench.build_model(copy.deepcopy(params), n).to(dev)
         model.edge_state_dtype = es
+        model.encoder_unsplit = unsplit
         data = bench.make_data(n, g, 1, dev)
         E = data.edge_index.shape[1]
         acc = {}
