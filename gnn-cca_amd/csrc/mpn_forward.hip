@@ -170,8 +170,8 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
             // mid-size batches, where the 256-row form would run split-K: 32-row workgroups, un-split, fused epilogue (enc_rows32.cuh)
             // GNNCCA_OPT_ENC_UNSPLIT: batches of >= 4096 nodes never split K -- where the 256-row form would, 32-row workgroups run
             // un-split with the same fused epilogue (enc_rows32.cuh), so a node's encoder output is bit for bit independent of the batch
-            // around it (a shard of a sharded batch reproduces the union's logits exactly).  Not the default: every 32-row workgroup
-            // streams all of W's pieces from L2 (N = 8192: 43.5 us against 29 + 11 for split-K + tail; profiles/r03_logs/r3_r32_ab1.log)
+            // around it (a shard of a sharded batch reproduces the union's logits exactly).  Not the default: one wave per SIMD at
+            // N <= 8192 (N = 8192: 41-43.5 us against 28 + 9 for split-K + tail; enc_rows32.cuh says where the time goes)
             static const int r32_nst = diag_env("GNNCCA_GEMM_R32_NST") ? std::atoi(diag_env("GNNCCA_GEMM_R32_NST")) : 0;
             const bool use_r32 = (options & GNNCCA_OPT_ENC_UNSPLIT) != 0 && fusable && O == 128 && K % 256 == 0 && !force_direct && N >= 4096 &&
                                  !(use_lds && ks_split == 1);

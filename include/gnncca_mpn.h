@@ -193,8 +193,8 @@ typedef struct gnncca_dropout {
  * agree across batch sizes within rounding only (<= 2e-6 asserted, 6e-8 measured).  With this option the mid-size batches take an
  * un-split 32-row kernel whose per-element arithmetic is the big un-split kernel's: a graph's logits are then BIT FOR BIT
  * independent of the batch (or the shard of a sharded batch) it is computed in, as long as that batch has >= 4096 nodes.
- * Price: that kernel streams all of W's pieces from L2 per 32 rows -- encoder 43.5 instead of 40.5 us at 8192 nodes, 87 instead
- * of 72 us at 16 384.  Off by default. */
+ * Price: encoder 48 instead of 44 us at 8192 nodes (plan launch included), 87 instead of 70 us at 16 384.
+ * Off by default. */
 #define GNNCCA_OPT_ENC_UNSPLIT 4u
 GNNCCA_API int gnncca_mpn_forward_ex(const gnncca_mpn_dims* dims, const void* packed_dev, const float* x,
                                      const int64_t* edge_index, const float* edge_attr, int64_t n_nodes,
