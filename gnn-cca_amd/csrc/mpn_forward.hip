@@ -127,10 +127,12 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
         const int ks = g == 0 ? ws.ksplit : 1;
         int kslice = (K + ks - 1) / ks;
         kslice = (kslice + 63) / 64 * 64;
-        // From 1024 nodes on the first encoder layer runs on the split-bf16 MFMA GEMM (round 3 lowered this from 4096: the f32 MFMA
-        // GEMM with the plan riding along took 19.5 us at dense1024 and 43 us at dense2048, the 128-row split kernel + a plan launch
-        // 11.0 + 5.8 and 17.4 + 17.1; profiles/r03_logs/r3_gemm_split_min.log)
-        static const int split_min = diag_env("GNNCCA_GEMM_SPLIT_MIN") ? std::atoi(diag_env("GNNCCA_GEMM_SPLIT_MIN")) : 1024;   // diagnostics
+        // From 384 nodes on the first encoder layer runs on the split-bf16 MFMA GEMM, the plan riding in its launch.  (Round 3 lowered this
+        // from 4096 to 1024 -- f32 MFMA GEMM + plan 19.5 us at dense1024, 43 at dense2048; 128-row split kernel + a plan launch 11.0 + 5.8
+        // and 17.4 + 17.1, r3_gemm_split_min.log -- and, once the plan rode along, to 384: GEMM 11.5 / 12.1 / 17.7 / 20.8 -> 9.3 / 9.2 /
+        // 10.5 / 13.2 us at 384 / 512 / 768 / 896 nodes, 3 x dense256 17.0 -> 10.0; at 256 nodes the f32 form stays ahead, 6.6 vs 7.6;
+        // r3_split_min2.log)
+        static const int split_min = diag_env("GNNCCA_GEMM_SPLIT_MIN") ? std::atoi(diag_env("GNNCCA_GEMM_SPLIT_MIN")) : 384;   // diagnostics
         const bool split = g == 0 && hdr.enc_w3 != 0 && N >= split_min && (reinterpret_cast<uintptr_t>(cur_in) & 15) == 0;
         EncPlanParams ep;
         std::memset(&ep, 0, sizeof(ep));
