@@ -359,12 +359,14 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
         const unsigned blocks = (unsigned)std::min<size_t>(((size_t)N + 3) / 4, 2048) + 1;  // + plan-repair workgroup
         // register-resident tail in the latency-bound regime only: on big batches it is VALU-bound (readlane traffic) and
         // measured 15 % slower than the LDS form (72 vs 62 us at N = 65 536)
-        const bool tail_fast = !dropping && N < 4096 && tp.F == 128 && tp.has_last && !tp.reatt_n && tp.trace_h == nullptr && tp.vec_reduce &&
-                               (reinterpret_cast<uintptr_t>(part) & 15) == 0;
-        // batches whose GEMM ran split-K: the tail on the matrix pipe, 32 nodes per workgroup
+        // graphs and batches whose GEMM ran split-K: the tail on the matrix pipe, 32 nodes per workgroup, from 2560 nodes (round 3 lowered this
+        // from 6144: 8.7 -> 6.9 us at N = 4096, 10.3 -> 7.5 at 5120, 10.4 -> 7.0 at 4000, 9.2 -> 7.2 at 3000, 8.6 -> 6.4 at 3072; equal at 2048
+        // (6.2), the register-resident tail ahead at 1024 (5.0 vs 7.6); profiles/r03_logs/r3_thresh1.log, r3_thresh2.log)
         static const bool no_mfma_tail = diag_env("GNNCCA_NO_MFMA_TAIL") != nullptr;  // diagnostics: A/B the two tails
-        static const int kTailMfmaMin = diag_env("GNNCCA_TAIL_MFMA_MIN") ? std::atoi(diag_env("GNNCCA_TAIL_MFMA_MIN")) : 6144;
+        static const int kTailMfmaMin = diag_env("GNNCCA_TAIL_MFMA_MIN") ? std::atoi(diag_env("GNNCCA_TAIL_MFMA_MIN")) : 2560;
         const bool tail_mfma = !dropping && !fused_tail && !no_mfma_tail && N >= kTailMfmaMin && tp.F == 128 && tp.has_last && nl == 2 && !tp.reatt_n &&
+                               (reinterpret_cast<uintptr_t>(part) & 15) == 0;
+        const bool tail_fast = !tail_mfma && !dropping && N < 4096 && tp.F == 128 && tp.has_last && !tp.reatt_n && tp.trace_h == nullptr && tp.vec_reduce &&
                                (reinterpret_cast<uintptr_t>(part) & 15) == 0;
         if (fused_tail) {
             // nothing: h0, the projections and the plan's flag word all came out of the GEMM launch
