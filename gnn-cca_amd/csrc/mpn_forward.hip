@@ -425,7 +425,10 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
     // every SIMD (small graphs are latency-bound); big batches keep one wave per node, which amortises the
     // per-node prologue / projection epilogue over all of the node's chunks
     {
-        const long long want = 4096 / (long long)N;  // waves per node that would fill the chip
+        // waves per node that would fill the chip; graphs whose nodes average >= 32 chunks (degree ~2000+) get four times that: the
+        // tail of a launch is then a few long segments (dense3000: 0.4315 -> 0.4039 ms with four waves per node, dense2048 equal;
+        // profiles/r03_logs/r3_wps1.log)
+        const long long want = (chunks >= 32 ? 16384 : 4096) / (long long)N;
         int wps = chunks >= 4 ? 4 : (chunks >= 2 ? 2 : 1);
         while (wps > 1 && wps > want) wps >>= 1;
         static const int force_wps = diag_env("GNNCCA_WPS") ? std::atoi(diag_env("GNNCCA_WPS")) : 0;  // diagnostics

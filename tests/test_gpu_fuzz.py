@@ -120,6 +120,37 @@ def test_config5_size_vs_oracle():
         assert np.abs(o.cpu().numpy() - r).max() <= 2e-5
 
 
+def test_very_dense_graph_vs_oracle():
+    """A dense 2100-node graph (4.4 M edges, 33 chunks of 64 edges per node): nodes of this degree are spread over four waves of a
+    workgroup whatever the node count (mpn_forward.hip: waves per segment), the cross-wave combine runs, the split-bf16 GEMM carries
+    the plan in its launch.  L = 2, one classified step, against the CPU oracle at full size."""
+    from gnn_cca_amd import MOTMPNet
+    params, arch, sd, _ = load_case(os.path.join(GOLDEN_DIR, "dense64.npz"))
+    params = copy.deepcopy(params)
+    params.update(num_enc_steps=2, num_class_steps=1)
+    n = 2100
+    sd = dict(sd)
+    for k in list(sd):
+        if k.startswith("MPNet.node_model"):
+            sd[k] = (sd[k] * np.float32(63.0 / (n - 1))).astype(np.float32)
+    rng = np.random.default_rng(6)
+    x = rng.standard_normal((n, 2048)).astype(np.float32)
+    x /= np.linalg.norm(x, axis=0, keepdims=True)
+    i, j = np.meshgrid(np.arange(n), np.arange(n), indexing="ij")
+    keep = i != j
+    ei = np.stack([i[keep], j[keep]]).astype(np.int64)
+    ea = rng.random((ei.shape[1], 4)).astype(np.float32)
+    ref = NumpyOracle(params, arch, sd, np.float32).forward(x, ei, ea)
+    m = MOTMPNet(copy.deepcopy(params), None, arch)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    m = m.cuda().eval()
+    with torch.no_grad():
+        out = m(Data(torch.from_numpy(x).cuda(), torch.from_numpy(ei).cuda(), torch.from_numpy(ea).cuda()))
+    assert len(out["classified_edges"]) == 1
+    for o, r in zip(out["classified_edges"], ref):
+        assert np.abs(o.cpu().numpy() - r).max() <= 2e-5
+
+
 def test_config4_size_replicated_graph_property():
     """BASELINE config 4 at full size on one GPU: 512 dense 128-node graphs (N = 65 536, E = 8.3 M) in one forward.  The
     oracle cannot run this in seconds, so the check is a size-independent property: the batch is 512 COPIES of one graph,
