@@ -37,6 +37,27 @@ def test_library_exports_every_declared_symbol():
     assert lib.gnncca_status_string(2).decode().startswith("GRAPH_NET_PARAMS not supported")
 
 
+def test_forward_options_match_the_header():
+    """The option bits of gnncca_mpn_forward_ex: the Python constants equal the header's #defines, and the module attributes
+    (edge_state_dtype, encoder_products, encoder_unsplit) map onto them; illegal values raise before anything is launched."""
+    from gnn_cca_amd import _native as nat
+    header = open(os.path.join(ROOT, "include", "gnncca_mpn.h")).read()
+    defs = {k: int(v) for k, v in re.findall(r"#define (GNNCCA_OPT_\w+) (\d+)u", header)}
+    assert defs == {"GNNCCA_OPT_EDGE_STATE_BF16": nat.OPT_EDGE_STATE_BF16, "GNNCCA_OPT_ENC_SPLIT3": nat.OPT_ENC_SPLIT3,
+                    "GNNCCA_OPT_ENC_UNSPLIT": nat.OPT_ENC_UNSPLIT}
+    assert len(set(defs.values())) == 3 and all(v & (v - 1) == 0 for v in defs.values())   # distinct single bits
+    m, *_ = _model("dense64")
+    assert m._options() == 0
+    m.edge_state_dtype, m.encoder_products, m.encoder_unsplit = "bf16", 3, True
+    assert m._options() == nat.OPT_EDGE_STATE_BF16 | nat.OPT_ENC_SPLIT3 | nat.OPT_ENC_UNSPLIT
+    m.encoder_products = 4
+    with pytest.raises(ValueError):
+        m._options()
+    m.encoder_products, m.edge_state_dtype = 6, "fp16"
+    with pytest.raises(ValueError):
+        m._options()
+
+
 @pytest.mark.parametrize("name", golden_cases())
 def test_state_dict_keys_and_shapes_match_reference(name):
     m, params, arch, sd, _ = _model(name)
