@@ -231,12 +231,8 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
             }
             if (use_r32) {
                 const dim3 rgrid((unsigned)((N + 31) / 32) + 1);
-                const int nst = r32_nst == 4 || r32_nst == 8 || r32_nst == 2 || r32_nst == 42 ? r32_nst : ((N + 31) / 32 <= 256 ? 8 : 4);
-                if (nst == 2)
-                    GNNCCA_LAUNCH((enc_gemm_rows32_fused_kernel<false, 2>), rgrid, dim3(256), 0, st, cur_in, w3, N, K, fp);
-                else if (nst == 42)
-                    GNNCCA_LAUNCH((enc_gemm_rows32_fused_kernel<false, 4, 2>), rgrid, dim3(256), 0, st, cur_in, w3, N, K, fp);
-                else if (nst == 8 && split3)
+                const int nst = r32_nst == 4 || r32_nst == 8 ? r32_nst : ((N + 31) / 32 <= 256 ? 8 : 4);
+                if (nst == 8 && split3)
                     GNNCCA_LAUNCH((enc_gemm_rows32_fused_kernel<true, 8>), rgrid, dim3(256), 0, st, cur_in, w3, N, K, fp);
                 else if (nst == 8)
                     GNNCCA_LAUNCH((enc_gemm_rows32_fused_kernel<false, 8>), rgrid, dim3(256), 0, st, cur_in, w3, N, K, fp);

@@ -286,6 +286,39 @@ def test_unsplit_32_row_encoder_vs_fp64_oracle(n_nodes, products):
         assert np.abs(o.cpu().numpy() - r).max() <= TOL_TIGHT * 2
 
 
+@pytest.mark.parametrize("unsplit", [False, True])
+def test_reattach_config_on_a_mid_size_batch(unsplit):
+    """reattach_initial_nodes / _edges on 8200 nodes: the encoder's fused epilogues do not apply (the projections take cat(h0, h)),
+    so the first layer runs split-K on the 256-row GEMM and finishes in the wave-per-node tail -- with and without
+    `encoder_unsplit`, which such a configuration ignores.  Sparse ring graph, general step kernels, against the oracle."""
+    params, arch, sd, _ = load_case(os.path.join(GOLDEN_DIR, "reattach_n1e1.npz"))
+    n_nodes = 8200
+    rng = np.random.default_rng(77)
+    x = rng.standard_normal((n_nodes, np.asarray(sd["encoder.node_mlp.fc_layers.0.weight"]).shape[1])).astype(np.float32)
+    x /= np.linalg.norm(x, axis=0, keepdims=True)
+    src = np.repeat(np.arange(n_nodes), 2)
+    dst = (src + np.tile([1, 5], n_nodes)) % n_nodes
+    ei = np.stack([src, dst]).astype(np.int64)
+    ea = rng.random((ei.shape[1], np.asarray(sd["encoder.edge_mlp.fc_layers.0.weight"]).shape[1])).astype(np.float32)
+    orc = NumpyOracle(params, arch, sd, np.float32)
+    tr = {}
+    ref = orc.forward(x, ei, ea, tr)
+    m = build(params, arch, sd)
+    m.encoder_unsplit = unsplit
+    d = Data(torch.from_numpy(x).cuda(), torch.from_numpy(ei).cuda(), torch.from_numpy(ea).cuda())
+    trace = {}
+    with torch.no_grad():
+        out = [t.clone() for t in m(d)["classified_edges"]]
+        m(d, trace=trace)
+    h64 = NumpyOracle(params, arch, sd, np.float64)._mlp("encoder.node_mlp", x.astype(np.float64))
+    err_gpu = np.abs(trace["h_enc"].cpu().numpy() - h64).max()
+    err_ref = np.abs(tr["h_enc"] - h64).max()
+    assert err_gpu <= max(4 * err_ref, 2e-7 * max(1.0, float(np.abs(h64).max()))), (err_gpu, err_ref)
+    for o, r in zip(out, ref):
+        scale = max(1.0, float(np.abs(r).max()))
+        assert np.abs(o.cpu().numpy() - r).max() <= TOL_TIGHT * 2 * scale
+
+
 def test_unsplit_encoder_launch_repairs_unsorted_plan():
     """The 32-row un-split launch folds the plan's findings in its extra workgroup, as the 256-row fused launch does: a SHUFFLED
     sparse edge list over 9000 nodes comes back in the caller's edge order."""
