@@ -395,6 +395,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # stdout carries ONE line, rank 0's JSON: communication libraries print banners from C++ ("[Gloo] Rank 0 is connected to ..."),
+    # so for the whole run file descriptor 1 points at stderr and the line goes to the saved descriptor
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
                          f"(or leave WORLD_SIZE unset and let bench.py start the ranks)")
@@ -605,7 +610,8 @@ def main():
                 res["cpu_baseline_fused"] = cpu_baseline_fused(params, model, args.nodes, args.graphs)
             except Exception as exc:  # noqa: BLE001
                 res["cpu_baseline_fused"] = {"error": f"{type(exc).__name__}: {exc}"}
-        print(json.dumps(res), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(res) + "\n").encode())
     if dist:
         dist.barrier()
         dist.destroy_process_group()
