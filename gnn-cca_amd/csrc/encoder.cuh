@@ -89,6 +89,13 @@ __global__ __launch_bounds__(256) void enc_gemm_plan_kernel(const EncPlanParams 
     GNNCCA_STAMP(1, 1);
 }
 
+// The plan alone (big batches give it a launch of its own): the same plan_block, without the GEMM tile's registers in the kernel's
+// budget -- enc_gemm_plan_kernel allocates 92 VGPRs (five waves per SIMD), a pure stream wants every wave slot it can get.
+__global__ __launch_bounds__(256) void plan_only_kernel(const EncPlanParams p) {
+    __shared__ unsigned s_fl;
+    plan_block(blockIdx.x, p.ei, p.E, p.N, p.seg_ptr, p.col32, p.blockflags, &s_fl, p.ell_S, p.plan_span);
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // Large-N encoder GEMM on the bf16 MFMA pipe with fp32-level accuracy ("split-bf16"):  x = x0 + x1 + x2 and
 // w = w0 + w1 + w2 with bf16 pieces (3 x 8 = 24 mantissa bits, the pieces of w prepared at pack time, those of x

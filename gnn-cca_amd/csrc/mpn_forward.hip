@@ -207,7 +207,7 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
                 if (plan_blocks > 0) {
                     ep.plan_span = plan_span(edge_index, E);
                     if (ep.plan_span > 1) plan_blocks = (plan_blocks + ep.plan_span - 1) / ep.plan_span;
-                    GNNCCA_LAUNCH(enc_gemm_plan_kernel, dim3(plan_blocks), dim3(256), 0, st, ep);
+                    GNNCCA_LAUNCH(plan_only_kernel, dim3(plan_blocks), dim3(256), 0, st, ep);
                     HIP_TRY(hipGetLastError());
                     PROF_MARK(GNNCCA_K_PLAN_ROWS);
                 }
@@ -299,7 +299,10 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
                 ep.plan_span = plan_span(edge_index, E);
                 if (ep.plan_span > 1) plan_blocks = (plan_blocks + ep.plan_span - 1) / ep.plan_span;
             }
-            GNNCCA_LAUNCH(enc_gemm_plan_kernel, dim3(ep.gemm_blocks + plan_blocks), dim3(256), 0, st, ep);
+            if (ep.gemm_blocks == 0)
+                GNNCCA_LAUNCH(plan_only_kernel, dim3(plan_blocks), dim3(256), 0, st, ep);
+            else
+                GNNCCA_LAUNCH(enc_gemm_plan_kernel, dim3(ep.gemm_blocks + plan_blocks), dim3(256), 0, st, ep);
             HIP_TRY(hipGetLastError());
             PROF_MARK(split ? GNNCCA_K_PLAN_ROWS : GNNCCA_K_ENC_GEMM);
         }
