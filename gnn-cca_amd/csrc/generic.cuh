@@ -221,7 +221,7 @@ static int forward_generic(const gnncca_mpn_dims* d, const void* packed_dev, con
         ep.blockflags = blockflags;
         ep.E = E;
         ep.N = N;
-        hipLaunchKernelGGL(enc_gemm_plan_kernel, dim3(plan_num_blocks(E)), dim3(256), 0, st, ep);
+        hipLaunchKernelGGL(plan_only_kernel, dim3(plan_num_blocks(E)), dim3(256), 0, st, ep);
         HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(gen_index32_kernel, dim3((E + 255) / 256), dim3(256), 0, st, ei, E, N, row32o, col32o);
         HIP_TRY(hipGetLastError());

@@ -658,7 +658,7 @@ int gnncca_post_prune_cluster_frames(const int64_t* edge_index, const int64_t* p
         ep.blockflags = blockflags;
         ep.E = E;
         ep.N = N;
-        hipLaunchKernelGGL(enc_gemm_plan_kernel, dim3(plan_num_blocks(E)), dim3(256), 0, st, ep);
+        hipLaunchKernelGGL(plan_only_kernel, dim3(plan_num_blocks(E)), dim3(256), 0, st, ep);
         HIP_TRY(hipGetLastError());
     }
     hipLaunchKernelGGL(gen_plan_finish_kernel, dim3(1), dim3(256), 0, st, ei, E, N, seg_ptr, col32, perm, cursor, flags,

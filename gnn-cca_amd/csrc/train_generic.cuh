@@ -535,7 +535,7 @@ static int train_forward_impl(const gnncca_mpn_dims* d, float* const* params, in
         EncPlanParams ep;
         std::memset(&ep, 0, sizeof(ep));
         ep.ei = ei, ep.seg_ptr = seg_ptr, ep.col32 = col32, ep.blockflags = blockflags, ep.E = E, ep.N = N;
-        hipLaunchKernelGGL(enc_gemm_plan_kernel, dim3(plan_num_blocks(E)), dim3(256), 0, st, ep);
+        hipLaunchKernelGGL(plan_only_kernel, dim3(plan_num_blocks(E)), dim3(256), 0, st, ep);
         hipLaunchKernelGGL(gen_index32_kernel, dim3((E + 255) / 256), dim3(256), 0, st, ei, E, N, row32, colo32);
         HIP_TRY(hipGetLastError());
     }
@@ -885,7 +885,7 @@ static int aggregate_impl(const float* msg, const int64_t* edge_index, int64_t n
         EncPlanParams ep;
         std::memset(&ep, 0, sizeof(ep));
         ep.ei = ei, ep.seg_ptr = seg_ptr, ep.col32 = col32, ep.blockflags = blockflags, ep.E = E, ep.N = N;
-        hipLaunchKernelGGL(enc_gemm_plan_kernel, dim3(plan_num_blocks(E)), dim3(256), 0, st, ep);
+        hipLaunchKernelGGL(plan_only_kernel, dim3(plan_num_blocks(E)), dim3(256), 0, st, ep);
     }
     hipLaunchKernelGGL(gen_plan_finish_kernel, dim3(1), dim3(256), 0, st, ei, E, N, seg_ptr, col32, perm, cursor, flags,
                        (const unsigned*)blockflags);
