@@ -760,6 +760,42 @@ def test_pipelined_gemm_short_k(node_in, n_nodes):
         assert np.abs(o.cpu().numpy() - r).max() <= TOL_TIGHT * 2 * scale
 
 
+@pytest.mark.parametrize("node_in,n_nodes", [(2048, 384), (2048, 400), (2048, 700), (2048, 1000), (512, 384), (512, 999), (96, 500), (64, 640)])
+def test_split_gemm_on_graphs_of_a_few_hundred_nodes(node_in, n_nodes):
+    """From 384 nodes the first encoder layer runs on the 128-row split-bf16 GEMM with the plan riding in its launch (round 3; below:
+    the f32 MFMA GEMM).  Few row blocks, deep split-K (up to 32 slices of 64 k), short K (one to three 32-deep chunks per workgroup),
+    ragged N; the register-resident tail sums the slabs.  Encoder output against fp64, logits against the fp32 oracle."""
+    from gnn_cca_amd import MOTMPNet
+    params, arch, _ = _default_model(1.0)
+    params = copy.deepcopy(params)
+    params["encoder_feats_dict"]["nodes"][arch]["node_in_dim"] = node_in
+    torch.manual_seed(node_in + n_nodes)
+    ref_m = MOTMPNet(copy.deepcopy(params), None, arch)
+    sd = {k: v.detach().clone().numpy() for k, v in ref_m.state_dict().items()}
+    rng = np.random.default_rng(n_nodes)
+    x = rng.standard_normal((n_nodes, node_in)).astype(np.float32)
+    src = np.repeat(np.arange(n_nodes), 3)
+    dst = (src + np.tile([1, 5, 17], n_nodes)) % n_nodes
+    ei = np.stack([src, dst]).astype(np.int64)
+    ea = rng.random((ei.shape[1], 4)).astype(np.float32)
+    orc = NumpyOracle(params, arch, sd, np.float32)
+    tr = {}
+    ref = orc.forward(x, ei, ea, tr)
+    m = build(params, arch, sd)
+    d = Data(torch.from_numpy(x).cuda(), torch.from_numpy(ei).cuda(), torch.from_numpy(ea).cuda())
+    trace = {}
+    with torch.no_grad():
+        out = [t.clone() for t in m(d)["classified_edges"]]
+        m(d, trace=trace)
+    h64 = NumpyOracle(params, arch, sd, np.float64)._mlp("encoder.node_mlp", x.astype(np.float64))
+    err_gpu = np.abs(trace["h_enc"].cpu().numpy() - h64).max()
+    err_ref = np.abs(tr["h_enc"] - h64).max()
+    assert err_gpu <= max(4 * err_ref, 2e-7 * max(1.0, float(np.abs(h64).max()))), (err_gpu, err_ref)
+    for o, r in zip(out, ref):
+        scale = max(1.0, float(np.abs(r).max()))
+        assert np.abs(o.cpu().numpy() - r).max() <= TOL_TIGHT * 2 * scale
+
+
 def test_non_finite_inputs_stay_inside_their_graph():
     """Non-finite node features are outside the contract of the fast kernels (their ReLU is an integer max on the float's bits:
     a positive NaN propagates, a negative one becomes 0; torch propagates both) -- what IS pinned: they do not leak.  A NaN / Inf
