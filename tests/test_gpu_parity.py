@@ -760,11 +760,13 @@ def test_pipelined_gemm_short_k(node_in, n_nodes):
         assert np.abs(o.cpu().numpy() - r).max() <= TOL_TIGHT * 2 * scale
 
 
-@pytest.mark.parametrize("node_in,n_nodes", [(2048, 384), (2048, 400), (2048, 700), (2048, 1000), (512, 384), (512, 999), (96, 500), (64, 640)])
+@pytest.mark.parametrize("node_in,n_nodes", [(2048, 384), (2048, 400), (2048, 700), (2048, 1000), (512, 384), (512, 999), (96, 500), (64, 640),
+                                              (2048, 2559), (2048, 2560), (2048, 3001), (512, 3500)])
 def test_split_gemm_on_graphs_of_a_few_hundred_nodes(node_in, n_nodes):
     """From 384 nodes the first encoder layer runs on the 128-row split-bf16 GEMM with the plan riding in its launch (round 3; below:
     the f32 MFMA GEMM).  Few row blocks, deep split-K (up to 32 slices of 64 k), short K (one to three 32-deep chunks per workgroup),
-    ragged N; the register-resident tail sums the slabs.  Encoder output against fp64, logits against the fp32 oracle."""
+    ragged N; the register-resident tail sums the slabs (below 2560 nodes; from there the MFMA tail, 32 nodes per workgroup).  Encoder
+    output against fp64, logits against the fp32 oracle."""
     from gnn_cca_amd import MOTMPNet
     params, arch, _ = _default_model(1.0)
     params = copy.deepcopy(params)
