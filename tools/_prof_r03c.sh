@@ -1,5 +1,5 @@
-# Round 3, third (final) collection: every workload of the first two, with the final kernels (plan riding in the 128-row GEMM,
-# the plan's up-front padded-layout check, the tail's preloaded weights, the 256-row epilogue in quarter order).
+# Round 3, fourth (final) collection: every workload of the first two, with the final kernels (plan riding in the 128-row GEMM,
+# the plan's up-front padded-layout check, the tail's preloaded weights, the 256-row epilogue in quarter order, plan_only_kernel, the MFMA tail from 2560 nodes).
 set -x
 python3 tools/collect_profiles.py r03_dense256 -- --steps 20 --warmup 5
 python3 tools/collect_profiles.py r03_64x256 -- --graphs 64 --nodes 256 --steps 40 --warmup 5 --mode eager
