@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the MI355X message-passing path on BASELINE.json's headline workload.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--nodes 256] [--graphs 1] [--L 4] [--mode eager|graph]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--nodes 256] [--graphs 1] [--L 4] [--mode auto|eager|graph|graphk]
 
 A "step" is one MOTMPNet.forward (encoder + L message-passing steps + the classifier on the last 3 steps, eval
 mode, no grad) over one batch of synthetic input already resident in HBM: `--graphs` independent fully-connected
@@ -225,7 +225,7 @@ class LazyDenseGraphs:
         return out
 
 
-def timed_blocks(run, steps, warmup, dist, device, backend, min_blocks=10, min_total_s=0.25, max_blocks=200):
+def timed_blocks(run, steps, warmup, dist, device, backend, min_blocks=10, min_total_s=0.25, max_blocks=200, run_block=None):
     """W untimed warm-up steps, then blocks of EXACTLY `steps` steps; every block is bracketed by barrier +
     torch.cuda.synchronize() on both sides and its time is the MAX over ranks (of the larger of host wall clock and the
     HIP-event span on the launch stream).  Returns the sorted block times; the caller reports the median.  The block
@@ -241,8 +241,11 @@ def timed_blocks(run, steps, warmup, dist, device, backend, min_blocks=10, min_t
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
         ev0.record()
-        for _ in range(steps):
-            out = run()
+        if run_block is not None:      # the K steps of a block as ONE HIP-graph launch (K forwards captured back to back)
+            out = run_block()
+        else:
+            for _ in range(steps):
+                out = run()
         ev1.record()
         torch.cuda.synchronize()
         wall = time.perf_counter() - t0   # this rank's K steps, drained; the MAX over ranks below is the job's time
@@ -365,7 +368,7 @@ def main():
     ap.add_argument("--nodes", type=int, default=256)
     ap.add_argument("--graphs", type=int, default=1, help="independent graphs per GPU per step")
     ap.add_argument("--L", type=int, default=4)
-    ap.add_argument("--mode", choices=["auto", "eager", "graph"], default="auto",
+    ap.add_argument("--mode", choices=["auto", "eager", "graph", "graphk"], default="auto",
                     help="eager: one C-ABI call per step; graph: the same call captured once in a HIP graph and replayed; "
                          "auto: time 50 steps of each after warm-up and keep the faster (reported in config.mode)")
     ap.add_argument("--edge-state", choices=["fp32", "bf16"], default="fp32",
@@ -467,17 +470,61 @@ def main():
             torch.cuda.synchronize()
             return (time.perf_counter() - t0) / n
 
-        mode_used, static_out, run = "eager", None, eager_run
-        if args.mode in ("graph", "auto"):
+        def try_capture_block(k):
+            """The K steps of a timed block -- K whole forwards, each with all of its launches -- captured back to back in ONE HIP graph:
+            the launch-bound loop runs without the host in it (a block of eager launches pays the first launch's latency and the GPU's
+            lag behind the host once per block: ~50 us, 2.5 us per step at K = 20).  Every forward still allocates its own outputs."""
+            try:
+                out_bytes = 4 * min(args.L, 3) * E
+                if k * out_bytes > (1 << 30):
+                    return None, None
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    for _ in range(k):
+                        out_k = model(data)
+
+                def replay_block():
+                    graph.replay()
+                    return out_k
+                return replay_block, out_k
+            except Exception as exc:  # noqa: BLE001
+                print(f"[bench] HIP graph capture of a {k}-step block failed ({type(exc).__name__}: {exc})", file=sys.stderr)
+                torch.cuda.synchronize()
+                return None, None
+
+        def quick_block(fn_block, fn_step, n=3):
+            """seconds per step of a block run as the timed region runs it"""
+            best = float("inf")
+            for _ in range(n):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                if fn_block is not None:
+                    fn_block()
+                else:
+                    for _ in range(args.steps):
+                        fn_step()
+                torch.cuda.synchronize()
+                best = min(best, (time.perf_counter() - t0) / args.steps)
+            return best
+
+        mode_used, static_out, run, run_block = "eager", None, eager_run, None
+        if args.mode in ("graph", "graphk", "auto"):
             replay, out_static = try_capture()
             if replay is None:
                 mode_used = "eager (graph capture failed)"
-            elif args.mode == "graph" or quick_time(replay) < quick_time(eager_run):
+            elif args.mode == "graph" or (args.mode == "auto" and quick_time(replay) < quick_time(eager_run)):
                 mode_used, static_out, run = "graph", out_static, replay
+            if replay is not None and args.mode in ("graphk", "auto"):
+                blk, out_k = try_capture_block(args.steps)
+                if blk is not None:
+                    blk()   # one untimed replay
+                    if args.mode == "graphk" or quick_block(blk, None) < quick_block(None, run):
+                        mode_used, static_out, run_block = f"graph of {args.steps} forwards per block", out_k, blk
             if args.mode == "auto":
                 mode_used += " (auto)"
 
-        blocks, out = timed_blocks(run, args.steps, args.warmup, dist, device, args.backend, min_blocks=args.min_blocks)
+        blocks, out = timed_blocks(run, args.steps, args.warmup, dist, device, args.backend, min_blocks=args.min_blocks,
+                                   run_block=run_block)
         t = blocks[len(blocks) // 2]      # median block of K steps (max over ranks inside every block)
         # every rank's OWN time per step (no barrier inside), gathered: how evenly the ranks run
         rank_ms = None
