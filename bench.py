@@ -18,7 +18,9 @@ sharded 512/N per rank through gnn_cca_amd.sharding.forward_sharded, timed the s
 
 Timing: >= 10 blocks of exactly `--steps` steps, each block bracketed by barrier + synchronize on both sides and reduced
 with MAX over ranks; the MEDIAN block is reported (ms_per_step = median block / steps), so a short `--steps` run is not
-one sub-millisecond sample.
+one sub-millisecond sample.  How the K steps of a block are issued is `--mode`: K eager C-ABI calls, K replays of a one-forward
+HIP graph, or ONE replay of a HIP graph that holds the K forwards back to back (every launch of every forward; nothing cached or
+skipped) -- `auto` keeps the fastest and says so in `config.mode`.
 
 Prints ONE JSON line (rank 0) with the driver's contract plus `roofline` (dominant kernel mpn_step_kernel, per-launch
 algorithmic bytes / HIP-event duration) and `cpu_baseline` (the reference-shaped torch CPU
@@ -369,8 +371,9 @@ def main():
     ap.add_argument("--graphs", type=int, default=1, help="independent graphs per GPU per step")
     ap.add_argument("--L", type=int, default=4)
     ap.add_argument("--mode", choices=["auto", "eager", "graph", "graphk"], default="auto",
-                    help="eager: one C-ABI call per step; graph: the same call captured once in a HIP graph and replayed; "
-                         "auto: time 50 steps of each after warm-up and keep the faster (reported in config.mode)")
+                    help="eager: one C-ABI call per step; graph: the same call captured once in a HIP graph and replayed per step; "
+                         "graphk: the K forwards of a timed block captured back to back in one HIP graph, replayed once per block; "
+                         "auto: time each form after warm-up and keep the fastest (reported in config.mode)")
     ap.add_argument("--edge-state", choices=["fp32", "bf16"], default="fp32",
                     help="storage of the edge latents between steps (bf16: GNNCCA_OPT_EDGE_STATE_BF16; arithmetic stays fp32)")
     ap.add_argument("--enc-products", type=int, choices=[6, 3], default=6,

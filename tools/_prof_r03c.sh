@@ -1,7 +1,7 @@
 # Round 3, fourth (final) collection: every workload of the first two, with the final kernels (plan riding in the 128-row GEMM,
 # the plan's up-front padded-layout check, the tail's preloaded weights, the 256-row epilogue in quarter order, plan_only_kernel, the MFMA tail from 2560 nodes).
 set -x
-python3 tools/collect_profiles.py r03_dense256 -- --steps 20 --warmup 5
+python3 tools/collect_profiles.py r03_dense256 -- --steps 20 --warmup 5 --mode eager
 python3 tools/collect_profiles.py r03_64x256 -- --graphs 64 --nodes 256 --steps 40 --warmup 5 --mode eager
 python3 tools/collect_profiles.py r03_512x128 -- --graphs 512 --nodes 128 --steps 20 --warmup 3 --mode eager
 python3 tools/collect_profiles.py r03_64x128 -- --graphs 64 --nodes 128 --steps 60 --warmup 5 --mode eager
