@@ -647,6 +647,10 @@ def main():
                                  "round trips (latency), `frac` is still algorithmic bytes / time / HBM peak; "
                                  "`roofline_at_scale` is the same kernel where HBM is the bound" if cache_resident else ""},
             "kernels_us": {k: float(np.mean(v)) * 1e3 for k, v in kernel_ms.items()},
+            "kernels_us_note": "per-kernel times of a SEPARATE eager pass with start / stop events attached to each dispatch "
+                               "(gnncca_mpn_forward_profiled); a dispatch's span includes its own launch latency, which consecutive "
+                               "kernels of a HIP-graph block overlap -- with config.mode = 'graph of K forwards per block' ms_per_step "
+                               "can therefore be below the sum of these",
         }
         if cfg4 is not None:
             res["config4_sharded"] = cfg4
