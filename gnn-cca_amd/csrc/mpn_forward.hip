@@ -435,7 +435,12 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
         sp.wps = wps;
     }
     sp.hin = hin;
-    sp.pd_lds = (N <= 1024) && d->num_enc_steps > 0;
+    // the P_dst gather table staged whole in LDS: graphs of 801 ... 1024 nodes only.  (Rounds 1-2 staged it for every N <= 1024; measured with
+    // a block of 200 forwards in one HIP graph, gathers straight from L2 are ahead below that: dense32 / 64 / 128 / 256 / 384 / 512 / 768
+    // -1.5 / -2 / -1.5 / -1.5 / -4 / -2.7 / -1.3 % per forward, dense1024 (L = 8) +1 %; profiles/r03_logs/r3_pdlds2.log, r3_pdlds3.log)
+    static const int pd_lds_max = diag_env("GNNCCA_PD_LDS_MAX") ? std::atoi(diag_env("GNNCCA_PD_LDS_MAX")) : 1024;   // diagnostics
+    static const int pd_lds_min = diag_env("GNNCCA_PD_LDS_MIN") ? std::atoi(diag_env("GNNCCA_PD_LDS_MIN")) : 801;
+    sp.pd_lds = (N >= pd_lds_min && N <= pd_lds_max) && d->num_enc_steps > 0;
     sp.e_bf16 = (options & GNNCCA_OPT_EDGE_STATE_BF16) != 0;  // honoured by the specialised kernels only
     sp.ell_S = use_ell ? ws.ell_S : 0;
     sp.drop = drop;

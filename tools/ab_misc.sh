@@ -1,7 +1,4 @@
-# GPU box: step kernels compiled for 5 / 6 waves per SIMD (diagnostic twins, -DGNNCCA_FAST_WAVES) at the latency-bound mid sizes
-for rep in 1 2; do
-for spec in 32x128 64x128 128x128 16x256 1x1024; do
-echo "--- default (4 waves per SIMD) $spec"; python3 tools/exp_sizes.py $spec
-echo "--- forced 5 waves $spec"; GNNCCA_LIB=$PWD/gnn-cca_amd/lib/libgnncca_mpn_w5.so python3 tools/exp_sizes.py $spec
-echo "--- forced 6 waves $spec"; GNNCCA_LIB=$PWD/gnn-cca_amd/lib/libgnncca_mpn_w6.so python3 tools/exp_sizes.py $spec
-done; done 2>&1 | grep -v amdgpu.ids
+for spec in "--nodes 1024 --L 8" "--nodes 768" "--nodes 512" "--nodes 384" "--nodes 128" "--nodes 32"; do for rep in 1 2; do
+echo "--- table in LDS $spec"; python3 bench.py $spec --no-cpu-baseline --no-scale-probe --no-config4 --profile-reps 0 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['ms_per_step']*1e3, d['config']['mode'])"
+echo "--- gathers from L2 $spec"; GNNCCA_DIAG=1 GNNCCA_PD_LDS_MAX=0 python3 bench.py $spec --no-cpu-baseline --no-scale-probe --no-config4 --profile-reps 0 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['ms_per_step']*1e3, d['config']['mode'])"
+done; done
