@@ -707,6 +707,7 @@ struct TailParams {
     float* psq_out;
     int off_prev_b, off_lastWT, off_last_b, off_projwT, off_projb;
     int ks, F, N, has_last, relu_prev, reatt_n, hin, vec_reduce;
+    int npw;   // enc_tail_fast_kernel: nodes (= waves that work) per workgroup, 1 / 2 / 4 (0 = 4)
     // graph-plan repair (runs in the extra last workgroup only when the graph was flagged unsorted)
     const long long* ei;
     int* seg_ptr;
@@ -867,6 +868,10 @@ __global__ __launch_bounds__(256) void enc_tail_fast_kernel(const TailParams p) 
         return;
     }
     const int nblk = gridDim.x - 1;
+    // small graphs: fewer nodes per workgroup, so that the slab reads of the graph's nodes spread over more CUs (a CU takes its
+    // 16 KB per node from L2 at a few ten GB/s; the other waves of the workgroup leave at once: no barrier in this kernel)
+    const int npw = p.npw > 0 ? p.npw : 4;
+    if (wave >= npw) return;
     const int o = lane & 31, half = lane >> 5;
     // split-K partial sum of one node row: lane (rg = half, rc = o) sums the slabs s = rg, rg + 2, ... of columns 4 rc .. 4 rc + 3
     auto partial_sum = [&](int node) {
@@ -879,7 +884,7 @@ __global__ __launch_bounds__(256) void enc_tail_fast_kernel(const TailParams p) 
         }
         return a;
     };
-    f32x4 pre = partial_sum(blockIdx.x * 4 + wave);
+    f32x4 pre = partial_sum(blockIdx.x * npw + wave);
     // the wave's share of the weights, once
     float w2[64], wp[kH];
 #pragma unroll
@@ -890,10 +895,10 @@ __global__ __launch_bounds__(256) void enc_tail_fast_kernel(const TailParams p) 
     const f32x4 b1 = *reinterpret_cast<const f32x4*>(blob + p.off_prev_b + 4 * o);
     const float last_b = blob[p.off_last_b + o];
     const float proj_b = blob[p.off_projb + po];
-    for (int grp = blockIdx.x; grp * 4 < p.N; grp += nblk) {
-        const int node = grp * 4 + wave;
+    for (int grp = blockIdx.x; grp * npw < p.N; grp += nblk) {
+        const int node = grp * npw + wave;
         f32x4 row = pre;
-        pre = partial_sum((grp + nblk) * 4 + wave);  // next node of this wave, in flight during the arithmetic below
+        pre = partial_sum((grp + nblk) * npw + wave);  // next node of this wave, in flight during the arithmetic below
         if (node >= p.N) continue;
         // both halves -> the full split-K sum, + bias, ReLU: lane l holds columns 4 (l & 31) .. + 3 of the 128-wide row
         // (same association as enc_tail_kernel, so that both tails agree bit for bit: (bias + even slabs) + odd slabs)

@@ -369,8 +369,15 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
                                (reinterpret_cast<uintptr_t>(part) & 15) == 0;
         if (fused_tail) {
             // nothing: h0, the projections and the plan's flag word all came out of the GEMM launch
-        } else if (tail_fast)
-            GNNCCA_LAUNCH(enc_tail_fast_kernel, dim3(blocks), dim3(256), 0, st, tp);
+        } else if (tail_fast) {
+            static const int tail_npw = diag_env("GNNCCA_TAIL_NPW") ? std::atoi(diag_env("GNNCCA_TAIL_NPW")) : 0;   // diagnostics
+            // nodes per workgroup: one up to 320 nodes, two up to 640, four beyond (a block of 200 forwards in one HIP graph: dense256 28.07 ->
+            // 27.4 us per forward with one, dense64 24.7 -> 24.1; dense512 39.97 -> 39.5-39.8 with two; dense1024 best with four;
+            // profiles/r03_logs/r3_tailnpw1.log)
+            tp.npw = tail_npw == 1 || tail_npw == 2 || tail_npw == 4 ? tail_npw : (N <= 320 ? 1 : (N <= 640 ? 2 : 4));
+            const unsigned fblocks = (unsigned)std::min<size_t>(((size_t)N + tp.npw - 1) / tp.npw, 2048) + 1;
+            GNNCCA_LAUNCH(enc_tail_fast_kernel, dim3(fblocks), dim3(256), 0, st, tp);
+        }
         else if (tail_mfma)
             GNNCCA_LAUNCH(enc_tail_mfma_kernel, dim3((unsigned)((N + 31) / 32) + 1), dim3(256), 0, st, tp,
                           blob + hdr.enc_node_w[nl - 1]);
