@@ -492,7 +492,8 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
         static const bool step_nomem = diag_env("GNNCCA_STEP_NOMEM") != nullptr;   // diagnostics: arithmetic-only timing of the step kernel
         static const bool step_noepi = diag_env("GNNCCA_STEP_NOEPI") != nullptr;   // diagnostics: what the projection epilogue costs
         static const bool step_nohook = diag_env("GNNCCA_STEP_NOHOOK") != nullptr;   // diagnostics: second round's state requested after the first round
-        sp.diag = (step_nomem ? 1 : 0) | (step_noepi ? 2 : 0) | (step_nohook ? 4 : 0);
+        static const bool step_earlybar = diag_env("GNNCCA_STEP_EARLYBAR") != nullptr;   // diagnostics: the staging barrier in front of the loop even with several waves per node
+        sp.diag = (step_nomem ? 1 : 0) | (step_noepi ? 2 : 0) | (step_nohook ? 4 : 0) | (step_earlybar ? 8 : 0);
         const bool pipe_ok = fast && !sp.msg_f32;
         if (pipe_ok)
             err = launch_pipe_dispatch(sp, msg, st);

@@ -132,7 +132,9 @@ __global__ __launch_bounds__(256) GNNCCA_FAST_ATTR void mpn_step_pipe_kernel(con
             if (tid + i * 256 < pd_n4) l4[tid + i * 256] = stage_pd[i];
     }
     GNNCCA_STAMP(p.stamp_slot, 1);
-    if (MSG || PD_LDS) __syncthreads();
+    // (with several waves per node the cross-wave combine below has a barrier of its own in front of the epilogue, the only reader of
+    // s_proj: no early barrier then unless the gathers need s_pd)
+    if (PD_LDS || (MSG && (wps == 1 || (p.diag & 8)))) __syncthreads();   // (diag bit 3: A/B with the early barrier of rounds 1-2)
     GNNCCA_STAMP(p.stamp_slot, 2);
     auto round_body = [&](int rb, Chunk& a, Chunk& b, int sid, int sland, int sdone) {
         load_target(a);
