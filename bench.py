@@ -382,6 +382,7 @@ def main():
     ap.add_argument("--enc-unsplit", action="store_true",
                     help="GNNCCA_OPT_ENC_UNSPLIT: forwards over >= 4096 nodes never split K in the first encoder layer (a graph's logits "
                          "are then bitwise independent of its batch / shard; off by default)")
+    ap.add_argument("--streams", type=int, default=3, help="forwards in flight of the `pipelined` leg (N = 1, --mode auto; 0 / 1: skip)")
     ap.add_argument("--no-scale-probe", action="store_true", help="skip the 64-graph batch probe of the step kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-config4", action="store_true", help="skip the sharded 512 x dense128 leg (BASELINE config 4)")
@@ -442,93 +443,81 @@ def main():
     N = data.x.shape[0]
 
     with torch.no_grad():
+        from gnn_cca_amd.inference import GraphedForward   # the product API of the graph forms (inference.py:173-283's per-frame loop)
+
         def eager_run():
             return model(data)
 
-        def try_capture():
-            """The whole forward (no sync / malloc / memset inside the C ABI call) captured once in a HIP graph."""
+        # The three issue forms of a block of K steps, each through the package API a caller would use:
+        #   eager        K calls of MOTMPNet.forward (one C-ABI call, six launches, per step)
+        #   graph        K replays of GraphedForward's one-forward HIP graph; the frame lives in the graph's static input buffers
+        #                (`static_inputs`: the producer writes each frame there), so a replay copies nothing
+        #   graph_block  ONE replay of GraphedForward.block([frame] * K, adopt_inputs=True): the K forwards -- every launch of each,
+        #                each with its own outputs -- captured back to back in one HIP graph
+        # `auto` times all three with the same block protocol, reports each in config.ms_per_step_by_mode and keeps the fastest as
+        # `value`.  `pipelined` (extra object) is GraphedForward(streams=S).submit: S forwards in flight; never `value`.
+        forms = {"eager": (eager_run, None)}
+        gf = GraphedForward(model, warmup=0)
+        if args.mode in ("graph", "graphk", "auto"):
             try:
-                side = torch.cuda.Stream()
-                side.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(side):
-                    for _ in range(3):
-                        model(data)
-                torch.cuda.current_stream().wait_stream(side)
-                graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
-                    out_static = model(data)
-                return graph.replay, out_static
+                static = gf.static_inputs(data)
+                static.x.copy_(data.x), static.edge_index.copy_(data.edge_index), static.edge_attr.copy_(data.edge_attr)
+                gf(static)
+                forms["graph"] = (lambda: gf(static), None)
             except Exception as exc:  # noqa: BLE001
                 print(f"[bench] HIP graph capture failed ({type(exc).__name__}: {exc}); using eager launches", file=sys.stderr)
                 torch.cuda.synchronize()
-                return None, None
-
-        def quick_time(fn, n=50):
-            for _ in range(5):
-                fn()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(n):
-                fn()
-            torch.cuda.synchronize()
-            return (time.perf_counter() - t0) / n
-
-        def try_capture_block(k):
-            """The K steps of a timed block -- K whole forwards, each with all of its launches -- captured back to back in ONE HIP graph:
-            the launch-bound loop runs without the host in it (a block of eager launches pays the first launch's latency and the GPU's
-            lag behind the host once per block: ~50 us, 2.5 us per step at K = 20).  Every forward still allocates its own outputs."""
-            try:
-                out_bytes = 4 * min(args.L, 3) * E
-                if k * out_bytes > (1 << 30):
-                    return None, None
-                graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
-                    for _ in range(k):
-                        out_k = model(data)
-
-                def replay_block():
-                    graph.replay()
-                    return out_k
-                return replay_block, out_k
-            except Exception as exc:  # noqa: BLE001
-                print(f"[bench] HIP graph capture of a {k}-step block failed ({type(exc).__name__}: {exc})", file=sys.stderr)
-                torch.cuda.synchronize()
-                return None, None
-
-        def quick_block(fn_block, fn_step, n=3):
-            """seconds per step of a block run as the timed region runs it"""
-            best = float("inf")
-            for _ in range(n):
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                if fn_block is not None:
-                    fn_block()
-                else:
-                    for _ in range(args.steps):
-                        fn_step()
-                torch.cuda.synchronize()
-                best = min(best, (time.perf_counter() - t0) / args.steps)
-            return best
-
-        mode_used, static_out, run, run_block = "eager", None, eager_run, None
-        if args.mode in ("graph", "graphk", "auto"):
-            replay, out_static = try_capture()
-            if replay is None:
-                mode_used = "eager (graph capture failed)"
-            elif args.mode == "graph" or (args.mode == "auto" and quick_time(replay) < quick_time(eager_run)):
-                mode_used, static_out, run = "graph", out_static, replay
-            if replay is not None and args.mode in ("graphk", "auto"):
-                blk, out_k = try_capture_block(args.steps)
-                if blk is not None:
-                    blk()   # one untimed replay
-                    if args.mode == "graphk" or quick_block(blk, None) < quick_block(None, run):
-                        mode_used, static_out, run_block = f"graph of {args.steps} forwards per block", out_k, blk
-            if args.mode == "auto":
-                mode_used += " (auto)"
-
-        blocks, out = timed_blocks(run, args.steps, args.warmup, dist, device, args.backend, min_blocks=args.min_blocks,
-                                   run_block=run_block)
+            out_bytes = 4 * min(args.L, 3) * E
+            if "graph" in forms and args.mode in ("graphk", "auto") and args.steps * out_bytes <= (1 << 30):
+                try:
+                    blk = gf.block([data] * args.steps, adopt_inputs=True)
+                    blk.replay()
+                    forms["graph_block"] = (None, lambda: blk.replay()[-1])
+                except Exception as exc:  # noqa: BLE001
+                    print(f"[bench] HIP graph capture of a {args.steps}-step block failed ({type(exc).__name__}: {exc})", file=sys.stderr)
+                    torch.cuda.synchronize()
+        want = {"eager": ["eager"], "graph": ["graph"], "graphk": ["graph_block"], "auto": ["eager", "graph", "graph_block"]}[args.mode]
+        timed = {}
+        for name in want:
+            if name not in forms:
+                continue
+            run_f, run_b = forms[name]
+            timed[name] = timed_blocks(run_f, args.steps, args.warmup, dist, device, args.backend, min_blocks=args.min_blocks,
+                                       run_block=run_b)
+        if not timed:   # the requested graph form could not be captured
+            timed["eager"] = timed_blocks(eager_run, args.steps, args.warmup, dist, device, args.backend, min_blocks=args.min_blocks)
+        by_mode = {k: v[0][len(v[0]) // 2] / args.steps * 1e3 for k, v in timed.items()}
+        best = min(by_mode, key=by_mode.get)
+        blocks, out = timed[best]
+        api = {"eager": "gnn_cca_amd.MOTMPNet.forward, one call per step (eager)",
+               "graph": "gnn_cca_amd.inference.GraphedForward.__call__, one HIP-graph replay per step (static inputs, no copies)",
+               "graph_block": f"gnn_cca_amd.inference.GraphedForward.block, one HIP graph of {args.steps} forwards per block"}
+        mode_used = api[best] + (" (auto: fastest of " + ", ".join(sorted(by_mode)) + ")" if args.mode == "auto" else "")
+        run = forms[best][0] or eager_run
         t = blocks[len(blocks) // 2]      # median block of K steps (max over ranks inside every block)
+        # S forwards in flight (GraphedForward(streams=S).submit; frames copied into each stream's static inputs): whole-job
+        # throughput of independent frames, reported beside `value`, never as `value`
+        pipelined = None
+        if world == 1 and args.streams > 1 and args.mode == "auto" and "graph" in forms:
+            try:
+                gfs = GraphedForward(model, streams=args.streams)
+                frames_s = [make_data(args.nodes, args.graphs, 100 + i, device) for i in range(args.streams)]
+
+                def run_streams():
+                    pend = [gfs.submit(f) for f in frames_s]
+                    return [p.result() for p in pend][-1]
+                k_s = max(1, args.steps // args.streams)
+                blocks_s, _ = timed_blocks(run_streams, k_s, max(1, args.warmup // args.streams), None, device, args.backend,
+                                           min_blocks=args.min_blocks)
+                t_s = blocks_s[len(blocks_s) // 2]
+                pipelined = {"api": f"gnn_cca_amd.inference.GraphedForward(streams={args.streams}).submit", "streams": args.streams,
+                             "ms_per_forward": t_s / (k_s * args.streams) * 1e3, "value": E * k_s * args.streams / t_s, "unit": "edges/s",
+                             "note": "independent frames, each copied into its stream's static inputs and replayed from that stream's HIP "
+                                     "graph on its own workspace; every forward complete; not `value`"}
+                del gfs, frames_s
+            except Exception as exc:  # noqa: BLE001
+                pipelined = {"error": f"{type(exc).__name__}: {exc}"}
+                torch.cuda.synchronize()
         # every rank's OWN time per step (no barrier inside), gathered: how evenly the ranks run
         rank_ms = None
         if world > 1:
@@ -543,12 +532,10 @@ def main():
             all_ms = [torch.zeros(1, dtype=torch.float64, device=dev_) for _ in range(world)]
             dist.all_gather(all_ms, torch.tensor([own], dtype=torch.float64, device=dev_))
             rank_ms = [float(v.item()) for v in all_ms]
-        if static_out is not None:
-            out = static_out
         ok = all(torch.isfinite(o).all().item() for o in out["classified_edges"])
 
         # ---- BASELINE config 4: 512 independent dense128 graphs, sharded 512/N per rank (forward_sharded) ----------
-        cfg4 = None
+        cfg4, share = None, None
         if not args.no_config4:
             from gnn_cca_amd.sharding import forward_sharded, shard_batch
             m4 = build_model(graph_net_params(L=4), 128, seed=rank).to(device)
@@ -578,6 +565,28 @@ def main():
                     "graphs_per_rank": hi4 - lo4, "edges_rank0": e4_local, "steps": steps4, "blocks": len(blocks4),
                     "ms_per_step": t4 / steps4 * 1e3, "outputs_finite": bool(ok4),
                     "kernels_us_rank0": {k: float(np.mean(v)) * 1e3 for k, v in k4.items()}}
+            # N = 1: the per-GPU share of the 8-GPU run of the same job (graphs [0, 512/8) of the SAME lazy sequence, as rank 0 of 8
+            # would build it) timed on this GPU, same box, same run: the only strong-scaling evidence obtainable without an 8-GPU
+            # node -- projected_8gpu_speedup = union ms / share ms (no collective on the data path; the broadcast is one-time)
+            share = None
+            if world == 1 and args.config4_graphs % 8 == 0:
+                lo8, hi8, batch8 = shard_batch(graphs4, 0, 8)
+                blocks8, _ = timed_blocks(lambda: forward_sharded(m4, graphs4, 0, 8, batch=batch8), steps4, min(args.warmup, 10), None,
+                                          device, args.backend, min_blocks=5, min_total_s=0.1)
+                t8 = blocks8[len(blocks8) // 2]
+                k8 = {}
+                for _ in range(5):
+                    _, times8 = m4.forward_profiled(batch8)
+                    for kind, ms in times8:
+                        k8.setdefault(kind, []).append(ms)
+                share = {"workload": f"{hi8 - lo8} x dense128 graphs (E={batch8.edge_index.shape[1]}): rank 0's share of "
+                                     f"{args.config4_graphs} graphs over 8 GPUs, run on this one GPU",
+                         "ms_per_step": t8 / steps4 * 1e3, "union_ms_per_step": t4 / steps4 * 1e3,
+                         "projected_8gpu_speedup": t4 / t8, "target": 6.0,
+                         "kernels_us": {k: float(np.mean(v)) * 1e3 for k, v in k8.items()},
+                         "note": "projection from one-GPU measurements, not an 8-GPU measurement: every rank runs this share "
+                                 "concurrently with no data-path collective"}
+                del batch8
             del m4, graphs4, batch4, res4
 
         # per-kernel durations (HIP events attached to every dispatch; separate pass so the timed region is undisturbed)
@@ -626,7 +635,7 @@ def main():
             "config": {"workload": f"{args.graphs} x dense{args.nodes} graph(s) per GPU per step "
                                    f"(N={N}, E={E}), feat 2048, L={args.L}, 3 classified steps, fp32 arithmetic, "
                                    f"{args.edge_state} edge state, eval",
-                       "mode": mode_used, "edge_state": args.edge_state, "edge_state_storage": "bf16" if args.edge_state == "bf16" else "f32",
+                       "mode": mode_used, "ms_per_step_by_mode": by_mode, "edge_state": args.edge_state, "edge_state_storage": "bf16" if args.edge_state == "bf16" else "f32",
                        "encoder_products": args.enc_products, "encoder_unsplit": args.enc_unsplit,
                        "outputs_finite": bool(ok),
                        "edge_steps_per_s": world * E * args.L * args.steps / t,
@@ -652,8 +661,12 @@ def main():
                                "kernels of a HIP-graph block overlap -- with config.mode = 'graph of K forwards per block' ms_per_step "
                                "can therefore be below the sum of these",
         }
+        if pipelined is not None:
+            res["pipelined"] = pipelined
         if cfg4 is not None:
             res["config4_sharded"] = cfg4
+            if share is not None:
+                res["config4_share"] = share
         if world == 1 and args.graphs == 1 and not args.no_scale_probe:
             res["roofline_at_scale"] = scale_probe(params, device, args)
         if world == 1 and not args.no_cpu_baseline:

@@ -14,6 +14,7 @@ extern thread_local int g_last_hip_error;  // hipError_t of the last failed HIP 
 // summation order, so the shipped library ignores every one of them unless GNNCCA_DIAG=1 is set in the same environment:
 // a stray variable in one rank's environment cannot silently change its numerics.
 const char* diag_env(const char* name);
+int diag_env_int(const char* name, int fallback, int lo, int hi);
 
 constexpr uint32_t kBlobMagic = 0x4D504E34u;  // "MPN4": bumped with every change of the blob layout (a blob is only
                                               // valid for the library build that packed it; load_packed_blob checks)

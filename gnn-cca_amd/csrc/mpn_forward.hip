@@ -437,7 +437,12 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
         const long long want = (chunks >= 32 ? 16384 : 4096) / (long long)N;
         int wps = chunks >= 4 ? 4 : (chunks >= 2 ? 2 : 1);
         while (wps > 1 && wps > want) wps >>= 1;
-        static const int force_wps = diag_env("GNNCCA_WPS") ? std::atoi(diag_env("GNNCCA_WPS")) : 0;  // diagnostics
+        // GNNCCA_OPT_ENC_UNSPLIT promises logits that do not depend on the batch around a graph for batches of >= 4096 nodes: the
+        // cross-wave combine sums in another order with another wave count, and `want` above depends on N (a shard of 2 x dense2048
+        // would get four waves per node, the union of 8 one), so the option pins one wave per node there, the rule of every round
+        // before the four-wave one (tests/test_gpu_sharded.py: dense2048 shard against its union, bitwise)
+        if ((options & GNNCCA_OPT_ENC_UNSPLIT) != 0 && N >= 4096) wps = 1;
+        static const int force_wps = diag_env_int("GNNCCA_WPS", 0, 1, 4);  // diagnostics
         if (force_wps == 1 || force_wps == 2 || force_wps == 4) wps = std::min(force_wps, chunks >= 4 ? 4 : (chunks >= 2 ? 2 : 1));
         sp.wps = wps;
     }

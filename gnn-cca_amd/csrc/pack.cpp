@@ -11,6 +11,7 @@
 //       [ x[row] | edge_attr ]           ->  W_nx (per-node projection Q) and W_ne (per edge, MFMA B operand)
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -573,12 +574,50 @@ GenWorkspace carve_generic(const gnncca_mpn_dims* d, int64_t n, int64_t e) {
     return w;
 }
 
+// The diagnostic switches this build reads.  With the gate open, a GNNCCA_* variable that is NOT in this list is
+// reported once on stderr: a stale A/B script then says so in its log instead of comparing a build with itself.
+static const char* const kDiagSwitches[] = {
+    "GNNCCA_DIAG", "GNNCCA_LIB", "GNNCCA_STEP_R2", "GNNCCA_STEP_NOMEM", "GNNCCA_STEP_NOEPI", "GNNCCA_STEP_NOHOOK", "GNNCCA_STEP_EARLYBAR",
+    "GNNCCA_STEP_NORANGE", "GNNCCA_PD_LDS_MIN", "GNNCCA_PD_LDS_MAX", "GNNCCA_TAIL_NPW", "GNNCCA_WPS", "GNNCCA_NO_NT", "GNNCCA_NO_PAD",
+    "GNNCCA_GEMM_DIRECT", "GNNCCA_GEMM_SPLIT_MIN", "GNNCCA_GEMM_LDS_MIN", "GNNCCA_GEMM_NOPIPE", "GNNCCA_NO_FUSE", "GNNCCA_NO_MFMA_TAIL",
+    "GNNCCA_TAIL_MFMA_MIN", "GNNCCA_NO_RIDE", "GNNCCA_GEMM_DIRECT_WG", "GNNCCA_GEMM_R32_NST", "GNNCCA_GEMM_M128", "GNNCCA_GEMM_BK"};
+
+extern "C" char** environ;
+
 const char* diag_env(const char* name) {
     static const bool on = [] {
         const char* v = std::getenv("GNNCCA_DIAG");
-        return v != nullptr && v[0] == '1' && v[1] == '\0';
+        const bool open = v != nullptr && v[0] == '1' && v[1] == '\0';
+        if (open && environ) {
+            for (char** e = environ; *e; ++e) {
+                if (std::strncmp(*e, "GNNCCA_", 7) != 0) continue;
+                const char* eq = std::strchr(*e, '=');
+                const size_t len = eq ? (size_t)(eq - *e) : std::strlen(*e);
+                bool known = false;
+                for (const char* k : kDiagSwitches) known = known || (std::strlen(k) == len && std::strncmp(k, *e, len) == 0);
+                if (!known) {
+                    std::fprintf(stderr, "[gnncca] GNNCCA_DIAG=1: '%.*s' is not a switch of this build and is ignored; recognised:", (int)len, *e);
+                    for (const char* k : kDiagSwitches) std::fprintf(stderr, " %s", k);
+                    std::fprintf(stderr, "\n");
+                }
+            }
+        }
+        return open;
     }();
     return on ? std::getenv(name) : nullptr;
+}
+
+// An integer-valued diagnostic switch: `fallback` when unset; a value outside [lo, hi] is reported once and ignored.
+int diag_env_int(const char* name, int fallback, int lo, int hi) {
+    const char* v = diag_env(name);
+    if (!v) return fallback;
+    char* end = nullptr;
+    const long x = std::strtol(v, &end, 10);
+    if (end == v || *end != '\0' || x < lo || x > hi) {
+        std::fprintf(stderr, "[gnncca] GNNCCA_DIAG=1: %s=%s is outside [%d, %d] and is ignored (default %d)\n", name, v, lo, hi, fallback);
+        return fallback;
+    }
+    return (int)x;
 }
 
 int ell_stride(const gnncca_mpn_dims* d, int64_t n, int64_t e) {

@@ -281,8 +281,11 @@ __global__ __launch_bounds__(256) GNNCCA_FAST_ATTR void mpn_step_fast_kernel(con
             if (tid + i * 256 < pd_n4) l4[tid + i * 256] = stage_pd[i];
     }
     GNNCCA_STAMP(p.stamp_slot, 1);
-    // (with several waves per node the cross-wave combine below has a barrier of its own in front of the epilogue, the only reader of
-    // s_proj: no early barrier then unless the gathers need s_pd)
+    // INVARIANT (shared with mpn_step_pipe_kernel): between the staging stores above and the combine's __syncthreads() below NOTHING reads
+    // s_proj or s_part, and no wave returns or skips that barrier (the BAD_INDEX return above is block-uniform and precedes the stores).
+    // With several waves per node the cross-wave combine's barrier is therefore the one that publishes s_proj to the epilogue, its only
+    // reader, and no early barrier is needed unless the gathers read s_pd.  A new LDS read in between, or a per-wave early exit, turns
+    // this into a silent race: GNNCCA_STEP_EARLYBAR (diag bit 3) restores the early barrier to bisect such a change.
     if (PD_LDS || (MSG && (wps == 1 || (p.diag & 8)))) __syncthreads();   // (diag bit 3: A/B with the early barrier of rounds 1-2)
     GNNCCA_STAMP(p.stamp_slot, 2);
     auto round_body = [&](int rb, Chunk& a, Chunk& b) {

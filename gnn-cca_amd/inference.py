@@ -1,0 +1,252 @@
+"""HIP-graph replay of the eval forward for the reference's per-frame inference loop.
+
+The caller of the hot path at inference time is a loop over frames, `inference.py:173-283`: build the frame's graph, then
+`outputs = mpn_model(data_batch)` (inference.py:283) -- one forward per frame.  On this path a forward of a frame-sized graph is
+six kernel launches of 4-7 us each, i.e. it is bound by launching, not by the kernels: an eager call costs
+the host ~30 us, about what the GPU needs.  `MOTMPNet.forward` in eval mode allocates nothing but its outputs, never
+synchronises and enqueues only on the current stream, so the whole call can be captured ONCE per input shape into a HIP graph and
+replayed: `GraphedForward` does that, in three forms.
+
+    gf = GraphedForward(model)                       # model: gnn_cca_amd.MOTMPNet, on the GPU, eval mode
+    for data in frames:
+        out = gf(data)                               # same dict as model(data); valid until the next call of this shape
+        preds = out['classified_edges'][-1].view(-1) # inference.py:286
+
+  * `gf(data)`: capture per input shape (after `warmup` eager calls of that shape), STATIC input buffers: the frame is copied
+    into the buffers the graph was captured on (three device-to-device copies on the current stream) and the graph is replayed.
+    A caller that produces its frames IN those buffers (`gf.static_inputs(data)`, e.g. as the output tensors of the graph-build
+    step) skips the copies: `gf(static)` sees its own tensors and replays at once.
+  * `gf.block(frames)`: K frames captured BACK TO BACK in one HIP graph (K whole forwards, every launch of each, each with its own
+    outputs) -- the K-deep form: one graph launch per K frames, the launch-bound loop runs without the host in it.
+    `blk.replay()` -> list of K output dicts; `blk.inputs[i]` are the static buffers of frame i.
+  * `streams=S`: S independent forwards in flight, each stream replaying its own graph on its own workspace (the module keeps a
+    workspace per stream; the packed weights are shared and read-only).  `gf.submit(data)` returns a `Pending` whose
+    `.result()` makes the CURRENT stream wait for that forward only.
+
+Replays are bitwise the eager forward (same kernels, same launch parameters, same order: tests/test_gpu_inference_graph.py).
+No CPU fallback, no caching of results: every replay runs every kernel of every forward it holds.
+"""
+import torch
+
+
+class _Frame:
+    """Duck-typed `data` of MOTMPNet.forward (models/mpn.py:266 reads .x, .edge_index, .edge_attr only)."""
+    __slots__ = ("x", "edge_index", "edge_attr")
+
+    def __init__(self, x, edge_index, edge_attr):
+        self.x, self.edge_index, self.edge_attr = x, edge_index, edge_attr
+
+
+def _key(data):
+    return (tuple(data.x.shape), tuple(data.edge_index.shape), tuple(data.edge_attr.shape), data.x.device.index)
+
+
+def _check(model, data):
+    if model.training:
+        raise RuntimeError("GraphedForward replays the eval forward: call model.eval() (training steps have GraphedTrainStep)")
+    if not (data.x.is_cuda and data.edge_index.is_cuda and data.edge_attr.is_cuda):
+        raise RuntimeError("gnn_cca_amd.inference runs on MI355X only: move the module and `data` to the GPU (there is no CPU fallback)")
+    model._check_inputs(data.x, data.edge_index, data.edge_attr)   # the reference's dtype contract (RuntimeError)
+
+
+def _clone(data):
+    return _Frame(data.x.detach().clone().contiguous(), data.edge_index.clone().contiguous(), data.edge_attr.detach().clone().contiguous())
+
+
+def _copy_into(static, data):
+    """The frame into the captured buffers (nothing when the caller already works in them)."""
+    if data.x.data_ptr() != static.x.data_ptr():
+        static.x.copy_(data.x, non_blocking=True)
+    if data.edge_index.data_ptr() != static.edge_index.data_ptr():
+        static.edge_index.copy_(data.edge_index, non_blocking=True)
+    if data.edge_attr.data_ptr() != static.edge_attr.data_ptr():
+        static.edge_attr.copy_(data.edge_attr, non_blocking=True)
+
+
+class GraphedBlock:
+    """K forwards captured back to back in ONE HIP graph (GraphedForward.block)."""
+
+    def __init__(self, graph, inputs, outputs, stamp, workspace):
+        self._graph, self.inputs, self.outputs, self._stamp, self._workspace = graph, inputs, outputs, stamp, workspace
+
+    def __len__(self):
+        return len(self.inputs)
+
+    def replay(self, frames=None):
+        """Run the K forwards (one graph launch on the current stream).  `frames`: K new frames to copy into the static inputs
+        first (same shapes as at capture; omit when the producer wrote them there).  Returns the K output dicts -- static tensors,
+        valid until the next replay."""
+        if frames is not None:
+            if len(frames) != len(self.inputs):
+                raise ValueError(f"this block holds {len(self.inputs)} frames, got {len(frames)}")
+            for s, f in zip(self.inputs, frames):
+                if _key(f) != _key(s):
+                    raise ValueError("frame shapes differ from the captured block's")
+                _copy_into(s, f)
+        self._graph.replay()
+        return self.outputs
+
+
+class Pending:
+    """A forward in flight on one of GraphedForward's streams."""
+
+    def __init__(self, outputs, event):
+        self._outputs, self._event = outputs, event
+
+    def result(self):
+        """The outputs, ordered after that forward on the CURRENT stream (no host synchronisation)."""
+        torch.cuda.current_stream().wait_event(self._event)
+        return self._outputs
+
+
+class GraphedForward:
+    def __init__(self, model, warmup=2, max_graphs=64, streams=1):
+        self.model = model
+        self.warmup, self.max_graphs = int(warmup), int(max_graphs)
+        self._seen = {}      # shape key -> eager calls so far
+        self._static = {}    # shape key -> static frame handed out by static_inputs() before the capture
+        self._graphs = {}    # (shape key, slot) -> (graph, static frame, outputs, stamp, workspace kept alive)
+        self._blocks = {}    # tuple of shape keys -> GraphedBlock
+        # the sequential forms (gf(data), gf.block(...)) capture on ONE private stream, i.e. on one grow-only workspace of the module:
+        # their replays are meant for one stream at a time (use submit() for forwards in flight together)
+        self._cap_stream = None
+        self._streams = [torch.cuda.Stream() for _ in range(int(streams))] if int(streams) > 1 else []
+        self._next_slot = 0
+
+    # -- what a captured graph depends on besides the input shapes: the packed weight blob's address and the module's options ------
+    def _stamp(self, device):
+        m = self.model
+        blob = m._packed_weights(device)   # repacks (eagerly, on the current stream, into the same buffer) if the parameters changed
+        return (blob.data_ptr(), m._options(), int(m.num_enc_steps), int(m.num_class_steps))
+
+    def _drop_stale(self, stamp):
+        stale = [k for k, v in self._graphs.items() if v[3] != stamp]
+        for k in stale:
+            del self._graphs[k]
+        for k in [k for k, b in self._blocks.items() if b._stamp != stamp]:
+            del self._blocks[k]
+
+    def _capture(self, frames, stream=None):
+        """Capture model(frame) for every frame of the list, back to back, on `stream` (default: this object's capture stream).
+        Returns (graph, outputs, the module workspace the graph addresses -- the caller keeps it alive with the graph)."""
+        m = self.model
+        if stream is None:
+            if self._cap_stream is None:
+                self._cap_stream = torch.cuda.Stream()
+            stream = self._cap_stream
+        with torch.no_grad():
+            stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(stream):      # the stream's workspace reaches its final size before the capture begins
+                big = max(frames, key=lambda f: (f.edge_index.shape[1], f.x.shape[0]))
+                m(big)
+                for f in frames:
+                    if f is not big and _key(f) != _key(big):
+                        m(f)
+            torch.cuda.current_stream().wait_stream(stream)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=stream):
+                outs = [m(f) for f in frames]
+            ws = m._hot.workspace
+        return graph, outs, ws
+
+    # -- one frame per call ------------------------------------------------------------------------------------------------------------
+    def static_inputs(self, data):
+        """The static input buffers of this frame shape (allocated on first use): write the next frame INTO them and pass the returned
+        object to `gf(...)` to replay without copies."""
+        _check(self.model, data)
+        key = (_key(data), 0)
+        entry = self._graphs.get(key)
+        if entry is not None:
+            return entry[1]
+        pre = self._static.get(key)
+        if pre is None:
+            pre = self._static[key] = _clone(data)
+        return pre
+
+    def __call__(self, data):
+        _check(self.model, data)
+        dev = data.x.device
+        stamp = self._stamp(dev)
+        key = (_key(data), 0)
+        entry = self._graphs.get(key)
+        if entry is not None and entry[3] == stamp:
+            graph, static, outs = entry[:3]
+            _copy_into(static, data)
+            graph.replay()
+            return outs
+        if data.x.shape[0] == 0 or data.edge_index.shape[1] == 0:
+            with torch.no_grad():
+                return self.model(data)     # nothing to launch: the eager call returns empty logits
+        self._drop_stale(stamp)
+        n = self._seen.get(key, 0)
+        if n < self.warmup or len(self._graphs) >= self.max_graphs:
+            self._seen[key] = n + 1
+            with torch.no_grad():
+                return self.model(data)
+        static = self._static.pop(key, None) or _clone(data)
+        _copy_into(static, data)
+        graph, outs, ws = self._capture([static])
+        graph.replay()   # capture records, it does not execute: this replay is this call's forward
+        self._graphs[key] = (graph, static, outs[0], stamp, ws)
+        return outs[0]
+
+    # -- K frames per graph launch -----------------------------------------------------------------------------------------------------
+    def block(self, frames, adopt_inputs=False):
+        """Capture (once per sequence of shapes) the forwards of `frames`, in order, in one HIP graph.  `adopt_inputs=True`: the
+        given tensors ARE the static buffers (they stay resident in HBM and the producer overwrites them in place); otherwise
+        they are cloned.  The same object may appear several times (one forward per appearance, each with its own outputs)."""
+        frames = list(frames)
+        if not frames:
+            raise ValueError("empty block")
+        for f in frames:
+            _check(self.model, f)
+            if f.x.shape[0] == 0 or f.edge_index.shape[1] == 0:
+                raise ValueError("a block cannot hold empty frames")
+        dev = frames[0].x.device
+        stamp = self._stamp(dev)
+        self._drop_stale(stamp)
+        key = (tuple(_key(f) for f in frames), tuple(f.x.data_ptr() for f in frames) if adopt_inputs else None)
+        blk = self._blocks.get(key)
+        if blk is None:
+            clones = {}
+            inputs = []
+            for f in frames:
+                if adopt_inputs:
+                    inputs.append(_Frame(f.x, f.edge_index, f.edge_attr))
+                else:
+                    if id(f) not in clones:
+                        clones[id(f)] = _clone(f)
+                    inputs.append(clones[id(f)])
+            graph, outs, ws = self._capture(inputs)
+            blk = self._blocks[key] = GraphedBlock(graph, inputs, outs, stamp, ws)
+        return blk
+
+    # -- S forwards in flight ------------------------------------------------------------------------------------------------------------
+    def submit(self, data):
+        """Enqueue this frame's forward on the next of the S streams (round robin) and return at once.  Each stream has its own
+        graph, static inputs and workspace per frame shape; the copy into the static inputs and the replay are ordered after the
+        work already on the CURRENT stream (the producer of `data`)."""
+        if not self._streams:
+            raise RuntimeError("GraphedForward(model, streams=S) with S > 1 is needed for submit()")
+        _check(self.model, data)
+        dev = data.x.device
+        stamp = self._stamp(dev)
+        slot = self._next_slot
+        self._next_slot = (slot + 1) % len(self._streams)
+        st = self._streams[slot]
+        key = (_key(data), 1 + slot)
+        entry = self._graphs.get(key)
+        if entry is None or entry[3] != stamp:
+            self._drop_stale(stamp)
+            static = _clone(data)
+            graph, outs, ws = self._capture([static], stream=st)
+            entry = self._graphs[key] = (graph, static, outs[0], stamp, ws)
+        graph, static, outs = entry[:3]
+        st.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(st):
+            _copy_into(static, data)
+            graph.replay()
+            ev = torch.cuda.Event()
+            ev.record(st)
+        return Pending(outs, ev)

@@ -828,6 +828,35 @@ def test_non_finite_inputs_stay_inside_their_graph():
     # (graph 1 itself: unspecified -- the kernels' fmaxf / integer-max ReLUs swallow some NaNs that torch would propagate)
 
 
+@pytest.mark.parametrize("n,g", [(100, 7), (450, 2)])
+def test_non_finite_node_zero_stays_inside_graph_zero_on_the_buffer_addressed_kernel(n, g):
+    """The same property on mpn_step_pipe_kernel (batches beyond 512 nodes; 2 x 450 nodes: its LDS gather-table variant), with the
+    poison in NODE 0 of graph 0.  A lane beyond its segment reads target id 0 from its out-of-range index load; if it then gathered
+    node 0's projection row, an Inf there would reach -- through the additive -3e38 tail mask of the split-bf16 message (inf - inf) --
+    the sums of every node with a partial chunk, in every graph.  Degrees 99 / 449 leave a partial chunk in every segment."""
+    params, arch, sd = _default_model(1.0 / (n - 1))
+    rng = np.random.default_rng(23)
+    x = rng.standard_normal((g * n, 2048)).astype(np.float32)
+    x /= np.linalg.norm(x, axis=0, keepdims=True)
+    ei = np.concatenate([_dense_graph(n, k * n) for k in range(g)], axis=1)
+    ea = rng.random((ei.shape[1], 4)).astype(np.float32)
+    m = build(params, arch, sd)
+    e_per = n * (n - 1)
+
+    def run(xx):
+        with torch.no_grad():
+            return [t.clone() for t in m(Data(torch.from_numpy(xx).cuda(), torch.from_numpy(ei).cuda(), torch.from_numpy(ea).cuda()))["classified_edges"]]
+
+    clean = run(x)
+    bad = x.copy()
+    bad[0, 3] = np.inf                   # graph 0, node 0
+    bad[0, 40] = np.nan
+    dirty = run(bad)
+    for c, d in zip(clean, dirty):
+        assert torch.isfinite(c).all()
+        assert torch.equal(c[e_per:], d[e_per:])          # graphs 1 ... g-1: bit for bit what they are next to a clean neighbour
+
+
 @pytest.mark.parametrize("kind", ["ragged", "ragged_unsorted", "regular", "empty_tail"])
 def test_ragged_batches_whose_edge_count_is_a_multiple_of_the_node_count(kind):
     """Batches beyond 1024 nodes (gather table in HBM, buffer-addressed step kernel) with E = 20 N but out-degrees 10 and 30 (and a

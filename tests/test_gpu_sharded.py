@@ -160,3 +160,29 @@ def test_unsplit_encoder_option_makes_shards_bitwise_equal_to_the_union():
             part = model(share)["classified_edges"]
         for a, b in zip(part, full):
             assert torch.equal(a, b[lo * e_per:hi * e_per]), (world, rank, float((a - b[lo * e_per:hi * e_per]).abs().max()))
+
+
+def test_unsplit_option_with_long_segments_shard_of_two_dense2048_equals_union_of_eight():
+    """waves-per-node is a function of the batch's node count for graphs whose nodes average >= 32 chunks
+    (degree ~2000+) -- a shard of 2 x dense2048 (N = 4096) would run four waves per node, the union of 8 (N = 16 384) one, and the
+    cross-wave combine sums in another order.  With GNNCCA_OPT_ENC_UNSPLIT the forward pins one wave per node from 4096 nodes on, so
+    the documented guarantee (batch-independent logits for batches of >= 4096 nodes) holds for long segments too: bitwise."""
+    import bench
+    n, g_all = 2048, 8
+    model = bench.build_model(bench.graph_net_params(), n).cuda()
+    model.encoder_unsplit = True
+    dev = torch.device("cuda", 0)
+    union = bench.make_data(n, g_all, 11, dev)
+    e_per = n * (n - 1)
+    with torch.no_grad():
+        full = [t.clone() for t in model(union)["classified_edges"]]
+        assert all(torch.isfinite(t).all() for t in full)
+        for lo, hi in ((0, 2), (4, 6), (5, 8)):
+            share = bench.Data()
+            share.x = union.x[lo * n:hi * n].contiguous()
+            share.edge_index = (union.edge_index[:, lo * e_per:hi * e_per] - lo * n).contiguous()
+            share.edge_attr = union.edge_attr[lo * e_per:hi * e_per].contiguous()
+            part = model(share)["classified_edges"]
+            for a, b in zip(part, full):
+                assert torch.equal(a, b[lo * e_per:hi * e_per]), (lo, hi, float((a - b[lo * e_per:hi * e_per]).abs().max()))
+            del share, part
