@@ -232,8 +232,11 @@ def timed_blocks(run, steps, warmup, dist, device, backend, min_blocks=10, min_t
     torch.cuda.synchronize() on both sides and its time is the MAX over ranks (of the larger of host wall clock and the
     HIP-event span on the launch stream).  Returns the sorted block times; the caller reports the median.  The block
     count is the same on every rank because every block time is all-reduced."""
-    for _ in range(warmup):
-        run()
+    if run is None:
+        run_block()                   # a block form warms up with one whole (untimed) block
+    else:
+        for _ in range(warmup):
+            run()
     blocks, out = [], None
     while len(blocks) < min_blocks or (sum(blocks) < min_total_s and len(blocks) < max_blocks):
         torch.cuda.synchronize()
@@ -472,7 +475,7 @@ def main():
                 try:
                     blk = gf.block([data] * args.steps, adopt_inputs=True)
                     blk.replay()
-                    forms["graph_block"] = (None, lambda: blk.replay()[-1])
+                    forms["graph_block"] = (None, lambda: blk.replay()[-1])   # (the block stays cached in gf)
                 except Exception as exc:  # noqa: BLE001
                     print(f"[bench] HIP graph capture of a {args.steps}-step block failed ({type(exc).__name__}: {exc})", file=sys.stderr)
                     torch.cuda.synchronize()
@@ -495,26 +498,24 @@ def main():
         mode_used = api[best] + (" (auto: fastest of " + ", ".join(sorted(by_mode)) + ")" if args.mode == "auto" else "")
         run = forms[best][0] or eager_run
         t = blocks[len(blocks) // 2]      # median block of K steps (max over ranks inside every block)
-        # S forwards in flight (GraphedForward(streams=S).submit; frames copied into each stream's static inputs): whole-job
-        # throughput of independent frames, reported beside `value`, never as `value`
+        # S forwards in flight: the K forwards of a block dealt onto S PARALLEL branches of one HIP graph (GraphedForward.block(...,
+        # chains=S): each branch on its own workspace, every forward complete with its own outputs) -- whole-job throughput of
+        # independent frames, reported beside `value`, never as `value`
         pipelined = None
-        if world == 1 and args.streams > 1 and args.mode == "auto" and "graph" in forms:
+        if world == 1 and args.streams > 1 and args.mode == "auto" and "graph_block" in forms:
             try:
-                gfs = GraphedForward(model, streams=args.streams)
-                frames_s = [make_data(args.nodes, args.graphs, 100 + i, device) for i in range(args.streams)]
-
-                def run_streams():
-                    pend = [gfs.submit(f) for f in frames_s]
-                    return [p.result() for p in pend][-1]
-                k_s = max(1, args.steps // args.streams)
-                blocks_s, _ = timed_blocks(run_streams, k_s, max(1, args.warmup // args.streams), None, device, args.backend,
-                                           min_blocks=args.min_blocks)
+                blk_s = gf.block([data] * args.steps, adopt_inputs=True, chains=args.streams)
+                blk_s.replay()
+                blocks_s, out_s = timed_blocks(None, args.steps, args.warmup, None, device, args.backend, min_blocks=args.min_blocks,
+                                               run_block=lambda: blk_s.replay())
                 t_s = blocks_s[len(blocks_s) // 2]
-                pipelined = {"api": f"gnn_cca_amd.inference.GraphedForward(streams={args.streams}).submit", "streams": args.streams,
-                             "ms_per_forward": t_s / (k_s * args.streams) * 1e3, "value": E * k_s * args.streams / t_s, "unit": "edges/s",
-                             "note": "independent frames, each copied into its stream's static inputs and replayed from that stream's HIP "
-                                     "graph on its own workspace; every forward complete; not `value`"}
-                del gfs, frames_s
+                same = all(torch.equal(a_, b_) for o in out_s for a_, b_ in zip(o["classified_edges"], out["classified_edges"]))
+                pipelined = {"api": f"gnn_cca_amd.inference.GraphedForward.block(frames, chains={args.streams})", "chains": args.streams,
+                             "ms_per_forward": t_s / args.steps * 1e3, "value": E * args.steps / t_s, "unit": "edges/s",
+                             "bitwise_equal_to_value_mode": bool(same),
+                             "note": f"the {args.steps} forwards of a block on {args.streams} parallel branches of one HIP graph (independent "
+                                     "frames in flight, one workspace per branch); every forward complete; not `value`"}
+                del blk_s, out_s
             except Exception as exc:  # noqa: BLE001
                 pipelined = {"error": f"{type(exc).__name__}: {exc}"}
                 torch.cuda.synchronize()

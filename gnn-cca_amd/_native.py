@@ -54,6 +54,7 @@ class Dropout(C.Structure):
 OPT_EDGE_STATE_BF16 = 1
 OPT_ENC_SPLIT3 = 2
 OPT_ENC_UNSPLIT = 4
+OPT_NO_COLUMN_RANGES = 8
 BWD_GRADS_ZEROED = 1
 
 
@@ -121,6 +122,7 @@ _SIGNATURES = {
                                         C.c_int64, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_void_p),
                                         C.POINTER(Dropout), C.c_void_p]),
     "gnncca_read_graph_flags": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.c_void_p]),
+    "gnncca_read_graph_flags2": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.c_void_p]),
 }
 
 _lib = None

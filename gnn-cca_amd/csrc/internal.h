@@ -122,7 +122,7 @@ int mlp_param_count(const gnncca_mlp& m);
 
 // Workspace carve-up (byte offsets, all multiples of 256).
 struct Workspace {
-    size_t flags, blockflags, seg_ptr, col32, perm, cursor, h0, act, partial, pd[2], psq[2], e, e0, total;
+    size_t flags, blockflags, seg_ptr, col32, perm, cursor, h0, act, partial, pd[2], psq[2], e, e0, rng, total;
     int ksplit;        // split-K factor of the first encoder GEMM
     int64_t e_stride;  // floats between two feature planes of the edge state
     int ell_S;         // padded edge-state layout: slots per node (multiple of 32), 0 = compact CSR order only

@@ -55,6 +55,14 @@ int gnncca_read_graph_flags(const void* workspace, uint32_t* flags_out, gnncca_s
     return GNNCCA_OK;
 }
 
+int gnncca_read_graph_flags2(const void* workspace, uint32_t flags_out[2], gnncca_stream_t stream) {
+    if (!workspace || !flags_out) return GNNCCA_ERR_INVALID_ARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    HIP_TRY(hipMemcpyAsync(flags_out, workspace, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return GNNCCA_OK;
+}
+
 }  // extern "C"
 
 static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const float* x, const int64_t* edge_index,
@@ -419,7 +427,7 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
     sp.off_wnebf = hdr.wne_bf16;
     static const bool step_r2 = diag_env("GNNCCA_STEP_R2") != nullptr;   // diagnostics: A/B against round 2's step kernel
     // which arithmetic the node message uses (StepParams::msg_f32): the traced (general) and the fast kernels follow ONE rule
-    sp.msg_f32 = (N <= 512 || step_r2 || !step_pipe_fits(N, E, ws.e_stride)) ? 1 : 0;
+    sp.msg_f32 = (N <= 512 || step_r2 || !step_pipe_fits(N, E, ws.e_stride, ws.total)) ? 1 : 0;
     sp.cls_hidden = hdr.cls_hidden;
     sp.N = N;
     sp.E = E;
@@ -447,6 +455,13 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
         sp.wps = wps;
     }
     sp.hin = hin;
+    // column ranges instead of the col32 stream on steps 2 ... L of the specialised kernels (StepParams::rng)
+    static const bool step_norange = diag_env("GNNCCA_STEP_NORANGE") != nullptr;   // diagnostics: A/B against streaming col32 on every step
+    static const int range_max_e = diag_env_int("GNNCCA_RANGE_MAX_E", 0x7FFFFFFF, 0, 0x7FFFFFFF);   // diagnostics: edge count up to which the buffer-addressed kernel uses them
+    sp.rng = (L >= 2 && !step_norange && !(options & GNNCCA_OPT_NO_COLUMN_RANGES) && (sp.msg_f32 || E <= range_max_e)) ? reinterpret_cast<int*>(base + ws.rng) : nullptr;
+    sp.ws_base = base;
+    sp.ws_bytes = ws.total;
+    sp.so_e = (unsigned)ws.e, sp.so_col = (unsigned)ws.col32, sp.so_perm = (unsigned)ws.perm;
     // the P_dst gather table staged whole in LDS: graphs of 801 ... 1024 nodes only.  (Rounds 1-2 staged it for every N <= 1024; measured with
     // a block of 200 forwards in one HIP graph, gathers straight from L2 are ahead below that: dense32 / 64 / 128 / 256 / 384 / 512 / 768
     // -1.5 / -2 / -1.5 / -1.5 / -4 / -2.7 / -1.3 % per forward, dense1024 (L = 8) +1 %; profiles/r03_logs/r3_pdlds2.log, r3_pdlds3.log)
@@ -486,6 +501,7 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
         sp.cls_layers = step >= first_cls ? hdr.cls_layers : 0;
         sp.logits = step >= first_cls ? logits_out + (size_t)(out_idx++) * E : nullptr;
         sp.pd_in = pd[(step - 1) & 1];
+        sp.so_pd = (unsigned)ws.pd[(step - 1) & 1];
         sp.psq_in = psq[(step - 1) & 1];
         sp.pd_out = step < L ? pd[step & 1] : nullptr;
         sp.psq_out = step < L ? psq[step & 1] : nullptr;

@@ -200,7 +200,7 @@ __device__ void plan_finish(const long long* __restrict__ ei, int E, int N, int*
     }
     fl = smem[0];
     __syncthreads();
-    if (tid == 0) flags[0] = fl;
+    if (tid == 0) flags[0] = fl, flags[1] = 0u;   // flags[1]: raised by step 1 when a node's columns are not <= 2 contiguous ranges
     if ((fl & GNNCCA_GRAPH_UNSORTED) && !(fl & GNNCCA_GRAPH_BAD_INDEX)) {
         int* si = reinterpret_cast<int*>(smem);
         plan_sort_fallback(ei, E, N, seg_ptr, col32, perm, cursor, si, si + 256, si + 512);

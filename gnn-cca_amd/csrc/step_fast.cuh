@@ -17,17 +17,19 @@ __device__ __forceinline__ float relu_bits(float x) { return __int_as_float(max(
 #ifdef GNNCCA_FAST_WAVES   // diagnostic builds: force the register budget of N waves per SIMD
 #define GNNCCA_FAST_ATTR __attribute__((amdgpu_waves_per_eu(GNNCCA_FAST_WAVES, GNNCCA_FAST_WAVES)))
 #else
-#define GNNCCA_FAST_ATTR
+#define GNNCCA_FAST_ATTR __attribute__((amdgpu_waves_per_eu(MSG ? 4 : 1)))   // the message variants must fit four waves per SIMD (128 VGPRs); the others stream: keep them light
 #endif
 template <bool FIRST, bool CLS, bool MSG, bool PD_LDS, bool EBF16, int NT>
 __global__ __launch_bounds__(256) GNNCCA_FAST_ATTR void mpn_step_fast_kernel(const StepParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_proj = smem;                                   // [32][48]   (MSG)
     float* s_part = s_proj + (MSG ? kH * kProjOut : 0);     // [4][32]
-    float* s_pd = s_part + 4 * kH;                          // [N][8]     (PD_LDS)
+    int* s_rng = reinterpret_cast<int*>(s_part + 4 * kH);   // [4][4]     (DERIVE: per-wave column-range findings)
+    float* s_pd = s_part + 4 * kH + 16;                     // [N][8]     (PD_LDS)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const float* __restrict__ blob = p.blob;
+    constexpr bool DERIVE = FIRST && MSG;      // step 1 of a forward with more steps to come: derive the column ranges (StepParams::rng)
     // Per-step scalars (152 floats) are read through the CONSTANT address space: wave-uniform addresses there
     // become s_load into SGPRs, which the VALU takes as operands directly -- no LDS, no VGPR copies.
     typedef const float __attribute__((address_space(4))) cfloat;
@@ -36,6 +38,7 @@ __global__ __launch_bounds__(256) GNNCCA_FAST_ATTR void mpn_step_fast_kernel(con
     GNNCCA_STAMP(p.stamp_slot, 0);
     // ---- prologue: every independent load is issued before the first wait ----------------------------------
     const unsigned gflags = p.flags[0];
+    const unsigned rbad = p.flags[1];
     const int wps = p.wps;
     const int node = blockIdx.x * (4 / wps) + wave / wps;
     const int sub = wave % wps;
@@ -43,6 +46,15 @@ __global__ __launch_bounds__(256) GNNCCA_FAST_ATTR void mpn_step_fast_kernel(con
     const int nclamp = active ? node : 0;
     int seg_s = p.seg_ptr[nclamp];
     int seg_t = p.seg_ptr[nclamp + 1];
+    // steps 2 ... L: the node's column ranges as step 1 left them (StepParams::rng; wave-uniform: four SGPRs)
+    const bool use_range = !FIRST && p.rng != nullptr && rbad == 0u;
+    int rs1 = 0, rl1 = 0, rd2 = 0;
+    if (!FIRST && p.rng != nullptr) {
+        typedef int i32x4 __attribute__((ext_vector_type(4)));
+        const i32x4 r = reinterpret_cast<const i32x4*>(p.rng)[nclamp];
+        rs1 = r[0], rl1 = r[1], rd2 = r[2];
+    }
+    const int nmax = p.N - 1;
     const int half = lane >> 5, ch = lane & 31;
     const float* __restrict__ psq = p.psq_in + (size_t)nclamp * kPsQStride;
     float psrc[kEF];
@@ -100,12 +112,36 @@ __global__ __launch_bounds__(256) GNNCCA_FAST_ATTR void mpn_step_fast_kernel(con
         float raw[kEF];
         float pd[kEF];
         int ko, j;
+        int jp;   // DERIVE: the target id of the previous edge of the sorted order
     };
     // phase A: everything addressed by the edge slot itself (target id, permutation, edge state)
     auto load_index = [&](int base, Chunk& c) {
         const int kk = max(min(base + lane, last), 0);   // (an empty segment: slot 0, never used)
         c.ko = unsorted ? p.perm[kk] : kk;
-        c.j = p.col32[kk];
+        if (use_range) {   // kernel-uniform: the node's columns are <= 2 contiguous runs -- the id is computed, no load, no round trip
+            const int q = kk - seg_s;
+            c.j = max(min(q + (q < rl1 ? rs1 : rd2), nmax), 0);   // (clamped: lanes of an empty segment gather a real row, never used)
+        } else {
+            c.j = p.col32[kk];
+            if (DERIVE) c.jp = p.col32[max(kk - 1, 0)];   // same lines: an L1 hit
+        }
+    };
+    // Step 1 derives each node's column ranges from the target ids it has loaded anyway: a break is an edge whose target is not its
+    // predecessor's + 1.  Wave-uniform bookkeeping on the scalar unit.
+    int d_nb = 0, d_first = 0x7FFFFFFF, d_start2 = 0, d_start1 = 0;
+    auto derive = [&](int base, const Chunk& c) {
+        const int k = base + lane;
+        const bool brk = k < seg_t && k > seg_s && c.j != c.jp + 1;
+        const unsigned long long m = __ballot(brk);
+        if (m != 0ull) {
+            if (d_nb == 0) {   // chunks of a wave come in ascending order: the first break seen is the wave's first
+                const int l = __ffsll((long long)m) - 1;
+                d_first = base + l - seg_s;
+                d_start2 = __builtin_amdgcn_readlane(c.j, l);
+            }
+            d_nb += __popcll(m);
+        }
+        if (base == seg_s) d_start1 = __builtin_amdgcn_readfirstlane(c.j);
     };
     auto load_state = [&](int base, Chunk& c) {
         const int kk = max(min(base + lane, last), 0);
@@ -291,6 +327,10 @@ __global__ __launch_bounds__(256) GNNCCA_FAST_ATTR void mpn_step_fast_kernel(con
     auto round_body = [&](int rb, Chunk& a, Chunk& b) {
         load_target(a);
         load_target(b);
+        if (DERIVE && p.rng != nullptr) {
+            derive(rb, a);
+            if (rb + stride < seg_t) derive(rb + stride, b);
+        }
         GNNCCA_STAMP(p.stamp_slot, 3);
         compute_chunk(rb, a);
         if (rb + stride < seg_t) compute_chunk(rb + stride, b);
@@ -334,11 +374,24 @@ __global__ __launch_bounds__(256) GNNCCA_FAST_ATTR void mpn_step_fast_kernel(con
         v += __shfl_xor(v, 32);
         if (wps > 1) {
             if (lane < kH) s_part[wave * kH + lane] = v;
+            if (DERIVE && lane == 0) s_rng[wave * 4] = d_nb, s_rng[wave * 4 + 1] = d_first, s_rng[wave * 4 + 2] = d_start2;
             __syncthreads();
             if (sub == 0) {
                 v = s_part[wave * kH + ch];
                 for (int u = 1; u < wps; ++u) v += s_part[(wave + u) * kH + ch];
+                if (DERIVE)
+                    for (int u = 1; u < wps; ++u) {
+                        d_nb += s_rng[(wave + u) * 4];
+                        const int f_u = s_rng[(wave + u) * 4 + 1];
+                        if (f_u < d_first) d_first = f_u, d_start2 = s_rng[(wave + u) * 4 + 2];
+                    }
             }
+        }
+        if (DERIVE && p.rng != nullptr && active && sub == 0 && lane == 0) {   // (start1, len1, start2 - len1, breaks) of this node
+            typedef int i32x4 __attribute__((ext_vector_type(4)));
+            const int len1 = d_nb ? d_first : seg_t - seg_s;
+            reinterpret_cast<i32x4*>(p.rng)[node] = i32x4{d_start1, len1, d_start2 - len1, d_nb};
+            if (d_nb > 1) atomicOr(p.flags + 1, 1u);   // not two runs: every later step of this forward streams col32
         }
         GNNCCA_STAMP(p.stamp_slot, 6);
         if (active && sub == 0) {
@@ -365,7 +418,7 @@ template <bool FIRST, bool CLS, bool MSG, bool PDL, bool EB, int NT>
 static hipError_t launch_fast_t(const StepParams& sp, hipStream_t st) {
     const int npg = 4 / sp.wps;
     const unsigned blocks = (unsigned)((sp.N + npg - 1) / npg);
-    const size_t lds = ((MSG ? (size_t)kH * kProjOut : 0) + 4 * kH + (PDL ? (size_t)sp.N * kPdStride : 0)) * sizeof(float);
+    const size_t lds = ((MSG ? (size_t)kH * kProjOut : 0) + 4 * kH + 16 + (PDL ? (size_t)sp.N * kPdStride : 0)) * sizeof(float);
     GNNCCA_LAUNCH((mpn_step_fast_kernel<FIRST, CLS, MSG, PDL, EB, NT>), dim3(blocks), dim3(256), lds, st, sp);
     return hipGetLastError();
 }
@@ -380,6 +433,7 @@ static hipError_t launch_fast(const StepParams& sp, hipStream_t st) {
     return sp.e_bf16 ? launch_fast_t<FIRST, CLS, MSG, PDL, true, 0>(sp, st) : launch_fast_t<FIRST, CLS, MSG, PDL, false, 0>(sp, st);
 }
 
+#ifndef GNNCCA_KERNELS_ONLY   // (tools: compile-only probes of single instantiations skip the dispatch tables)
 static hipError_t launch_fast_dispatch(const StepParams& sp, bool msg, hipStream_t st) {
     const int key = (sp.first ? 8 : 0) | (sp.cls_layers ? 4 : 0) | (msg ? 2 : 0) | (sp.pd_lds ? 1 : 0);
     switch (key) {
@@ -405,6 +459,7 @@ static hipError_t launch_fast_dispatch(const StepParams& sp, bool msg, hipStream
     }
     return hipErrorInvalidValue;
 }
+#endif
 
 
 }  // namespace gnncca

@@ -23,7 +23,7 @@ struct StepParams {
     const int* seg_ptr;
     const int* col32;
     const int* perm;
-    const unsigned* flags;
+    unsigned* flags;         // [0] graph flags (plan), [1] column-range verdict (step 1)
     const float* edge_attr;
     float* e;
     float* e0;
@@ -54,6 +54,18 @@ struct StepParams {
                              // <= 512 nodes, where a launch is a chain of dependent latencies and the split-bf16 form's operand
                              // construction costs more than its matrix-pipe overlap returns (1 x dense256: 4.6 vs 4.8 us per step);
                              // 0: split-bf16 (msg_bf16.cuh).  One rule for the traced and the fast kernels: same bits either way
+    // Column ranges (round 4).  Every graph the reference builds (inference.py:209-216: per camera, cartesian_prod of its detections with
+    // every detection of the other cameras, targets ascending) and every dense graph gives a source node at most TWO contiguous runs of
+    // target ids.  Step 1 of the specialised kernels reads the target ids anyway and derives, per node, (start1, len1, start2 - len1,
+    // number of breaks) into `rng`; a node with more than one break raises flags[1].  Steps 2 ... L then COMPUTE the target id of
+    // position q of a segment -- q + (q < len1 ? start1 : start2 - len1) -- instead of streaming col32 (4 of 56 B per edge) and, more
+    // to the point, request the P_dst gather together with the edge state instead of one dependent round trip later.  flags[1] != 0
+    // (graphs with arbitrary columns): every step streams col32 as before.  nullptr: off (L < 2, diagnostics).
+    int* rng;
+    // mpn_step_pipe_kernel addresses the workspace through ONE buffer descriptor: its base, size and the byte offsets of the regions
+    const void* ws_base;
+    unsigned long long ws_bytes;
+    unsigned so_e, so_col, so_perm, so_pd;
     int diag;                // GNNCCA_DIAG experiments (0 in production): bit 0 = timing-only run of mpn_step_pipe_kernel with
                              // zero-record stream descriptors (no HBM traffic: what the arithmetic alone costs)
 };

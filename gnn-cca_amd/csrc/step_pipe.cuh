@@ -33,30 +33,39 @@ __device__ __forceinline__ float buf_load_f32(rsrc_t r, unsigned voff, unsigned 
 }
 
 // host-side eligibility: every buffer this kernel addresses with 32-bit offsets stays below 2^31 bytes
-static inline bool step_pipe_fits(long long N, long long E, long long e_stride) {
+static inline bool step_pipe_fits(long long N, long long E, long long e_stride, unsigned long long ws_bytes) {
     const long long lim = 1ll << 31;
-    return 6 * e_stride * 4 <= lim && E * 16 <= lim && N * 32 <= lim;
+    // (the whole workspace is addressed through one descriptor: it must end below the out-of-range offset 2^31 of a dead lane, and
+    // below 2^31 - 4 so that "the slot before slot 0" of DERIVE's predecessor load is out of range too)
+    return 6 * e_stride * 4 <= lim && E * 16 <= lim && N * 32 <= lim && ws_bytes <= (unsigned long long)lim - 4096;
 }
 
 #define GNNCCA_SB() __builtin_amdgcn_sched_barrier(0)
 
-template <bool FIRST, bool CLS, bool MSG, bool PD_LDS, bool EBF16, int NT>
+// RNG: the column-range code is compiled in (StepParams::rng) -- step 1 derives the ranges, later steps compute target ids from them.  A
+// template parameter and not only a run-time switch because this kernel's scalar register file is full: the few SGPRs the ranges need
+// turn into v_readlane / v_writelane spill traffic on the VALU, which is what the issue-bound big batches are short of; the host
+// instantiates RNG for the latency-bound regime only (mpn_forward.hip).
+template <bool FIRST, bool CLS, bool MSG, bool PD_LDS, bool EBF16, int NT, bool RNG = false>
 __global__ __launch_bounds__(256) GNNCCA_FAST_ATTR void mpn_step_pipe_kernel(const StepParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_proj = smem;                                   // [32][48]   (MSG)
     float* s_part = s_proj + (MSG ? kH * kProjOut : 0);     // [4][32]
-    float* s_pd = s_part + 4 * kH;                          // [N][8]     (PD_LDS)
+    int* s_rng = reinterpret_cast<int*>(s_part + 4 * kH);   // [4][4]     (DERIVE: per-wave column-range findings)
+    float* s_pd = s_part + 4 * kH + 16;                     // [N + 1][8] (PD_LDS)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const float* __restrict__ blob = p.blob;
     typedef const float __attribute__((address_space(4))) cfloat;
     cfloat* cw = (cfloat*)(unsigned long long)(blob + p.off_fast);
+    constexpr bool DERIVE = FIRST && MSG && RNG;   // step 1 of a forward with more steps to come: derive the column ranges (StepParams::rng)
     constexpr int AUX_ST = NT >= 1 ? 2 : 0;    // nt: streams written / read once (see mpn_step_fast_kernel on the policy)
     constexpr int AUX_LD = NT >= 2 ? 2 : 0;
 
     GNNCCA_STAMP(p.stamp_slot, 0);
     // ---- prologue: every independent load is issued before the first wait ----------------------------------
     const unsigned gflags = p.flags[0];
+    const unsigned rbad = p.flags[1];
     const int wps = p.wps;
     const int node = blockIdx.x * (4 / wps) + wave / wps;
     const int sub = wave % wps;
@@ -64,6 +73,14 @@ __global__ __launch_bounds__(256) GNNCCA_FAST_ATTR void mpn_step_pipe_kernel(con
     const int nclamp = active ? node : 0;
     int seg_s = p.seg_ptr[nclamp];
     int seg_t = p.seg_ptr[nclamp + 1];
+    // steps 2 ... L: the node's column ranges as step 1 left them (wave-uniform: four SGPRs)
+    const bool use_range = RNG && !FIRST && rbad == 0u;
+    int rbk = 0, rA = 0, rB = 0;
+    if (RNG && !FIRST) {
+        typedef int i32x4 __attribute__((ext_vector_type(4)));
+        const i32x4 r = reinterpret_cast<const i32x4*>(p.rng)[nclamp];
+        rbk = seg_s + r[1], rA = r[0] - seg_s, rB = r[2] - seg_s;
+    }
     const int half = lane >> 5, ch = lane & 31;
     const float* __restrict__ psq = p.psq_in + (size_t)nclamp * kPsQStride;
     float psrc[kEF];
@@ -101,11 +118,15 @@ __global__ __launch_bounds__(256) GNNCCA_FAST_ATTR void mpn_step_pipe_kernel(con
     const int eoff = (p.ell_S > 0 && !(gflags & (GNNCCA_GRAPH_UNSORTED | GNNCCA_GRAPH_IRREGULAR))) ? nclamp * p.ell_S - seg_s : 0;
     const unsigned plane_b = (unsigned)p.e_stride * 4u;                       // bytes between two feature planes
     const unsigned long long live = (p.diag & 1) ? 0ull : 1ull;               // timing-only diagnostic: every stream descriptor empty
-    const rsrc_t r_e = make_rsrc(p.e, live * (EBF16 ? 3 : 6) * plane_b);
-    const rsrc_t r_col = make_rsrc(p.col32, live * (unsigned long long)p.E * 4);
-    const rsrc_t r_perm = make_rsrc(p.perm, unsorted ? (unsigned long long)p.E * 4 : 0ull);   // sorted: every load returns 0, no traffic
+    // ONE descriptor for everything this kernel streams out of the forward's workspace -- edge state, target ids, permutation, P_dst
+    // table -- with the region's byte offset as the scalar offset of each access (round 4; rounds 1-3 kept a descriptor per buffer:
+    // 16 SGPRs where 4 + 3 do, in a kernel whose scalar file is full -- hipcc spills SGPRs into VGPR lanes with v_writelane /
+    // v_readlane, i.e. on the VALU, the unit this kernel is bound by: 23 of the 430 instructions of a steady-state round).  The host
+    // guarantees ws_bytes < 2^31 - 4096 (step_pipe_fits), so the out-of-range offset 2^31 of a dead lane is beyond it for every region.
+    const rsrc_t r_ws = make_rsrc(p.ws_base, live * p.ws_bytes);
+    const unsigned so_e = p.so_e, so_col = p.so_col, so_perm = p.so_perm, so_pd = p.so_pd;
+    const unsigned us_oob = unsorted ? 0u : kOobOffset;                       // sorted rows: the permutation is never fetched (its loads return 0)
     const rsrc_t r_attr = make_rsrc(p.edge_attr, live * (unsigned long long)p.E * 16);
-    const rsrc_t r_pd = make_rsrc(p.pd_in, (unsigned long long)p.N * (kPdStride * 4));
     const rsrc_t r_log = make_rsrc(p.logits, CLS ? live * (unsigned long long)p.E * 4 : 0ull);
 
     f32x16 acc;  // 'sum' / 'mean' only: 'max' takes the general kernel
@@ -143,6 +164,10 @@ __global__ __launch_bounds__(256) GNNCCA_FAST_ATTR void mpn_step_pipe_kernel(con
     auto round_body = [&](int rb, Chunk& a, Chunk& b, int sid, int sland, int sdone) {
         load_target(a);
         load_target(b);
+        if (DERIVE) {
+            derive(rb, a);
+            if (rb + stride < seg_t) derive(rb + stride, b);
+        }
         GNNCCA_STAMP(p.stamp_slot, sid);
 #ifdef GNNCCA_STAMPS   // diagnostic build: when did the round's operands arrive?
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -201,11 +226,24 @@ __global__ __launch_bounds__(256) GNNCCA_FAST_ATTR void mpn_step_pipe_kernel(con
         v += __shfl_xor(v, 32);
         if (wps > 1) {
             if (lane < kH) s_part[wave * kH + lane] = v;
+            if (DERIVE && lane == 0) s_rng[wave * 4] = d_nb, s_rng[wave * 4 + 1] = d_first, s_rng[wave * 4 + 2] = d_start2;
             __syncthreads();
             if (sub == 0) {
                 v = s_part[wave * kH + ch];
                 for (int u = 1; u < wps; ++u) v += s_part[(wave + u) * kH + ch];
+                if (DERIVE)
+                    for (int u = 1; u < wps; ++u) {
+                        d_nb += s_rng[(wave + u) * 4];
+                        const int f_u = s_rng[(wave + u) * 4 + 1];
+                        if (f_u < d_first) d_first = f_u, d_start2 = s_rng[(wave + u) * 4 + 2];
+                    }
             }
+        }
+        if (DERIVE && active && sub == 0 && lane == 0) {   // (start1, len1, start2 - len1, breaks) of this node
+            typedef int i32x4 __attribute__((ext_vector_type(4)));
+            const int len1 = d_nb ? d_first : seg_t - seg_s;
+            reinterpret_cast<i32x4*>(p.rng)[node] = i32x4{d_start1, len1, d_start2 - len1, d_nb};
+            if (d_nb > 1) atomicOr(p.flags + 1, 1u);   // not two runs: every later step of this forward streams col32
         }
         GNNCCA_STAMP(p.stamp_slot, 6);
         if (active && sub == 0 && !(p.diag & 2)) {   // (diag bit 1: timing-only run without the projection epilogue)
@@ -236,12 +274,12 @@ __global__ __launch_bounds__(256) GNNCCA_FAST_ATTR void mpn_step_pipe_kernel(con
     GNNCCA_STAMP(p.stamp_slot, 7);
 }
 
-template <bool FIRST, bool CLS, bool MSG, bool PDL, bool EB, int NT>
+template <bool FIRST, bool CLS, bool MSG, bool PDL, bool EB, int NT, bool RNG = false>
 static hipError_t launch_pipe_t(const StepParams& sp, hipStream_t st) {
     const int npg = 4 / sp.wps;
     const unsigned blocks = (unsigned)((sp.N + npg - 1) / npg);
-    const size_t lds = ((MSG ? (size_t)kH * kProjOut : 0) + 4 * kH + (PDL ? ((size_t)sp.N + 1) * kPdStride : 0)) * sizeof(float);
-    GNNCCA_LAUNCH((mpn_step_pipe_kernel<FIRST, CLS, MSG, PDL, EB, NT>), dim3(blocks), dim3(256), lds, st, sp);
+    const size_t lds = ((MSG ? (size_t)kH * kProjOut : 0) + 4 * kH + 16 + (PDL ? ((size_t)sp.N + 1) * kPdStride : 0)) * sizeof(float);
+    GNNCCA_LAUNCH((mpn_step_pipe_kernel<FIRST, CLS, MSG, PDL, EB, NT, RNG>), dim3(blocks), dim3(256), lds, st, sp);
     return hipGetLastError();
 }
 
@@ -252,9 +290,14 @@ static hipError_t launch_pipe(const StepParams& sp, hipStream_t st) {
         if (nt == 2) return sp.e_bf16 ? launch_pipe_t<FIRST, CLS, MSG, false, true, 2>(sp, st) : launch_pipe_t<FIRST, CLS, MSG, false, false, 2>(sp, st);
         if (nt == 1) return sp.e_bf16 ? launch_pipe_t<FIRST, CLS, MSG, false, true, 1>(sp, st) : launch_pipe_t<FIRST, CLS, MSG, false, false, 1>(sp, st);
     }
+    // the column-range variants (StepParams::rng != nullptr: the host's choice) exist for the default cache policy and where they do
+    // something: step 1 when it derives (FIRST && MSG), every later step
+    if (sp.rng != nullptr && (!FIRST || MSG))
+        return sp.e_bf16 ? launch_pipe_t<FIRST, CLS, MSG, PDL, true, 0, true>(sp, st) : launch_pipe_t<FIRST, CLS, MSG, PDL, false, 0, true>(sp, st);
     return sp.e_bf16 ? launch_pipe_t<FIRST, CLS, MSG, PDL, true, 0>(sp, st) : launch_pipe_t<FIRST, CLS, MSG, PDL, false, 0>(sp, st);
 }
 
+#ifndef GNNCCA_KERNELS_ONLY   // (tools: compile-only probes of single instantiations skip the dispatch tables)
 static hipError_t launch_pipe_dispatch(const StepParams& sp, bool msg, hipStream_t st) {
     const int key = (sp.first ? 8 : 0) | (sp.cls_layers ? 4 : 0) | (msg ? 2 : 0) | (sp.pd_lds ? 1 : 0);
     switch (key) {
@@ -280,5 +323,6 @@ static hipError_t launch_pipe_dispatch(const StepParams& sp, bool msg, hipStream
     }
     return hipErrorInvalidValue;
 }
+#endif
 
 }  // namespace gnncca

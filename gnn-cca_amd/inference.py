@@ -18,7 +18,8 @@ replayed: `GraphedForward` does that, in three forms.
     step) skips the copies: `gf(static)` sees its own tensors and replays at once.
   * `gf.block(frames)`: K frames captured BACK TO BACK in one HIP graph (K whole forwards, every launch of each, each with its own
     outputs) -- the K-deep form: one graph launch per K frames, the launch-bound loop runs without the host in it.
-    `blk.replay()` -> list of K output dicts; `blk.inputs[i]` are the static buffers of frame i.
+    `blk.replay()` -> list of K output dicts; `blk.inputs[i]` are the static buffers of frame i.  `gf.block(frames, chains=S)`
+    deals the K forwards onto S parallel branches of that graph (S frames in flight, one workspace per branch).
   * `streams=S`: S independent forwards in flight, each stream replaying its own graph on its own workspace (the module keeps a
     workspace per stream; the packed weights are shared and read-only).  `gf.submit(data)` returns a `Pending` whose
     `.result()` makes the CURRENT stream wait for that forward only.
@@ -110,6 +111,7 @@ class GraphedForward:
         # the sequential forms (gf(data), gf.block(...)) capture on ONE private stream, i.e. on one grow-only workspace of the module:
         # their replays are meant for one stream at a time (use submit() for forwards in flight together)
         self._cap_stream = None
+        self._chain_streams = []   # extra capture streams of block(..., chains=S): one workspace each
         self._streams = [torch.cuda.Stream() for _ in range(int(streams))] if int(streams) > 1 else []
         self._next_slot = 0
 
@@ -126,28 +128,48 @@ class GraphedForward:
         for k in [k for k, b in self._blocks.items() if b._stamp != stamp]:
             del self._blocks[k]
 
-    def _capture(self, frames, stream=None):
-        """Capture model(frame) for every frame of the list, back to back, on `stream` (default: this object's capture stream).
-        Returns (graph, outputs, the module workspace the graph addresses -- the caller keeps it alive with the graph)."""
+    def _capture(self, frames, stream=None, chains=1):
+        """Capture model(frame) for every frame of the list on `stream` (default: this object's capture stream): back to back, or --
+        `chains` > 1 -- dealt round robin onto that many PARALLEL branches of the graph (fork after the graph's root, join before its
+        end; branch c runs on its own stream at capture time, hence on its own workspace of the module).
+        Returns (graph, outputs, the module workspaces the graph addresses -- the caller keeps them alive with the graph)."""
         m = self.model
         if stream is None:
             if self._cap_stream is None:
                 self._cap_stream = torch.cuda.Stream()
             stream = self._cap_stream
+        chains = max(1, min(int(chains), len(frames)))
+        while len(self._chain_streams) < chains - 1:
+            self._chain_streams.append(torch.cuda.Stream())
+        lanes = [stream] + self._chain_streams[:chains - 1]
         with torch.no_grad():
-            stream.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(stream):      # the stream's workspace reaches its final size before the capture begins
-                big = max(frames, key=lambda f: (f.edge_index.shape[1], f.x.shape[0]))
-                m(big)
-                for f in frames:
-                    if f is not big and _key(f) != _key(big):
-                        m(f)
-            torch.cuda.current_stream().wait_stream(stream)
+            big = max(frames, key=lambda f: (f.edge_index.shape[1], f.x.shape[0]))
+            for st in lanes:                     # every stream's workspace reaches its final size before the capture begins
+                st.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(st):
+                    m(big)
+                    for f in frames:
+                        if f is not big and _key(f) != _key(big):
+                            m(f)
+                torch.cuda.current_stream().wait_stream(st)
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
+            outs, ws = [None] * len(frames), []
             with torch.cuda.graph(graph, stream=stream):
-                outs = [m(f) for f in frames]
-            ws = m._hot.workspace
+                if chains > 1:
+                    fork = torch.cuda.Event()
+                    fork.record(stream)
+                    for st in lanes[1:]:
+                        st.wait_event(fork)
+                for c, st in enumerate(lanes):
+                    with torch.cuda.stream(st):
+                        for i in range(c, len(frames), chains):
+                            outs[i] = m(frames[i])
+                        ws.append(m._hot.workspace)
+                for st in lanes[1:]:
+                    join = torch.cuda.Event()
+                    join.record(st)
+                    stream.wait_event(join)
         return graph, outs, ws
 
     # -- one frame per call ------------------------------------------------------------------------------------------------------------
@@ -192,10 +214,13 @@ class GraphedForward:
         return outs[0]
 
     # -- K frames per graph launch -----------------------------------------------------------------------------------------------------
-    def block(self, frames, adopt_inputs=False):
-        """Capture (once per sequence of shapes) the forwards of `frames`, in order, in one HIP graph.  `adopt_inputs=True`: the
-        given tensors ARE the static buffers (they stay resident in HBM and the producer overwrites them in place); otherwise
-        they are cloned.  The same object may appear several times (one forward per appearance, each with its own outputs)."""
+    def block(self, frames, adopt_inputs=False, chains=1):
+        """Capture (once per sequence of shapes) the forwards of `frames` in one HIP graph.  `adopt_inputs=True`: the given
+        tensors ARE the static buffers (they stay resident in HBM and the producer overwrites them in place); otherwise they are
+        cloned.  The same object may appear several times (one forward per appearance, each with its own outputs).
+        `chains=S` > 1: the forwards are dealt round robin onto S parallel branches of the graph -- S independent frames in flight,
+        each branch on its own workspace -- instead of one chain in frame order (a frame-sized forward is six dependent launches
+        that leave most of the chip idle)."""
         frames = list(frames)
         if not frames:
             raise ValueError("empty block")
@@ -206,7 +231,7 @@ class GraphedForward:
         dev = frames[0].x.device
         stamp = self._stamp(dev)
         self._drop_stale(stamp)
-        key = (tuple(_key(f) for f in frames), tuple(f.x.data_ptr() for f in frames) if adopt_inputs else None)
+        key = (tuple(_key(f) for f in frames), tuple(f.x.data_ptr() for f in frames) if adopt_inputs else None, int(chains))
         blk = self._blocks.get(key)
         if blk is None:
             clones = {}
@@ -218,7 +243,7 @@ class GraphedForward:
                     if id(f) not in clones:
                         clones[id(f)] = _clone(f)
                     inputs.append(clones[id(f)])
-            graph, outs, ws = self._capture(inputs)
+            graph, outs, ws = self._capture(inputs, chains=chains)
             blk = self._blocks[key] = GraphedBlock(graph, inputs, outs, stamp, ws)
         return blk
 

@@ -196,6 +196,12 @@ typedef struct gnncca_dropout {
  * Price: encoder 48 instead of 44 us at 8192 nodes (plan launch included), 87 instead of 70 us at 16 384.
  * Off by default. */
 #define GNNCCA_OPT_ENC_UNSPLIT 4u
+/* GNNCCA_OPT_NO_COLUMN_RANGES: by default (forwards with >= 2 message-passing steps, specialised kernels) step 1 derives, per source
+ * node, whether its target ids form at most two contiguous runs -- true for every graph the reference builds (inference.py:209-216:
+ * per camera, cartesian_prod with the detections of the other cameras) and for dense graphs -- and steps 2 ... L then COMPUTE the
+ * target ids instead of streaming them; a forward with any other node streams them on every step, as with this option.  Results are
+ * bit for bit the same either way (tests/test_gpu_column_ranges.py); the option exists for A/B measurements. */
+#define GNNCCA_OPT_NO_COLUMN_RANGES 8u
 GNNCCA_API int gnncca_mpn_forward_ex(const gnncca_mpn_dims* dims, const void* packed_dev, const float* x,
                                      const int64_t* edge_index, const float* edge_attr, int64_t n_nodes,
                                      int64_t n_edges, void* workspace, size_t workspace_bytes, float* logits_out,
@@ -346,6 +352,9 @@ GNNCCA_API int gnncca_aggregate(const float* messages, const int64_t* edge_index
 
 /* Synchronises `stream` and returns the flag word of the last forward that used `workspace`. */
 GNNCCA_API int gnncca_read_graph_flags(const void* workspace, uint32_t* flags_out, gnncca_stream_t stream);
+/* The same plus, in flags_out[1], the column-range verdict of that forward: 0 = every node's target ids were <= 2 contiguous runs (or
+ * the forward never asked: L < 2, general kernels, GNNCCA_OPT_NO_COLUMN_RANGES), 1 = some node's were not and every step streamed them. */
+GNNCCA_API int gnncca_read_graph_flags2(const void* workspace, uint32_t flags_out[2], gnncca_stream_t stream);
 
 #ifdef __cplusplus
 }

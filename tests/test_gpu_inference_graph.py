@@ -139,6 +139,15 @@ def test_block_of_k_frames_in_one_graph():
     assert len(ptrs) == 6
     for o in outs:
         assert _eq(o["classified_edges"], want)
+    # the same K forwards on three parallel branches of one graph (three frames in flight, a workspace per branch)
+    frames3 = [_frame(a, seed=40 + s) for s in range(7)]
+    with torch.no_grad():
+        want3 = [[t.clone() for t in m(f)["classified_edges"]] for f in frames3]
+    blk3 = gf.block(frames3, chains=3)
+    for rep in range(3):
+        outs = blk3.replay()
+        for o, w in zip(outs, want3):
+            assert _eq(o["classified_edges"], w), rep
 
 
 def test_forwards_in_flight_on_several_streams():
