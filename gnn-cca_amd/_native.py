@@ -54,7 +54,7 @@ class Dropout(C.Structure):
 OPT_EDGE_STATE_BF16 = 1
 OPT_ENC_SPLIT3 = 2
 OPT_ENC_UNSPLIT = 4
-OPT_NO_COLUMN_RANGES = 8
+OPT_COLUMN_RANGES = 8
 BWD_GRADS_ZEROED = 1
 
 

@@ -458,7 +458,7 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
     // column ranges instead of the col32 stream on steps 2 ... L of the specialised kernels (StepParams::rng)
     static const bool step_norange = diag_env("GNNCCA_STEP_NORANGE") != nullptr;   // diagnostics: A/B against streaming col32 on every step
     static const int range_max_e = diag_env_int("GNNCCA_RANGE_MAX_E", 0x7FFFFFFF, 0, 0x7FFFFFFF);   // diagnostics: edge count up to which the buffer-addressed kernel uses them
-    sp.rng = (L >= 2 && !step_norange && !(options & GNNCCA_OPT_NO_COLUMN_RANGES) && (sp.msg_f32 || E <= range_max_e)) ? reinterpret_cast<int*>(base + ws.rng) : nullptr;
+    sp.rng = (L >= 2 && !step_norange && (options & GNNCCA_OPT_COLUMN_RANGES) != 0 && (sp.msg_f32 || E <= range_max_e)) ? reinterpret_cast<int*>(base + ws.rng) : nullptr;
     sp.ws_base = base;
     sp.ws_bytes = ws.total;
     sp.so_e = (unsigned)ws.e, sp.so_col = (unsigned)ws.col32, sp.so_perm = (unsigned)ws.perm;

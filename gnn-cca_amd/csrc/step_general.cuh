@@ -60,7 +60,8 @@ struct StepParams {
     // number of breaks) into `rng`; a node with more than one break raises flags[1].  Steps 2 ... L then COMPUTE the target id of
     // position q of a segment -- q + (q < len1 ? start1 : start2 - len1) -- instead of streaming col32 (4 of 56 B per edge) and, more
     // to the point, request the P_dst gather together with the edge state instead of one dependent round trip later.  flags[1] != 0
-    // (graphs with arbitrary columns): every step streams col32 as before.  nullptr: off (L < 2, diagnostics).
+    // (graphs with arbitrary columns): every step streams col32 as before.  nullptr: off -- the default (GNNCCA_OPT_COLUMN_RANGES
+    // asks for it): measured, the id load and the gather behind it are not on the launches' critical path (include/gnncca_mpn.h).
     int* rng;
     // mpn_step_pipe_kernel addresses the workspace through ONE buffer descriptor: its base, size and the byte offsets of the regions
     const void* ws_base;

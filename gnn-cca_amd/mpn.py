@@ -362,9 +362,10 @@ class MOTMPNet(nn.Module):
         # bit for bit independent of the batch / shard it is computed in (default False: within rounding, <= 2e-6; the un-split kernel
         # of mid-size batches is 4-20 % slower on the encoder)
         self.encoder_unsplit = False
-        # True (default): steps 2 ... L compute the target ids from per-node column ranges derived by step 1 when every node's ids
-        # form <= 2 contiguous runs (dense and cross-camera graphs); False: GNNCCA_OPT_NO_COLUMN_RANGES (same bits; A/B measurements)
-        self.column_ranges = True
+        # True: GNNCCA_OPT_COLUMN_RANGES -- steps 2 ... L compute the target ids from per-node column ranges derived by step 1 when every
+        # node's ids form <= 2 contiguous runs (dense and cross-camera graphs).  Same bits either way; default False: measured, it
+        # gains nothing on MI355X (include/gnncca_mpn.h)
+        self.column_ranges = False
         # train mode: 'auto' = the fused kernels where they apply (the shipped shapes), else the layer-by-layer engine;
         # 'layerwise' / 'fused' force one (set it before the first training forward, or call .train() again)
         self.train_engine = 'auto'
@@ -377,7 +378,7 @@ class MOTMPNet(nn.Module):
         return (nat.OPT_EDGE_STATE_BF16 if self.edge_state_dtype == 'bf16' else 0) | \
                (nat.OPT_ENC_SPLIT3 if self.encoder_products == 3 else 0) | \
                (nat.OPT_ENC_UNSPLIT if self.encoder_unsplit else 0) | \
-               (0 if getattr(self, 'column_ranges', True) else nat.OPT_NO_COLUMN_RANGES)
+               (nat.OPT_COLUMN_RANGES if getattr(self, 'column_ranges', False) else 0)
 
     # -- construction --------------------------------------------------------------------------------------
     def _build_core_MPNet(self, model_params, encoder_feats_dict):
@@ -805,7 +806,7 @@ class MOTMPNet(nn.Module):
 
     def column_ranges_state(self):
         """Synchronises; 0 = the last forward found every node's target ids to be <= 2 contiguous runs (or never asked: fewer than two
-        steps, general kernels, column_ranges = False), 1 = some node's were not and every step streamed the ids."""
+        steps, general kernels, column_ranges left False), 1 = some node's were not and every step streamed the ids."""
         ws = self._hot.workspace
         if ws is None:
             return 0

@@ -196,12 +196,15 @@ typedef struct gnncca_dropout {
  * Price: encoder 48 instead of 44 us at 8192 nodes (plan launch included), 87 instead of 70 us at 16 384.
  * Off by default. */
 #define GNNCCA_OPT_ENC_UNSPLIT 4u
-/* GNNCCA_OPT_NO_COLUMN_RANGES: by default (forwards with >= 2 message-passing steps, specialised kernels) step 1 derives, per source
- * node, whether its target ids form at most two contiguous runs -- true for every graph the reference builds (inference.py:209-216:
- * per camera, cartesian_prod with the detections of the other cameras) and for dense graphs -- and steps 2 ... L then COMPUTE the
- * target ids instead of streaming them; a forward with any other node streams them on every step, as with this option.  Results are
- * bit for bit the same either way (tests/test_gpu_column_ranges.py); the option exists for A/B measurements. */
-#define GNNCCA_OPT_NO_COLUMN_RANGES 8u
+/* GNNCCA_OPT_COLUMN_RANGES (forwards with >= 2 message-passing steps, specialised kernels): step 1 derives, per source node, whether
+ * its target ids form at most two contiguous runs -- true for every graph the reference builds (inference.py:209-216: per camera,
+ * cartesian_prod with the detections of the other cameras) and for dense graphs -- and steps 2 ... L then COMPUTE the target ids
+ * instead of streaming them (4 of 56 B per edge, and the P_dst gather no longer waits for an id); a forward with any other node
+ * streams them on every step, as without the option.  Results are bit for bit the same either way
+ * (tests/test_gpu_column_ranges.py).  OFF by default: measured on MI355X it gains nothing -- 1 x dense256 27.6 -> 28.4 us per
+ * forward, 64 x dense128 99.9 -> 101.3, 64 x dense256 / 512 x dense128 / 200 x dense256 within noise (profiles/r04_logs/ab_ranges1.log):
+ * the id load and the gather behind it are not on these launches' critical path, and step 1 pays for the derivation. */
+#define GNNCCA_OPT_COLUMN_RANGES 8u
 GNNCCA_API int gnncca_mpn_forward_ex(const gnncca_mpn_dims* dims, const void* packed_dev, const float* x,
                                      const int64_t* edge_index, const float* edge_attr, int64_t n_nodes,
                                      int64_t n_edges, void* workspace, size_t workspace_bytes, float* logits_out,
@@ -353,7 +356,7 @@ GNNCCA_API int gnncca_aggregate(const float* messages, const int64_t* edge_index
 /* Synchronises `stream` and returns the flag word of the last forward that used `workspace`. */
 GNNCCA_API int gnncca_read_graph_flags(const void* workspace, uint32_t* flags_out, gnncca_stream_t stream);
 /* The same plus, in flags_out[1], the column-range verdict of that forward: 0 = every node's target ids were <= 2 contiguous runs (or
- * the forward never asked: L < 2, general kernels, GNNCCA_OPT_NO_COLUMN_RANGES), 1 = some node's were not and every step streamed them. */
+ * the forward never asked: no GNNCCA_OPT_COLUMN_RANGES, L < 2, general kernels), 1 = some node's were not and every step streamed them. */
 GNNCCA_API int gnncca_read_graph_flags2(const void* workspace, uint32_t flags_out[2], gnncca_stream_t stream);
 
 #ifdef __cplusplus

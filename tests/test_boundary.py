@@ -44,14 +44,14 @@ def test_forward_options_match_the_header():
     header = open(os.path.join(ROOT, "include", "gnncca_mpn.h")).read()
     defs = {k: int(v) for k, v in re.findall(r"#define (GNNCCA_OPT_\w+) (\d+)u", header)}
     assert defs == {"GNNCCA_OPT_EDGE_STATE_BF16": nat.OPT_EDGE_STATE_BF16, "GNNCCA_OPT_ENC_SPLIT3": nat.OPT_ENC_SPLIT3,
-                    "GNNCCA_OPT_ENC_UNSPLIT": nat.OPT_ENC_UNSPLIT, "GNNCCA_OPT_NO_COLUMN_RANGES": nat.OPT_NO_COLUMN_RANGES}
+                    "GNNCCA_OPT_ENC_UNSPLIT": nat.OPT_ENC_UNSPLIT, "GNNCCA_OPT_COLUMN_RANGES": nat.OPT_COLUMN_RANGES}
     assert len(set(defs.values())) == 4 and all(v & (v - 1) == 0 for v in defs.values())   # distinct single bits
     m, *_ = _model("dense64")
     assert m._options() == 0
     m.edge_state_dtype, m.encoder_products, m.encoder_unsplit = "bf16", 3, True
     assert m._options() == nat.OPT_EDGE_STATE_BF16 | nat.OPT_ENC_SPLIT3 | nat.OPT_ENC_UNSPLIT
-    m.column_ranges = False
-    assert m._options() == nat.OPT_EDGE_STATE_BF16 | nat.OPT_ENC_SPLIT3 | nat.OPT_ENC_UNSPLIT | nat.OPT_NO_COLUMN_RANGES
+    m.column_ranges = True
+    assert m._options() == nat.OPT_EDGE_STATE_BF16 | nat.OPT_ENC_SPLIT3 | nat.OPT_ENC_UNSPLIT | nat.OPT_COLUMN_RANGES
     m.encoder_products = 4
     with pytest.raises(ValueError):
         m._options()

@@ -1,8 +1,8 @@
-"""Column ranges (round 4): steps 2 ... L of the specialised step kernels compute the target ids of a segment from the per-node
+"""Column ranges (round 4; an option, off by default -- measured: no gain): steps 2 ... L of the specialised step kernels compute the target ids of a segment from the per-node
 (start1, len1, start2) step 1 derives, when every node's target ids are <= 2 contiguous runs -- the shape of every graph the reference
 builds (inference.py:209-216) and of dense graphs; any other forward streams col32 on every step.  Pinned here: the verdict
 (`column_ranges_state`) for each graph family, and logits BIT FOR BIT equal to the streaming path (`model.column_ranges = False`,
-GNNCCA_OPT_NO_COLUMN_RANGES) -- on the f32 kernel of graphs up to 512 nodes and on the buffer-addressed kernel beyond."""
+the default; True = GNNCCA_OPT_COLUMN_RANGES) -- on the f32 kernel of graphs up to 512 nodes and on the buffer-addressed kernel beyond."""
 import numpy as np
 import pytest
 import torch
@@ -136,6 +136,7 @@ def test_verdict_is_per_forward_and_shapes_may_alternate():
     same stream, same workspace -- nothing of the previous forward may leak (stale ranges, a stale verdict)."""
     params, arch, sd = _default_model(1.0 / 99)
     m = build(params, arch, sd)
+    m.column_ranges = True
     m_ref = build(params, arch, sd)
     m_ref.column_ranges = False
     good, n_g = cross_camera_graph([30, 20, 50])
