@@ -237,6 +237,10 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
                     HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsGemmBytes));
                 attr_dev = dev;
             }
+            // (Round 4 measured a 64-ROW split-K tiling for the mid-size batches -- 128 row blocks at 8192 nodes, split-K 4, two 64-KB-LDS
+            // workgroups per CU, half the slabs: correct, and slower at every size: 32.1 vs 27.8 us at N = 8192 with a 7.0 instead of 9.3 us
+            // tail, 59 vs 46 at 16 384, 129 vs 96 at 32 768 -- 4x the W traffic from L2 and one accumulation chain per wave; the kernel and
+            // the log are kept under profiles/r04_logs/: enc_rows64.cuh.txt, ab_enc64_1.log.)
             if (use_r32) {
                 const dim3 rgrid((unsigned)((N + 31) / 32) + 1);
                 const int nst = r32_nst == 4 || r32_nst == 8 ? r32_nst : ((N + 31) / 32 <= 256 ? 8 : 4);
