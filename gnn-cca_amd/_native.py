@@ -116,6 +116,7 @@ _SIGNATURES = {
     "gnncca_aggregate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t,
                                    C.c_void_p]),
     "gnncca_train_tape_bytes": (C.c_size_t, [C.POINTER(MpnDims), C.c_int64, C.c_int64]),
+    "gnncca_train_tape_latents": (C.c_int, [C.POINTER(MpnDims), C.c_int64, C.c_int64, C.POINTER(C.c_int64), C.c_int]),
     "gnncca_train_forward": (C.c_int, [C.POINTER(MpnDims), C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_int64, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(Dropout), C.c_void_p]),
     "gnncca_train_backward": (C.c_int, [C.POINTER(MpnDims), C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,

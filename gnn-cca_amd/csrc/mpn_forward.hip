@@ -593,6 +593,21 @@ size_t gnncca_train_tape_bytes(const gnncca_mpn_dims* d, int64_t n_nodes, int64_
     return P.total;
 }
 
+int gnncca_train_tape_latents(const gnncca_mpn_dims* d, int64_t n_nodes, int64_t n_edges, int64_t* offsets_out, int n_offsets) {
+    TrPlan P;
+    if (!d || !offsets_out || n_nodes < 0 || n_edges < 0 || !tr_plan(d, n_nodes, n_edges, &P)) return GNNCCA_ERR_INVALID_ARG;
+    const int L = d->num_enc_steps;
+    if (n_offsets != 2 + 2 * L) return GNNCCA_ERR_INVALID_ARG;
+    auto last = [](const TrCall& c, const gnncca_mlp& m) -> int64_t { return m.n_layers > 0 ? (int64_t)c.lay[m.n_layers - 1].a : -1; };
+    offsets_out[0] = last(P.enc_node, d->enc_node);
+    offsets_out[1] = last(P.enc_edge, d->enc_edge);
+    for (int s = 0; s < L; ++s) {
+        offsets_out[2 + 2 * s] = (int64_t)P.h[s];
+        offsets_out[3 + 2 * s] = last(P.edge[s], d->edge_mlp);
+    }
+    return GNNCCA_OK;
+}
+
 int gnncca_train_forward(const gnncca_mpn_dims* d, float* const* params_dev, int n_params, const float* x, const int64_t* edge_index,
                          const float* edge_attr, int64_t n_nodes, int64_t n_edges, void* tape, size_t tape_bytes, float* logits_out,
                          const gnncca_dropout* dropout, gnncca_stream_t stream) {

@@ -87,9 +87,11 @@ class _Replayed(nn.Module):
     MOTMPNet forward runs fused inside libgnncca_mpn.so.  When a caller has registered forward hooks on one of them (the way
     per-step latents are usually tapped from the reference), MOTMPNet.forward runs the traced native forward and then
     REPLAYS the reference's call sequence (models/mpn.py:266-297) through ``__call__`` of these containers: each call returns
-    the tensors the fused kernels produced for it, so hooks see the same inputs and outputs as on the reference (EVAL MODE
-    ONLY: a train-mode forward does not replay, hooks on these containers then do not fire and MOTMPNet.forward warns once).  A
-    container called on its own, outside MOTMPNet.forward, evaluates itself with the stand-alone entry points (eval mode)."""
+    the tensors the fused kernels produced for it, so hooks see the same inputs and outputs as on the reference -- in eval mode
+    the latents of the traced forward, in train mode the latents the training forward saved for its backward (train-mode values:
+    BatchNorm with batch statistics, Dropout applied; the classifier outputs are the autograd-connected logits, the latents are
+    detached views).  A container called on its own, outside MOTMPNet.forward, evaluates itself with the stand-alone entry points
+    (eval mode)."""
 
     def _take_replayed(self):
         queue = getattr(self, '_replay_queue', None)
@@ -222,6 +224,8 @@ class _MPNTrainFunction(torch.autograd.Function):
                                                              C.byref(drop) if drop is not None else None, _raw_stream(x.device))
                 nat.check(st, "gnncca_classifier_train")
                 bn.num_batches_tracked += n_out  # one BatchNorm call per classified step (models/mpn.py:292)
+        if module._containers_hooked():   # forward hooks on encoder / MPNet / classifier: MOTMPNet.forward replays them from these
+            module._train_latents = (trace['h_enc'], trace['e_enc'], list(trace['h_steps'].unbind(0)), list(trace['e_steps'].unbind(0)))
         ctx.module = module
         ctx.n_params = len(params)
         ctx.has_bn = bn is not None
@@ -280,6 +284,18 @@ class _LayerwiseTrainFunction(torch.autograd.Function):
                                           n, e, tape.data_ptr(), tape.numel(), logits.data_ptr(),
                                           C.byref(drop) if drop is not None else None, _raw_stream(dev))
         nat.check(st, "gnncca_train_forward")
+        if module._containers_hooked() and n > 0 and e > 0:
+            L = int(module.num_enc_steps)
+            offs = (C.c_int64 * (2 + 2 * L))()
+            nat.check(lib.gnncca_train_tape_latents(C.byref(d), n, e, offs, 2 + 2 * L), "gnncca_train_tape_latents")
+
+            def view(off, rows, width, passthrough):
+                if off < 0:
+                    return passthrough
+                return tape[off:off + rows * width * 4].view(torch.float32).view(rows, width)
+            module._train_latents = (view(offs[0], n, d.node_dim, x), view(offs[1], e, d.edge_dim, edge_attr),
+                                     [view(offs[2 + 2 * s], n, d.node_dim, None) for s in range(L)],
+                                     [view(offs[3 + 2 * s], e, d.edge_dim, None) for s in range(L)])
         module._count_batchnorm_calls(n_out if e > 0 else 0, e > 0)
         ctx.module, ctx.tape, ctx.drop, ctx.drop_seed = module, tape, drop, seed
         ctx.save_for_backward(x, edge_index, edge_attr, *params)
@@ -393,8 +409,12 @@ class MOTMPNet(nn.Module):
         # widths of the concatenations at mpn.py:68 and mpn.py:97
         edge_mlp = MLP(nf * 2 * h + ef * f, edge_cfg['fc_dims'], edge_cfg['dropout_p'], edge_cfg['use_batchnorm'])
         node_mlp = MLP(nf * h + f, node_cfg['fc_dims'], node_cfg['dropout_p'], node_cfg['use_batchnorm'])
-        # The reference then builds an unused `node_mlp_old` Linear(2h, h) (mpn.py:241-242); it only advances
-        # the global RNG after every real parameter exists, so it is not reproduced.
+        # The reference then builds an unused `node_mlp_old` = Linear(2h, h) + ReLU (mpn.py:241-242).  It registers nothing, but its
+        # initialisation draws from torch's global generator after every real parameter exists: a seeded script (main_training.py seeds,
+        # builds the model, then shuffles / samples) sees a different stream afterwards unless the same amount is drawn here.  The
+        # throwaway layer is built and dropped (tests/test_boundary.py: same seed => same parameters AND same generator state as the
+        # reference, pinned by tests/golden/rng_after_init.npz).
+        nn.Linear(2 * h, h)
         return MetaLayer(edge_model=EdgeModel(edge_mlp), node_model=NodeModel(node_mlp, node_agg_fn.lower()))
 
     # -- native description ----------------------------------------------------------------------------------
@@ -595,12 +615,6 @@ class MOTMPNet(nn.Module):
         """See class docstring.  ``trace`` (optional dict) receives the intermediate latents for debugging.
         In train mode the outputs carry an autograd graph to the parameters (row N3)."""
         if self.training:
-            if self._containers_hooked() and not getattr(self, '_warned_train_hooks', False):
-                # the replay of the container calls exists for eval mode only (the training tape keeps other tensors)
-                import warnings
-                warnings.warn("forward hooks on encoder / MPNet / classifier do not fire in train mode on gnn_cca_amd.MOTMPNet "
-                              "(the fused training forward has no such calls); tap the latents in eval mode", RuntimeWarning)
-                self._warned_train_hooks = True
             return self._forward_train(data)
         if trace is None and self._containers_hooked():
             return self._forward_replayed(data)
@@ -618,16 +632,21 @@ class MOTMPNet(nn.Module):
         reference's own call sequence (models/mpn.py:266-297) through the containers, each call handing back what the fused
         kernels computed for it.  Hooks on deeper modules (edge_model, node_model, the MLPs) do not fire: those calls do not
         exist as separate steps on this path."""
-        x, edge_index, edge_attr = data.x, data.edge_index, data.edge_attr
         trace = {}
-        logits = self._forward_native(x, edge_index, edge_attr, trace)
+        logits = self._forward_native(data.x, data.edge_index, data.edge_attr, trace)
+        return self._replay_containers(data, list(logits.unbind(0)), trace['h_enc'], trace['e_enc'], list(trace['h_steps'].unbind(0)),
+                                       list(trace['e_steps'].unbind(0)))
+
+    def _replay_containers(self, data, logits, h_enc, e_enc, h_steps, e_steps):
+        """The call sequence of models/mpn.py:266-297 through the three containers; every call returns the given tensors."""
+        x, edge_index, edge_attr = data.x, data.edge_index, data.edge_attr
         L, n_cls = int(self.num_enc_steps), int(self.num_class_steps)
-        enc_q, mp_q, cls_q = [(trace['e_enc'], trace['h_enc'])], [], []
+        enc_q, mp_q, cls_q = [(e_enc, h_enc)], [], []
         first_class_step = L - n_cls + 1
         for step in range(1, L + 1):
-            mp_q.append((trace['h_steps'][step - 1], trace['e_steps'][step - 1]))
-        for i in range(logits.shape[0]):
-            cls_q.append((logits[i], None))
+            mp_q.append((h_steps[step - 1], e_steps[step - 1]))
+        for t in logits:
+            cls_q.append((t, None))
         self.encoder._replay_queue, self.MPNet._replay_queue, self.classifier._replay_queue = enc_q, mp_q, cls_q
         try:
             latent_edge, latent_node = self.encoder(edge_attr, x)
@@ -746,7 +765,11 @@ class MOTMPNet(nn.Module):
         x, edge_index, edge_attr = self._check_inputs(data.x, data.edge_index, data.edge_attr)
         self._check_batchnorm_rows(x.shape[0], edge_index.shape[1])
         fn = _MPNTrainFunction if self._train_path == 'fused' else _LayerwiseTrainFunction
+        self._train_latents = None
         logits = fn.apply(self, x.detach(), edge_index, edge_attr.detach(), *params)
+        latents, self._train_latents = self._train_latents, None
+        if latents is not None:   # forward hooks on the containers: the reference's call sequence, fed from what the forward saved
+            return self._replay_containers(data, list(logits.unbind(0)), *latents)
         return {'classified_edges': list(logits.unbind(0))}
 
     def _forward_native(self, x, edge_index, edge_attr, trace=None, dropout=None):

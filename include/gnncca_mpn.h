@@ -327,6 +327,13 @@ GNNCCA_API int gnncca_mpn_backward_train(const gnncca_mpn_dims* dims, const floa
  * `grad_logits` [n_out][E].  The shipped shapes have the fused pair gnncca_mpn_forward_train / gnncca_mpn_backward_train;
  * this engine is the one that covers everything else (one launch per op, correctness first). */
 GNNCCA_API size_t gnncca_train_tape_bytes(const gnncca_mpn_dims* dims, int64_t n_nodes, int64_t n_edges);
+/* Where the tape of gnncca_train_forward keeps the latents a forward hook on the reference's containers would see (models/mpn.py:270,
+ * 288: the outputs of `encoder` and of every `MPNet` call, train-mode values: batch-statistics BatchNorm, Dropout applied): byte
+ * offsets into the tape, offsets_out[0] = encoder node output [N][node_dim], [1] = encoder edge output [E][edge_dim], then per step s
+ * (0-based) [2 + 2 s] = node latents after the step [N][node_dim], [3 + 2 s] = edge latents after the step [E][edge_dim]; -1 where
+ * the MLP has no layer (its input passes through).  n_offsets must be 2 + 2 * num_enc_steps.  Pure function of (dims, N, E). */
+GNNCCA_API int gnncca_train_tape_latents(const gnncca_mpn_dims* dims, int64_t n_nodes, int64_t n_edges, int64_t* offsets_out,
+                                         int n_offsets);
 GNNCCA_API int gnncca_train_forward(const gnncca_mpn_dims* dims, float* const* params_dev, int n_params, const float* x,
                                     const int64_t* edge_index, const float* edge_attr, int64_t n_nodes, int64_t n_edges,
                                     void* tape, size_t tape_bytes, float* logits_out, const gnncca_dropout* dropout,

@@ -60,6 +60,28 @@ def test_forward_options_match_the_header():
         m._options()
 
 
+@pytest.mark.parametrize("case", ["default_bn", "bn_off_mean", "reattach", "generic"])
+def test_same_seed_gives_the_reference_parameters_and_generator_state(case):
+    """Construction under a seed reproduces the reference bit for bit: every parameter / buffer of the state_dict (sha256 over
+    names and bytes, in order) AND the state of torch's global generator afterwards -- the reference's unused `node_mlp_old`
+    (models/mpn.py:241-242) draws from it after the real parameters exist, so a seeded training script that shuffles or samples
+    after building the model sees the same stream.  Golden: tests/golden/make_golden_rng.py (the reference's own constructor)."""
+    import hashlib
+    import json
+    from gnn_cca_amd import MOTMPNet
+    g = np.load(os.path.join(GOLDEN_DIR, "rng_after_init.npz"))
+    params, arch, seed = json.loads(str(g[f"{case}::params_json"])), str(g[f"{case}::arch"]), int(g[f"{case}::seed"])
+    torch.manual_seed(seed)
+    m = MOTMPNet(copy.deepcopy(params), None, arch)
+    after = torch.rand(8).numpy()
+    h = hashlib.sha256()
+    for k, v in m.state_dict().items():
+        h.update(k.encode())
+        h.update(v.detach().cpu().contiguous().numpy().tobytes())
+    assert np.array_equal(np.frombuffer(h.digest(), dtype=np.uint8), g[f"{case}::state_sha256"])
+    assert np.array_equal(after, g[f"{case}::after"])
+
+
 @pytest.mark.parametrize("name", golden_cases())
 def test_state_dict_keys_and_shapes_match_reference(name):
     m, params, arch, sd, _ = _model(name)
