@@ -1,12 +1,16 @@
-"""Importable alias of the package directory ``gnn-cca_amd/`` (a hyphen cannot appear in a Python module name).
+"""In-tree import name of the package directory ``gnn-cca_amd/`` (a hyphen cannot appear in a Python module name).
 
-``import gnn_cca_amd`` executes ``gnn-cca_amd/__init__.py`` with this package's ``__path__`` pointing there, so
-``gnn_cca_amd.mpn``, ``gnn_cca_amd._native`` ... resolve to the files under ``gnn-cca_amd/``.
+This is an ordinary package whose search path is extended to that directory: ``gnn_cca_amd.mpn``, ``gnn_cca_amd._native`` ...
+resolve to the files under ``gnn-cca_amd/`` through the normal import machinery (no exec).  An installed copy (``setup.py`` maps
+the package name onto the directory) does not need this file.
+
+    from gnn_cca_amd import MOTMPNet          # same constructor / forward / state_dict as models/mpn.py:144-299
 """
 import os as _os
 
-_real = _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "gnn-cca_amd")
-__path__ = [_real]
-with open(_os.path.join(_real, "__init__.py")) as _f:
-    exec(compile(_f.read(), _os.path.join(_real, "__init__.py"), "exec"))
-del _f
+__path__.append(_os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "gnn-cca_amd"))
+
+from .mlp import MLP  # noqa: E402,F401
+from .mpn import EdgeModel, MetaLayer, MLPGraphIndependent, MOTMPNet, NodeModel  # noqa: E402,F401
+
+__all__ = ["MOTMPNet", "MetaLayer", "EdgeModel", "NodeModel", "MLPGraphIndependent", "MLP"]
