@@ -365,6 +365,147 @@ def cpu_baseline_fused(params, model, n_nodes, n_graphs, budget_s=8.0):
                       f"threads on a {os.cpu_count()}-thread host; fused split-weight C restatement (oracle/mpn_oracle_c.c), fp32"}
 
 
+# ---- the reference's actual inference workload: real frame shapes of EPFL-Terrace through rows N1 + MPN + N2 ------------------------
+def terrace_frames(batch, n_batches, seed=0):
+    """Batches of `batch` consecutive valid frames of the reference's own sequence (tests/golden/terrace_topology.npz: camera and
+    person id of every detection, derived from datasets/EPFL-Terrace/*/gt/gt.txt by tests/golden/make_terrace_topology.py --
+    4816 valid frames, 19.1 detections / 343 edges per frame on average, at most 34 / 866).  Images and ReID weights are not in the
+    repository, so positions and embeddings are SYNTHETIC: a ground-plane position and a 256-d / 2048-d appearance vector per
+    person, plus detection noise.  Returns a list of dicts of host arrays (what libs/datasets.py + the CNN would hand over)."""
+    z = np.load(os.path.join(ROOT, "tests", "golden", "terrace_topology.npz"))
+    ptr, cam, person = z["node_ptr"], z["cam"].astype(np.int64), z["person"].astype(np.int64)
+    n_frames = len(ptr) - 1
+    rng = np.random.default_rng(seed)
+    n_person = int(person.max()) + 1
+    app_reid = rng.standard_normal((n_person, 256)).astype(np.float32)
+    app_node = rng.standard_normal((n_person, 2048)).astype(np.float32)
+    pos = rng.uniform(-8.0, 8.0, size=(n_person, 2))
+    out = []
+    for b in range(n_batches):
+        f0 = (b * max((n_frames - batch) // max(n_batches, 1), 1)) % max(n_frames - batch, 1)   # batches spread over the whole sequence
+        lo, hi = int(ptr[f0]), int(ptr[f0 + batch])
+        ids, cams = person[lo:hi], cam[lo:hi]
+        n = hi - lo
+        out.append({"sizes": np.diff(ptr[f0:f0 + batch + 1]).astype(np.int64), "id_cam": cams, "ids": ids,
+                    "xw": pos[ids, 0] + rng.normal(0, 0.3, n), "yw": pos[ids, 1] + rng.normal(0, 0.3, n),
+                    "max_dist": np.full(batch, 80.0),
+                    "node": (app_node[ids] + 0.5 * rng.standard_normal((n, 2048))).astype(np.float32),
+                    "reid": (app_reid[ids] + 0.5 * rng.standard_normal((n, 256))).astype(np.float32)})
+    return out
+
+
+def terrace_leg(device, args, batch=64, n_batches=16, cpu_budget_s=12.0):
+    """`terrace_pipeline`: batches of 64 real-shaped frames (train BATCH_SIZE, config_training.yaml:53-54) through
+    build_graph_batch -> MOTMPNet -> threshold -> prune_and_cluster (inference.py:189-345 without the bridge heuristics), every
+    batch a different set of frames (no shape repeats, so nothing is graph-captured: eager calls); the CPU oracle chain
+    (oracle.graph_oracle + oracle.TorchOracle + oracle.post_oracle) is the parity check and the baseline."""
+    import copy
+
+    from gnn_cca_amd.graph_build import build_graph_batch
+    from gnn_cca_amd.postprocess import prune_and_cluster, threshold
+    from oracle import graph_oracle as go
+    from oracle import post_oracle as po
+    from oracle.mpn_oracle import TorchOracle
+    params = graph_net_params(L=4)
+    frames = terrace_frames(batch, n_batches)
+    model = build_model(copy.deepcopy(params), 20, seed=0).to(device)    # out-degrees ~19: node-MLP conditioned with 1/19
+    dev_in = [(torch.from_numpy(f["node"]).to(device), torch.from_numpy(f["reid"]).to(device)) for f in frames]
+
+    def run(i):
+        f, (node, reid) = frames[i], dev_in[i]
+        b = build_graph_batch(f["xw"], f["yw"], f["ids"], f["id_cam"], f["sizes"], f["max_dist"], node, reid)
+        with torch.no_grad():
+            out = model(b)
+        probs, preds = threshold(out["classified_edges"][-1])
+        post = prune_and_cluster(b.edge_index, preds, b.x.shape[0], b.node_ptr_dev, b.edge_ptr_dev)
+        return b, out, preds, post
+
+    # random weights put every logit on one side of 0: centre them on batch 0 so that pruning / clustering have work to do
+    with torch.no_grad():
+        b0, out0, _, _ = run(0)
+        sd = model.state_dict()
+        last_bias = [k for k in sd if k.startswith("classifier.") and k.endswith(".bias")][-1]
+        sd[last_bias] -= out0["classified_edges"][-1].median()
+        model.load_state_dict(sd)
+    for i in range(min(3, n_batches)):
+        run(i)
+    torch.cuda.synchronize()
+    stage = {"graph_build": 0.0, "mpn": 0.0, "post": 0.0}
+    t0 = time.perf_counter()
+    reps = 3
+    edges = nodes = 0
+    for _ in range(reps):
+        for i in range(n_batches):
+            b, _, _, _ = run(i)
+            edges += b.edge_index.shape[1]
+            nodes += b.x.shape[0]
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    for i in range(n_batches):   # stage split (synchronised between stages: for the split only, not part of the figure above)
+        f, (node, reid) = frames[i], dev_in[i]
+        torch.cuda.synchronize(); t = time.perf_counter()
+        b = build_graph_batch(f["xw"], f["yw"], f["ids"], f["id_cam"], f["sizes"], f["max_dist"], node, reid)
+        torch.cuda.synchronize(); stage["graph_build"] += time.perf_counter() - t; t = time.perf_counter()
+        with torch.no_grad():
+            out = model(b)
+        torch.cuda.synchronize(); stage["mpn"] += time.perf_counter() - t; t = time.perf_counter()
+        probs, preds = threshold(out["classified_edges"][-1])
+        prune_and_cluster(b.edge_index, preds, b.x.shape[0], b.node_ptr_dev, b.edge_ptr_dev)
+        torch.cuda.synchronize(); stage["post"] += time.perf_counter() - t
+    # ---- parity + CPU baseline: the oracle chain on the same batches --------------------------------------------------------------
+    sdn = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    orc = TorchOracle(copy.deepcopy(params), "resnet50", sdn)
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
+    parity, cpu_t, cpu_edges, cpu_frames = None, 0.0, 0, 0
+    for i in range(n_batches):
+        f = frames[i]
+        tc = time.perf_counter()
+        reid_n, node_n = go.normalize_columns(f["reid"]), go.normalize_columns(f["node"])
+        ei, ea, _ = go.build(f["xw"], f["yw"], f["ids"], f["id_cam"], f["sizes"], f["max_dist"], reid_n)
+        ref = orc.forward(node_n, ei, ea)
+        r_probs, r_preds = po.threshold(np.asarray(ref[-1]).reshape(-1))
+        r_pruned = po.prune(ei, r_preds)
+        n = node_n.shape[0]
+        r_lab, r_k = po.clusters(ei, r_pruned, n)
+        cpu_t += time.perf_counter() - tc
+        cpu_edges += ei.shape[1]
+        cpu_frames += batch
+        if i == 0:
+            b, out, preds, post = run(0)
+            torch.cuda.synchronize()
+            g_logit = out["classified_edges"][-1].view(-1).cpu().numpy()
+            r_logit = np.asarray(ref[-1]).reshape(-1)
+            firm = np.abs(r_logit) > 1e-4     # an edge whose logit sits on the threshold may legitimately flip
+            flips = int((preds.cpu().numpy() != r_preds).sum())
+            parity = {"edge_index_equal": bool(np.array_equal(b.edge_index.cpu().numpy(), ei)),
+                      "edge_attr_max_abs_err": float(np.abs(b.edge_attr.cpu().numpy() - ea).max()),
+                      "logit_max_abs_err": [float(np.abs(o.view(-1).cpu().numpy() - np.asarray(r).reshape(-1)).max())
+                                            for o, r in zip(out["classified_edges"], ref)],
+                      "prediction_flips": flips, "flips_on_firm_logits": int((preds.cpu().numpy() != r_preds)[firm].sum()),
+                      "pruned_equal": bool(np.array_equal(post["pruned"].cpu().numpy(), r_pruned)) if flips == 0 else None,
+                      "clusters_equal": (bool(int(post["n_clusters"].item()) == r_k and po.same_partition(post["labels"].cpu().numpy(), r_lab))
+                                         if flips == 0 else None),
+                      "clusters": int(post["n_clusters"].item()), "active_edges": int(post["pruned"].sum().item()),
+                      "tolerance_abs": 1e-4, "against": "oracle.graph_oracle + oracle.TorchOracle + oracle.post_oracle, batch 0"}
+            parity["ok"] = bool(parity["edge_index_equal"] and parity["edge_attr_max_abs_err"] <= 1e-5 and
+                                max(parity["logit_max_abs_err"]) <= 1e-4 and parity["flips_on_firm_logits"] == 0 and
+                                parity["pruned_equal"] is not False and parity["clusters_equal"] is not False)
+        if cpu_t > cpu_budget_s:
+            break
+    n_done = reps * n_batches
+    return {"workload": f"{n_batches} batches of {batch} consecutive valid EPFL-Terrace frames (real per-frame camera / identity "
+                        f"structure, synthetic positions and embeddings): {nodes // n_done} detections, {edges // n_done} edges per batch",
+            "pipeline": "gnn_cca_amd.graph_build.build_graph_batch -> MOTMPNet.forward (L=4) -> postprocess.threshold -> "
+                        "postprocess.prune_and_cluster, eager, host planning and H2D of the per-detection arrays included",
+            "ms_per_batch": dt / n_done * 1e3, "frames_per_s": batch * n_done / dt, "edges_per_s": edges / dt,
+            "stage_ms_per_batch_synchronised": {k: v / n_batches * 1e3 for k, v in stage.items()},
+            "parity": parity,
+            "cpu_baseline": {"ms_per_batch": cpu_t / max(cpu_frames // batch, 1) * 1e3, "frames_per_s": cpu_frames / cpu_t,
+                             "edges_per_s": cpu_edges / cpu_t, "cores": min(os.cpu_count() or 1, 16), "kind": "port",
+                             "sample": f"{cpu_frames // batch} of the same batches through the oracle chain (numpy graph build, torch CPU "
+                                       f"MPN op for op, numpy / scipy post-processing)"}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -388,6 +529,7 @@ def main():
     ap.add_argument("--streams", type=int, default=3, help="forwards in flight of the `pipelined` leg (N = 1, --mode auto; 0 / 1: skip)")
     ap.add_argument("--no-scale-probe", action="store_true", help="skip the 64-graph batch probe of the step kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-terrace", action="store_true", help="skip the EPFL-Terrace frame-distribution pipeline leg (N = 1)")
     ap.add_argument("--no-config4", action="store_true", help="skip the sharded 512 x dense128 leg (BASELINE config 4)")
     ap.add_argument("--config4-graphs", type=int, default=512)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for rehearsals)")
@@ -498,8 +640,8 @@ def main():
         mode_used = api[best] + (" (auto: fastest of " + ", ".join(sorted(by_mode)) + ")" if args.mode == "auto" else "")
         run = forms[best][0] or eager_run
         t = blocks[len(blocks) // 2]      # median block of K steps (max over ranks inside every block)
-        # S forwards in flight: the K forwards of a block dealt onto S PARALLEL branches of one HIP graph (GraphedForward.block(...,
-        # chains=S): each branch on its own workspace, every forward complete with its own outputs) -- whole-job throughput of
+        # S forwards in flight: the K forwards of a block dealt onto S HIP graphs replayed on S streams (GraphedForward.block(...,
+        # chains=S): each chain on its own workspace, every forward complete with its own outputs) -- whole-job throughput of
         # independent frames, reported beside `value`, never as `value`
         pipelined = None
         if world == 1 and args.streams > 1 and args.mode == "auto" and "graph_block" in forms:
@@ -513,8 +655,8 @@ def main():
                 pipelined = {"api": f"gnn_cca_amd.inference.GraphedForward.block(frames, chains={args.streams})", "chains": args.streams,
                              "ms_per_forward": t_s / args.steps * 1e3, "value": E * args.steps / t_s, "unit": "edges/s",
                              "bitwise_equal_to_value_mode": bool(same),
-                             "note": f"the {args.steps} forwards of a block on {args.streams} parallel branches of one HIP graph (independent "
-                                     "frames in flight, one workspace per branch); every forward complete; not `value`"}
+                             "note": f"the {args.steps} forwards of a block as {args.streams} HIP graphs on {args.streams} streams (independent "
+                                     "frames in flight, one workspace per chain); every forward complete; not `value`"}
                 del blk_s, out_s
             except Exception as exc:  # noqa: BLE001
                 pipelined = {"error": f"{type(exc).__name__}: {exc}"}
@@ -670,6 +812,11 @@ def main():
                 res["config4_share"] = share
         if world == 1 and args.graphs == 1 and not args.no_scale_probe:
             res["roofline_at_scale"] = scale_probe(params, device, args)
+        if world == 1 and not args.no_terrace:
+            try:
+                res["terrace_pipeline"] = terrace_leg(device, args)
+            except Exception as exc:  # noqa: BLE001
+                res["terrace_pipeline"] = {"error": f"{type(exc).__name__}: {exc}"}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(params, model, args.nodes, args.graphs)
             res["parity"] = res["cpu_baseline"].pop("parity", None)

@@ -19,7 +19,7 @@ replayed: `GraphedForward` does that, in three forms.
   * `gf.block(frames)`: K frames captured BACK TO BACK in one HIP graph (K whole forwards, every launch of each, each with its own
     outputs) -- the K-deep form: one graph launch per K frames, the launch-bound loop runs without the host in it.
     `blk.replay()` -> list of K output dicts; `blk.inputs[i]` are the static buffers of frame i.  `gf.block(frames, chains=S)`
-    deals the K forwards onto S parallel branches of that graph (S frames in flight, one workspace per branch).
+    deals the K forwards onto S graphs replayed on S streams (S frames in flight, one workspace per chain).
   * `streams=S`: S independent forwards in flight, each stream replaying its own graph on its own workspace (the module keeps a
     workspace per stream; the packed weights are shared and read-only).  `gf.submit(data)` returns a `Pending` whose
     `.result()` makes the CURRENT stream wait for that forward only.
@@ -65,18 +65,19 @@ def _copy_into(static, data):
 
 
 class GraphedBlock:
-    """K forwards captured back to back in ONE HIP graph (GraphedForward.block)."""
+    """K forwards captured in ONE HIP graph back to back, or (chains = S) in S graphs replayed on S streams (GraphedForward.block)."""
 
-    def __init__(self, graph, inputs, outputs, stamp, workspace):
-        self._graph, self.inputs, self.outputs, self._stamp, self._workspace = graph, inputs, outputs, stamp, workspace
+    def __init__(self, graphs, streams, inputs, outputs, stamp, workspaces):
+        self._graphs, self._streams, self.inputs, self.outputs, self._stamp, self._workspaces = graphs, streams, inputs, outputs, stamp, workspaces
 
     def __len__(self):
         return len(self.inputs)
 
     def replay(self, frames=None):
-        """Run the K forwards (one graph launch on the current stream).  `frames`: K new frames to copy into the static inputs
-        first (same shapes as at capture; omit when the producer wrote them there).  Returns the K output dicts -- static tensors,
-        valid until the next replay."""
+        """Run the K forwards: one graph launch on the current stream -- or, with S chains, one launch per chain on its own stream,
+        forked from and joined back into the current stream by events (no host synchronisation).  `frames`: K new frames to copy into
+        the static inputs first (same shapes as at capture; omit when the producer wrote them there).  Returns the K output dicts --
+        static tensors, valid until the next replay."""
         if frames is not None:
             if len(frames) != len(self.inputs):
                 raise ValueError(f"this block holds {len(self.inputs)} frames, got {len(frames)}")
@@ -84,7 +85,19 @@ class GraphedBlock:
                 if _key(f) != _key(s):
                     raise ValueError("frame shapes differ from the captured block's")
                 _copy_into(s, f)
-        self._graph.replay()
+        if len(self._graphs) == 1:
+            self._graphs[0].replay()
+            return self.outputs
+        cur = torch.cuda.current_stream()
+        fork = torch.cuda.Event()
+        fork.record(cur)
+        for g, st in zip(self._graphs, self._streams):
+            st.wait_event(fork)
+            with torch.cuda.stream(st):
+                g.replay()
+            done = torch.cuda.Event()
+            done.record(st)
+            cur.wait_event(done)
         return self.outputs
 
 
@@ -111,7 +124,7 @@ class GraphedForward:
         # the sequential forms (gf(data), gf.block(...)) capture on ONE private stream, i.e. on one grow-only workspace of the module:
         # their replays are meant for one stream at a time (use submit() for forwards in flight together)
         self._cap_stream = None
-        self._chain_streams = []   # extra capture streams of block(..., chains=S): one workspace each
+        self._chain_streams = []   # streams of block(..., chains=S): one graph and one workspace each
         self._streams = [torch.cuda.Stream() for _ in range(int(streams))] if int(streams) > 1 else []
         self._next_slot = 0
 
@@ -128,48 +141,28 @@ class GraphedForward:
         for k in [k for k, b in self._blocks.items() if b._stamp != stamp]:
             del self._blocks[k]
 
-    def _capture(self, frames, stream=None, chains=1):
-        """Capture model(frame) for every frame of the list on `stream` (default: this object's capture stream): back to back, or --
-        `chains` > 1 -- dealt round robin onto that many PARALLEL branches of the graph (fork after the graph's root, join before its
-        end; branch c runs on its own stream at capture time, hence on its own workspace of the module).
-        Returns (graph, outputs, the module workspaces the graph addresses -- the caller keeps them alive with the graph)."""
+    def _capture(self, frames, stream=None):
+        """Capture model(frame) for every frame of the list, back to back, on `stream` (default: this object's capture stream).
+        Returns (graph, outputs, the module workspace the graph addresses -- the caller keeps it alive with the graph)."""
         m = self.model
         if stream is None:
             if self._cap_stream is None:
                 self._cap_stream = torch.cuda.Stream()
             stream = self._cap_stream
-        chains = max(1, min(int(chains), len(frames)))
-        while len(self._chain_streams) < chains - 1:
-            self._chain_streams.append(torch.cuda.Stream())
-        lanes = [stream] + self._chain_streams[:chains - 1]
         with torch.no_grad():
-            big = max(frames, key=lambda f: (f.edge_index.shape[1], f.x.shape[0]))
-            for st in lanes:                     # every stream's workspace reaches its final size before the capture begins
-                st.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(st):
-                    m(big)
-                    for f in frames:
-                        if f is not big and _key(f) != _key(big):
-                            m(f)
-                torch.cuda.current_stream().wait_stream(st)
+            stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(stream):      # the stream's workspace reaches its final size before the capture begins
+                big = max(frames, key=lambda f: (f.edge_index.shape[1], f.x.shape[0]))
+                m(big)
+                for f in frames:
+                    if f is not big and _key(f) != _key(big):
+                        m(f)
+            torch.cuda.current_stream().wait_stream(stream)
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
-            outs, ws = [None] * len(frames), []
             with torch.cuda.graph(graph, stream=stream):
-                if chains > 1:
-                    fork = torch.cuda.Event()
-                    fork.record(stream)
-                    for st in lanes[1:]:
-                        st.wait_event(fork)
-                for c, st in enumerate(lanes):
-                    with torch.cuda.stream(st):
-                        for i in range(c, len(frames), chains):
-                            outs[i] = m(frames[i])
-                        ws.append(m._hot.workspace)
-                for st in lanes[1:]:
-                    join = torch.cuda.Event()
-                    join.record(st)
-                    stream.wait_event(join)
+                outs = [m(f) for f in frames]
+            ws = m._hot.workspace
         return graph, outs, ws
 
     # -- one frame per call ------------------------------------------------------------------------------------------------------------
@@ -218,9 +211,10 @@ class GraphedForward:
         """Capture (once per sequence of shapes) the forwards of `frames` in one HIP graph.  `adopt_inputs=True`: the given
         tensors ARE the static buffers (they stay resident in HBM and the producer overwrites them in place); otherwise they are
         cloned.  The same object may appear several times (one forward per appearance, each with its own outputs).
-        `chains=S` > 1: the forwards are dealt round robin onto S parallel branches of the graph -- S independent frames in flight,
-        each branch on its own workspace -- instead of one chain in frame order (a frame-sized forward is six dependent launches
-        that leave most of the chip idle)."""
+        `chains=S` > 1: the forwards are dealt round robin onto S graphs, each replayed on its own stream and workspace -- S
+        independent frames in flight instead of one chain in frame order (a frame-sized forward is six dependent launches that
+        leave most of the chip idle; parallel branches inside ONE HIP graph were measured too and barely overlap: 25.8 vs 27.6 us
+        per forward at three branches)."""
         frames = list(frames)
         if not frames:
             raise ValueError("empty block")
@@ -243,8 +237,23 @@ class GraphedForward:
                     if id(f) not in clones:
                         clones[id(f)] = _clone(f)
                     inputs.append(clones[id(f)])
-            graph, outs, ws = self._capture(inputs, chains=chains)
-            blk = self._blocks[key] = GraphedBlock(graph, inputs, outs, stamp, ws)
+            chains = max(1, min(int(chains), len(inputs)))
+            if chains == 1:
+                graph, outs, ws = self._capture(inputs)
+                blk = GraphedBlock([graph], [None], inputs, outs, stamp, [ws])
+            else:   # chain c = frames c, c + S, c + 2 S, ... as one graph on its own stream (its own workspace of the module)
+                while len(self._chain_streams) < chains:
+                    self._chain_streams.append(torch.cuda.Stream())
+                graphs, wss, outs = [], [], [None] * len(inputs)
+                for c in range(chains):
+                    idx = list(range(c, len(inputs), chains))
+                    g, o, ws = self._capture([inputs[i] for i in idx], stream=self._chain_streams[c])
+                    graphs.append(g)
+                    wss.append(ws)
+                    for i, oi in zip(idx, o):
+                        outs[i] = oi
+                blk = GraphedBlock(graphs, self._chain_streams[:chains], inputs, outs, stamp, wss)
+            self._blocks[key] = blk
         return blk
 
     # -- S forwards in flight ------------------------------------------------------------------------------------------------------------

@@ -71,11 +71,11 @@ def test_train_mode_hooks_fire_with_train_mode_latents(prefix, name, engine):
         h.remove()
     L = int(params["num_enc_steps"])
     assert len(seen["enc"]) == 1 and len(seen["mp_out"]) == L and len(seen["cls"]) == len(out["classified_edges"])
-    # same logits and gradients as without hooks, bit for bit (the same kernels ran)
+    # same logits as without hooks, bit for bit (the same kernels ran); same gradients up to the order of the backward's atomic sums
     for s, t in zip(out["classified_edges"], out0["classified_edges"]):
         assert s.requires_grad and torch.equal(s.detach(), t.detach())
     for (k, p), (_, p0) in zip(m.named_parameters(), m0.named_parameters()):
-        assert p.grad is not None and torch.equal(p.grad, p0.grad), k
+        assert p.grad is not None and torch.allclose(p.grad, p0.grad, rtol=1e-4, atol=1e-6 * max(1.0, float(p0.grad.abs().max()))), k
     for (dec, none), o in zip(seen["cls"], out["classified_edges"]):
         assert none is None and dec is o
     # the latents are the train-mode ones of the autograd oracle
