@@ -257,27 +257,49 @@ class GraphedForward:
         return blk
 
     # -- S forwards in flight ------------------------------------------------------------------------------------------------------------
-    def submit(self, data):
-        """Enqueue this frame's forward on the next of the S streams (round robin) and return at once.  Each stream has its own
-        graph, static inputs and workspace per frame shape; the copy into the static inputs and the replay are ordered after the
-        work already on the CURRENT stream (the producer of `data`)."""
+    def slot_inputs(self, data, slot):
+        """The static input buffers of stream `slot` (0 ... S-1) for this frame shape, allocated and captured on first use: write a
+        frame INTO them and `submit` the returned object to replay on that stream without copies."""
         if not self._streams:
-            raise RuntimeError("GraphedForward(model, streams=S) with S > 1 is needed for submit()")
+            raise RuntimeError("GraphedForward(model, streams=S) with S > 1 is needed for slot_inputs()")
         _check(self.model, data)
-        dev = data.x.device
-        stamp = self._stamp(dev)
-        slot = self._next_slot
-        self._next_slot = (slot + 1) % len(self._streams)
-        st = self._streams[slot]
+        return self._slot_entry(data, int(slot) % len(self._streams), self._stamp(data.x.device))[1]
+
+    def _slot_entry(self, data, slot, stamp):
         key = (_key(data), 1 + slot)
         entry = self._graphs.get(key)
         if entry is None or entry[3] != stamp:
             self._drop_stale(stamp)
             static = _clone(data)
-            graph, outs, ws = self._capture([static], stream=st)
+            graph, outs, ws = self._capture([static], stream=self._streams[slot])
             entry = self._graphs[key] = (graph, static, outs[0], stamp, ws)
-        graph, static, outs = entry[:3]
-        st.wait_stream(torch.cuda.current_stream(dev))
+        return entry
+
+    def submit(self, data, after_current=True):
+        """Enqueue this frame's forward on one of the S streams and return at once: the stream whose static inputs `data` IS
+        (`slot_inputs`: no copies), else the next one round robin (the frame is copied into that stream's static inputs).  Each
+        stream has its own graph, static inputs and workspace per frame shape.  `after_current=True` orders the copy and the replay
+        after the work already on the CURRENT stream (the producer of `data`); a producer that writes the slot's inputs on the slot's
+        own stream, or synchronises by itself, passes False and saves the fork (an event record + a stream wait per call).
+        A slot's outputs are reused by its next frame: take `.result()` (or copy) before submitting to the same slot again."""
+        if not self._streams:
+            raise RuntimeError("GraphedForward(model, streams=S) with S > 1 is needed for submit()")
+        _check(self.model, data)
+        dev = data.x.device
+        stamp = self._stamp(dev)
+        slot = None
+        for i in range(len(self._streams)):   # is `data` one of the slots' own static frames?
+            e = self._graphs.get((_key(data), 1 + i))
+            if e is not None and e[1] is data:
+                slot = i
+                break
+        if slot is None:
+            slot = self._next_slot
+            self._next_slot = (slot + 1) % len(self._streams)
+        st = self._streams[slot]
+        graph, static, outs = self._slot_entry(data, slot, stamp)[:3]
+        if after_current:
+            st.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(st):
             _copy_into(static, data)
             graph.replay()

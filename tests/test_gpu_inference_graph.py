@@ -163,6 +163,15 @@ def test_forwards_in_flight_on_several_streams():
         for i, p in enumerate(pend):
             got = [t.clone() for t in p.result()["classified_edges"]]
             assert _eq(got, want[lo + i]), lo + i
+    # frames written into a slot's own static inputs replay on that slot without copies
+    slots = [gf.slot_inputs(frames[0], i) for i in range(3)]
+    assert len({s.x.data_ptr() for s in slots}) == 3
+    for i, s in enumerate(slots):
+        s.x.copy_(frames[i].x), s.edge_attr.copy_(frames[i].edge_attr)
+    torch.cuda.synchronize()
+    pend = [gf.submit(s, after_current=False) for s in slots]
+    for i, p in enumerate(pend):
+        assert _eq(p.result()["classified_edges"], want[i]), i
     with pytest.raises(RuntimeError):
         GraphedForward(m).submit(frames[0])
 

@@ -1,7 +1,7 @@
 """Forward hooks on encoder / MPNet / classifier in TRAIN mode (missing 3): the reference fires them in both modes
 (models/mpn.py:270,288,292 are ordinary nn.Module calls).  MOTMPNet.forward replays the container calls from the latents the
 training forward saved for its backward -- the fused engine's trace, the layer-by-layer engine's tape -- so hooks see TRAIN-mode
-values (BatchNorm with batch statistics, Dropout-free here), the classifier outputs are the autograd-connected logits, and the
+values (BatchNorm with batch statistics, Dropout applied), the classifier outputs are the autograd-connected logits, and the
 gradients are what they are without hooks.  Checked against the autograd oracle's train-mode latents (pinned by the reference's own
 logits / gradients in tests/golden/bwd_*.npz and lw_*.npz)."""
 import numpy as np
@@ -52,12 +52,19 @@ CASES = [("bwd_", "terrace32", "auto"), ("bwd_", "cls_bn_train", "auto"), ("bwd_
 def test_train_mode_hooks_fire_with_train_mode_latents(prefix, name, engine):
     params, arch, sd, grads, after, a = load_bwd(name, prefix)
     labels = torch.from_numpy(np.asarray(a["labels"])).cuda().float()
+    # Dropout (the generic golden has it): both models and the oracle draw the golden's masks
+    seed = int(a["dropout_seed"]) if "dropout_seed" in a else None
+    ps = [float(v) for v in a["dropout_p"]] if "dropout_p" in a else [0.0] * 4
     # without hooks: the reference run
     m0 = build(params, arch, sd, engine)
+    if seed is not None:
+        m0.set_dropout_seed(seed)
     out0 = m0(data_of(a))
     loss_of(out0, labels).backward()
     # with hooks
     m = build(params, arch, sd, engine)
+    if seed is not None:
+        m.set_dropout_seed(seed)
     d = data_of(a)
     seen = {"enc": [], "mp_in": [], "mp_out": [], "cls": []}
     hooks = [m.encoder.register_forward_hook(lambda mod, i, o: seen["enc"].append(o)),
@@ -79,7 +86,8 @@ def test_train_mode_hooks_fire_with_train_mode_latents(prefix, name, engine):
     for (dec, none), o in zip(seen["cls"], out["classified_edges"]):
         assert none is None and dec is o
     # the latents are the train-mode ones of the autograd oracle
-    orc = TapOracle(params, arch, sd)
+    orc = TapOracle(params, arch, sd, dropout=(dict(p_enc=ps[0], p_edge=ps[1], p_node=ps[2], p_cls=ps[3], seed=seed)
+                                               if seed is not None and any(q > 0 for q in ps) else None))
     orc.forward(a["x"], a["edge_index"], a["edge_attr"])
     e_enc, h_enc = seen["enc"][0]                      # (edge_out, node_out): edge first (models/mpn.py:142)
     tol = 2e-5
