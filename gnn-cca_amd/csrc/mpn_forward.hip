@@ -466,11 +466,14 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
     sp.ws_base = base;
     sp.ws_bytes = ws.total;
     sp.so_e = (unsigned)ws.e, sp.so_col = (unsigned)ws.col32, sp.so_perm = (unsigned)ws.perm;
-    // the P_dst gather table staged whole in LDS: graphs of 801 ... 1024 nodes only.  (Rounds 1-2 staged it for every N <= 1024; measured with
-    // a block of 200 forwards in one HIP graph, gathers straight from L2 are ahead below that: dense32 / 64 / 128 / 256 / 384 / 512 / 768
-    // -1.5 / -2 / -1.5 / -1.5 / -4 / -2.7 / -1.3 % per forward, dense1024 (L = 8) +1 %; profiles/r03_logs/r3_pdlds2.log, r3_pdlds3.log)
-    static const int pd_lds_max = diag_env("GNNCCA_PD_LDS_MAX") ? std::atoi(diag_env("GNNCCA_PD_LDS_MAX")) : 1024;   // diagnostics
-    static const int pd_lds_min = diag_env("GNNCCA_PD_LDS_MIN") ? std::atoi(diag_env("GNNCCA_PD_LDS_MIN")) : 801;
+    // The P_dst gather table staged whole in LDS: OFF by default since round 4.  Rounds 1-2 staged it for every N <= 1024; round 3 found
+    // gathers straight from L2 ahead below 801 nodes (dense32 ... dense768 -1.3 ... -4 % per forward, r3_pdlds2.log, r3_pdlds3.log) and
+    // kept it for 801 ... 1024; with four waves per node and the kernels as they are now the table loses there as well -- dense1024,
+    // L = 8 (BASELINE config 5): 120.4 -> 118.3 us per forward with the fp32 edge state, 112.8 -> 110.1 with bf16
+    // (profiles/r04_logs/ab_config5.log; with ONE wave per node the table still wins, 141 vs 151 us, but that form is slower anyway).
+    // The switches keep the variant reachable for A/B runs: GNNCCA_PD_LDS_MIN / _MAX name the node range that stages it.
+    static const int pd_lds_max = diag_env_int("GNNCCA_PD_LDS_MAX", 1024, 0, 1024);   // diagnostics
+    static const int pd_lds_min = diag_env_int("GNNCCA_PD_LDS_MIN", 0x7FFFFFFF, 0, 0x7FFFFFFF);
     sp.pd_lds = (N >= pd_lds_min && N <= pd_lds_max) && d->num_enc_steps > 0;
     sp.e_bf16 = (options & GNNCCA_OPT_EDGE_STATE_BF16) != 0;  // honoured by the specialised kernels only
     sp.ell_S = use_ell ? ws.ell_S : 0;

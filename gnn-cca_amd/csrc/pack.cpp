@@ -577,7 +577,7 @@ GenWorkspace carve_generic(const gnncca_mpn_dims* d, int64_t n, int64_t e) {
 // The diagnostic switches this build reads.  With the gate open, a GNNCCA_* variable that is NOT in this list is
 // reported once on stderr: a stale A/B script then says so in its log instead of comparing a build with itself.
 static const char* const kDiagSwitches[] = {
-    "GNNCCA_DIAG", "GNNCCA_LIB", "GNNCCA_STEP_R2", "GNNCCA_STEP_NOMEM", "GNNCCA_STEP_NOEPI", "GNNCCA_STEP_NOHOOK", "GNNCCA_STEP_EARLYBAR",
+    "GNNCCA_DIAG", "GNNCCA_LIB", "GNNCCA_STAMPS", "GNNCCA_STEP_R2", "GNNCCA_STEP_NOMEM", "GNNCCA_STEP_NOEPI", "GNNCCA_STEP_NOHOOK", "GNNCCA_STEP_EARLYBAR",
     "GNNCCA_STEP_NORANGE", "GNNCCA_RANGE_MAX_E", "GNNCCA_PD_LDS_MIN", "GNNCCA_PD_LDS_MAX", "GNNCCA_TAIL_NPW", "GNNCCA_WPS", "GNNCCA_NO_NT", "GNNCCA_NO_PAD",
     "GNNCCA_GEMM_DIRECT", "GNNCCA_GEMM_SPLIT_MIN", "GNNCCA_GEMM_LDS_MIN", "GNNCCA_GEMM_NOPIPE", "GNNCCA_NO_FUSE", "GNNCCA_NO_MFMA_TAIL",
     "GNNCCA_TAIL_MFMA_MIN", "GNNCCA_NO_RIDE", "GNNCCA_GEMM_DIRECT_WG", "GNNCCA_GEMM_R32_NST"};

@@ -22,6 +22,7 @@ for spec in sys.argv[1:]:
     L = int(l) if l else 4
     params = bench.graph_net_params(L=L)
     model = bench.build_model(copy.deepcopy(params), n).to(dev)
+    model.edge_state_dtype = 'bf16' if os.environ.get('AB_BF16') else 'fp32'
     data = bench.make_data(n, g, 1, dev)
     E = data.edge_index.shape[1]
     K = 50 if E < 3e6 else 10
@@ -58,6 +59,6 @@ for spec in sys.argv[1:]:
     for on in (True, False):
         r = res[on]
         ks = " ".join(f"{k}={np.median(v):.1f}" for k, v in r["k"].items())
-        print(f"[{tag}] {spec:10s} ranges={'on ' if on else 'off'} fwd(us)={' '.join(f'{t:.2f}' for t in r['fwd'])}  | {ks}", flush=True)
+        print(f"[{tag}{' bf16' if os.environ.get('AB_BF16') else ''}] {spec:10s} ranges={'on ' if on else 'off'} fwd(us)={' '.join(f'{t:.2f}' for t in r['fwd'])}  | {ks}", flush=True)
     del model, data
     torch.cuda.empty_cache()
