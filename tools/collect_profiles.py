@@ -39,7 +39,8 @@ def run(tag, sub, extra, bench_args):
 
 def main():
     tag = sys.argv[1]
-    bench_args = sys.argv[sys.argv.index("--") + 1:] + ["--no-cpu-baseline", "--no-scale-probe", "--no-config4", "--profile-reps", "0"]
+    trace_only = "--trace-only" in sys.argv[2:sys.argv.index("--")]   # kernel-trace + stats only (e.g. the HIP-graph block form of the headline)
+    bench_args = sys.argv[sys.argv.index("--") + 1:] + ["--no-cpu-baseline", "--no-scale-probe", "--no-config4", "--no-terrace", "--streams", "0", "--profile-reps", "0"]
     summary = {"command": "python3 bench.py " + " ".join(bench_args), "kernels": {}}
     d = run(tag, "trace", ["--kernel-trace", "--stats"], bench_args)
     stats = glob.glob(os.path.join(d, "*", "*kernel_stats.csv"))
@@ -57,7 +58,7 @@ def main():
                "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU"],
               ["SQ_INSTS_MFMA", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_SALU", "SQ_INSTS_LDS",
                "SQ_WAIT_INST_LDS", "GRBM_GUI_ACTIVE"]]
-    for gi, grp in enumerate(groups):
+    for gi, grp in enumerate([] if trace_only else groups):
         d = run(tag, "pmc%d" % gi, ["--pmc"] + grp, bench_args)
         acc = {}
         for f in glob.glob(os.path.join(d, "*", "*counter_collection.csv")):

@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def main():
     kern, groups = sys.argv[1], [g.split(",") for g in sys.argv[2].split(";")]
-    bench_args = sys.argv[sys.argv.index("--") + 1:] + ["--no-cpu-baseline", "--no-scale-probe", "--no-config4", "--profile-reps", "0", "--mode", "eager",
+    bench_args = sys.argv[sys.argv.index("--") + 1:] + ["--no-cpu-baseline", "--no-scale-probe", "--no-config4", "--no-terrace", "--streams", "0", "--profile-reps", "0", "--mode", "eager",
                                                          "--steps", "30", "--warmup", "5"]
     res = {}
     for gi, grp in enumerate(groups):
@@ -31,11 +31,12 @@ def main():
             proc = subprocess.Popen(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=log, stderr=subprocess.STDOUT,
                                     start_new_session=True)
             try:
-                proc.wait(timeout=150)
+                proc.wait(timeout=int(os.environ.get('PMC_PASS_TIMEOUT', '150')))
             except subprocess.TimeoutExpired:
                 os.killpg(proc.pid, signal.SIGKILL)
                 proc.wait()
-                print(f"group {gi} killed after 150 s: {grp}", flush=True)
+                print(f"group {gi} killed at its limit: {grp}; last lines of rocprofv3's output:", flush=True)
+                print("".join(open(os.path.join(out, "run.log"), errors="replace").readlines()[-12:]), flush=True)
                 continue
         for f in glob.glob(os.path.join(out, "*", "*counter_collection.csv")):
             acc = {}
