@@ -211,6 +211,10 @@ static int forward_generic(const gnncca_mpn_dims* d, const void* packed_dev, con
     const GenSeg none = {nullptr, nullptr, 0, 0};
     const long long* ei = reinterpret_cast<const long long*>(edge_index);
 
+    // the fused form of the message-passing steps: one launch per step (generic_fused.cuh) when every width fits its per-thread LDS budget
+    int fT = 0, fW = 0;
+    static const bool gen_unfused = diag_env("GNNCCA_GEN_UNFUSED") != nullptr;   // diagnostics: A/B against the op-by-op path
+    const bool use_fused = !gen_unfused && gen_fused_ok(d, &fT, &fW);
     // graph plan (same kernels as the MFMA family: plan blocks, then one finishing workgroup)
     if (E > 0) {
         EncPlanParams ep;
@@ -223,8 +227,10 @@ static int forward_generic(const gnncca_mpn_dims* d, const void* packed_dev, con
         ep.N = N;
         hipLaunchKernelGGL(plan_only_kernel, dim3(plan_num_blocks(E)), dim3(256), 0, st, ep);
         HIP_TRY(hipGetLastError());
-        hipLaunchKernelGGL(gen_index32_kernel, dim3((E + 255) / 256), dim3(256), 0, st, ei, E, N, row32o, col32o);
-        HIP_TRY(hipGetLastError());
+        if (!use_fused) {   // the op-by-op path gathers by the caller's edge order
+            hipLaunchKernelGGL(gen_index32_kernel, dim3((E + 255) / 256), dim3(256), 0, st, ei, E, N, row32o, col32o);
+            HIP_TRY(hipGetLastError());
+        }
     }
     hipLaunchKernelGGL(gen_plan_finish_kernel, dim3(1), dim3(256), 0, st, ei, E, N, seg_ptr, col32, perm, cursor, flags,
                        (const unsigned*)blockflags);
@@ -301,6 +307,61 @@ static int forward_generic(const gnncca_mpn_dims* d, const void* packed_dev, con
         return hipGetLastError() == hipSuccess ? GNNCCA_OK : GNNCCA_ERR_HIP;
     };
     if (L == 0) return classify_edges(e0, EF);
+    // ---- the fused form: one launch per step (generic_fused.cuh) when every width fits its per-thread LDS budget -----------------------
+    if (use_fused) {
+        GenStepParams gp;
+        std::memset(&gp, 0, sizeof(gp));
+        gp.blob = blob;
+        gp.seg_ptr = seg_ptr, gp.col32 = col32, gp.perm = perm, gp.flags = flags;
+        gp.N = N, gp.E = E;
+        gen_fill_mlp(&gp.edge, d->edge_mlp, hdr.w[2], hdr.b[2]);
+        gen_fill_mlp(&gp.node, d->node_mlp, hdr.w[3], hdr.b[3]);
+        gen_fill_mlp(&gp.cls, d->cls_edge, hdr.w[4], hdr.b[4]);
+        gp.H = H, gp.EF = EF, gp.agg = d->agg;
+        gp.hin_w = d->reattach_nodes ? 2 * H : H;
+        gp.h0 = d->reattach_nodes ? h0 : nullptr;
+        gp.o1e = d->edge_mlp.layers[0].out_dim, gp.o1n = d->node_mlp.layers[0].out_dim;
+        gp.tab_ld = 2 * gp.o1e + gp.o1n;
+        gp.k0_edge = 2 * gp.hin_w, gp.k0_node = gp.hin_w;
+        gp.lds_stride = fT + 1;
+        gp.wmax = fW;
+        const int parts = std::max(1, fT / std::max(H, 1));
+        const size_t lds = ((size_t)2 * fW * (fT + 1) + gp.hin_w + (size_t)parts * H) * sizeof(float);
+        if (lds > 64 * 1024)
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gen_step_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        float* tab[2] = {reinterpret_cast<float*>(base + ws.tab[0]), reinterpret_cast<float*>(base + ws.tab[1])};
+        // step 1's tables from the encoder's node features
+        gp.tab_out = tab[0];
+        hipLaunchKernelGGL(gen_project_kernel, dim3((unsigned)N), dim3(256), (size_t)gp.hin_w * sizeof(float), st, gp, (const float*)h0);
+        HIP_TRY(hipGetLastError());
+        for (int step = 1; step <= L; ++step) {
+            float* e_new = eb[2 + (step & 1)];
+            const bool need_h = step < L || (trace && trace->h_steps);
+            float* hn = h_lat[step & 1];
+            if (d->reattach_edges) {
+                gp.e_a = e0, gp.e_a_ld = EF, gp.e_a_w = EF;
+                gp.e_b = e_cur, gp.e_b_ld = e_ld, gp.e_b_w = EF;
+            } else {
+                gp.e_a = e_cur, gp.e_a_ld = e_ld, gp.e_a_w = EF;
+                gp.e_b = nullptr, gp.e_b_ld = 0, gp.e_b_w = 0;
+            }
+            gp.tab_in = tab[(step - 1) & 1];
+            gp.tab_out = step < L ? tab[step & 1] : nullptr;
+            gp.e_new = e_new, gp.e_new_ld = ew;
+            gp.logits = step >= first_cls ? logits_out + (size_t)(out_idx++) * E : nullptr;
+            gp.h_new = need_h ? hn : nullptr;
+            hipLaunchKernelGGL(gen_step_fused_kernel, dim3((unsigned)N), dim3((unsigned)fT), lds, st, gp);
+            HIP_TRY(hipGetLastError());
+            e_cur = e_new;
+            e_ld = ew;
+            if (trace && trace->e_steps)
+                HIP_TRY(hipMemcpy2DAsync(trace->e_steps + (size_t)(step - 1) * E * EF, (size_t)EF * 4, e_new, (size_t)ew * 4,
+                                         (size_t)EF * 4, E, hipMemcpyDeviceToDevice, st));
+            if (need_h && trace && trace->h_steps)
+                HIP_TRY(hipMemcpyAsync(trace->h_steps + (size_t)(step - 1) * N * H, hn, (size_t)N * H * 4, hipMemcpyDeviceToDevice, st));
+        }
+        return GNNCCA_OK;
+    }
     for (int step = 1; step <= L; ++step) {
         float* e_new = eb[2 + (step & 1)];        // this step's latent edge features
         float* msg = eb[2 + ((step + 1) & 1)];    // this step's per-edge messages (the previous latent is dead by then)

@@ -110,7 +110,7 @@ const gnncca_mlp& mlp_by_index(const gnncca_mpn_dims* d, int i);
 
 struct GenWorkspace {
     size_t flags, blockflags, seg_ptr, col32, perm, cursor, row32o, col32o;
-    size_t node[3], h0, edge[4], e0, partial, total;
+    size_t node[3], h0, edge[4], e0, partial, tab[2], total;   // tab: per-node projection tables of the fused step (generic_fused.cuh)
     int64_t node_w, edge_w;  // floats per row of the node / edge scratch buffers
 };
 GenWorkspace carve_generic(const gnncca_mpn_dims* d, int64_t n, int64_t e);

@@ -27,6 +27,7 @@
 #include "step_general.cuh"
 #include "step_fast.cuh"
 #include "step_pipe.cuh"
+#include "generic_fused.cuh"
 #include "generic.cuh"
 #include "postprocess.cuh"
 #include "backward.cuh"

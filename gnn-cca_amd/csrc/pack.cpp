@@ -570,6 +570,11 @@ GenWorkspace carve_generic(const gnncca_mpn_dims* d, int64_t n, int64_t e) {
     w.e0 = take(E * (size_t)d->edge_dim * 4);
     const int ks = gen_enc0_ksplit(d, n);
     w.partial = take(ks > 0 ? (size_t)ks * N * (size_t)d->enc_node.layers[0].out_dim * 4 : 0);
+    {   // [N][2 * o1e + o1n]: P_src | P_dst | Q of the fused step kernel, ping-pong
+        const size_t o1e = d->edge_mlp.n_layers > 0 ? (size_t)d->edge_mlp.layers[0].out_dim : 0;
+        const size_t o1n = d->node_mlp.n_layers > 0 ? (size_t)d->node_mlp.layers[0].out_dim : 0;
+        for (int i = 0; i < 2; ++i) w.tab[i] = take(N * (2 * o1e + o1n) * 4);
+    }
     w.total = off;
     return w;
 }
@@ -580,7 +585,7 @@ static const char* const kDiagSwitches[] = {
     "GNNCCA_DIAG", "GNNCCA_LIB", "GNNCCA_STAMPS", "GNNCCA_STEP_R2", "GNNCCA_STEP_NOMEM", "GNNCCA_STEP_NOEPI", "GNNCCA_STEP_NOHOOK", "GNNCCA_STEP_EARLYBAR",
     "GNNCCA_STEP_NORANGE", "GNNCCA_RANGE_MAX_E", "GNNCCA_PD_LDS_MIN", "GNNCCA_PD_LDS_MAX", "GNNCCA_TAIL_NPW", "GNNCCA_WPS", "GNNCCA_NO_NT", "GNNCCA_NO_PAD",
     "GNNCCA_GEMM_DIRECT", "GNNCCA_GEMM_SPLIT_MIN", "GNNCCA_GEMM_LDS_MIN", "GNNCCA_GEMM_NOPIPE", "GNNCCA_NO_FUSE", "GNNCCA_NO_MFMA_TAIL",
-    "GNNCCA_TAIL_MFMA_MIN", "GNNCCA_NO_RIDE", "GNNCCA_GEMM_DIRECT_WG", "GNNCCA_GEMM_R32_NST"};
+    "GNNCCA_TAIL_MFMA_MIN", "GNNCCA_NO_RIDE", "GNNCCA_GEMM_DIRECT_WG", "GNNCCA_GEMM_R32_NST", "GNNCCA_GEN_UNFUSED"};
 
 extern "C" char** environ;
 
