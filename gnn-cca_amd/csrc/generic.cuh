@@ -214,7 +214,7 @@ static int forward_generic(const gnncca_mpn_dims* d, const void* packed_dev, con
     // the fused form of the message-passing steps: one launch per step (generic_fused.cuh) when every width fits its per-thread LDS budget
     int fT = 0, fW = 0;
     static const bool gen_unfused = diag_env("GNNCCA_GEN_UNFUSED") != nullptr;   // diagnostics: A/B against the op-by-op path
-    const bool use_fused = !gen_unfused && gen_fused_ok(d, &fT, &fW);
+    const bool use_fused = !gen_unfused && gen_fused_ok(d, n_nodes, &fT, &fW);
     // graph plan (same kernels as the MFMA family: plan blocks, then one finishing workgroup)
     if (E > 0) {
         EncPlanParams ep;
@@ -232,14 +232,73 @@ static int forward_generic(const gnncca_mpn_dims* d, const void* packed_dev, con
             HIP_TRY(hipGetLastError());
         }
     }
-    hipLaunchKernelGGL(gen_plan_finish_kernel, dim3(1), dim3(256), 0, st, ei, E, N, seg_ptr, col32, perm, cursor, flags,
-                       (const unsigned*)blockflags);
-    HIP_TRY(hipGetLastError());
+    if (!use_fused) {   // (the fused form folds the plan's findings in its encoder-tail launch)
+        hipLaunchKernelGGL(gen_plan_finish_kernel, dim3(1), dim3(256), 0, st, ei, E, N, seg_ptr, col32, perm, cursor, flags,
+                           (const unsigned*)blockflags);
+        HIP_TRY(hipGetLastError());
+    }
 
     // encoder (models/mpn.py:270): node MLP on x, edge MLP on edge_attr
     int s;
     const int ks0 = gen_enc0_ksplit(d, n_nodes);
-    if (d->enc_node.n_layers > 0 && ks0 > 0) {
+    GenStepParams gp;   // the fused form's per-step parameters (the part that does not change from step to step)
+    std::memset(&gp, 0, sizeof(gp));
+    float* tab[2] = {reinterpret_cast<float*>(base + ws.tab[0]), reinterpret_cast<float*>(base + ws.tab[1])};
+    if (use_fused) {
+        gp.blob = blob;
+        gp.seg_ptr = seg_ptr, gp.col32 = col32, gp.perm = perm, gp.flags = flags;
+        gp.N = N, gp.E = E;
+        gp.H = H, gp.EF = EF, gp.agg = d->agg;
+        gp.hin_w = d->reattach_nodes ? 2 * H : H;
+        int wfl = 0;
+        gen_fill_mlp(&gp.edge, d->edge_mlp, hdr.w[2], hdr.b[2], 2 * gp.hin_w, (d->reattach_edges ? 2 : 1) * EF, &wfl);   // the e block of cat[x[row] | x[col] | e]
+        gen_fill_mlp(&gp.node, d->node_mlp, hdr.w[3], hdr.b[3], gp.hin_w, EF, &wfl);                                  // the e' block of cat[x[row] | e']
+        gen_fill_mlp(&gp.cls, d->cls_edge, hdr.w[4], hdr.b[4], -1, 0, &wfl);
+        gp.w_floats = (wfl + 3) / 4 * 4;
+        gp.h0 = d->reattach_nodes ? h0 : nullptr;
+        gp.o1e = d->edge_mlp.layers[0].out_dim, gp.o1n = d->node_mlp.layers[0].out_dim;
+        gp.tab_ld = 2 * gp.o1e + gp.o1n;
+        gp.lds_stride = fT + 1;
+        gp.wmax = fW;
+        gp.tab_out = tab[0];
+        // encoder.node_mlp: the wide first layer on the MFMA family's split-K fp32 GEMM when it pays, everything behind it -- slab sum,
+        // further layers, h0, step 1's projection tables, the plan's flag fold -- in ONE launch (gen_node_tail_kernel)
+        GenTailParams tq;
+        std::memset(&tq, 0, sizeof(tq));
+        int dummy = 0;
+        gen_fill_mlp(&tq.enc, d->enc_node, hdr.w[0], hdr.b[0], -1, 0, &dummy);
+        tq.x = x, tq.node_in = d->node_in;
+        tq.h0 = h0, tq.trace_h = trace ? trace->h_enc : nullptr;
+        tq.ei = ei, tq.seg_ptr = seg_ptr, tq.col32 = col32, tq.perm = perm, tq.cursor = cursor, tq.flags = flags, tq.blockflags = blockflags, tq.E = E;
+        int wenc = std::max(std::max(gp.hin_w, H), 1024);   // (plan_finish wants 3 KB of scratch)
+        for (int l = 0; l < d->enc_node.n_layers; ++l) wenc = std::max(wenc, (int)d->enc_node.layers[l].out_dim);
+        if (d->enc_node.n_layers > 0 && ks0 > 0) {
+            const gnncca_layer& l0 = d->enc_node.layers[0];
+            float* part = reinterpret_cast<float*>(base + ws.partial);
+            int kslice = (l0.in_dim + ks0 - 1) / ks0;
+            kslice = (kslice + 63) / 64 * 64;
+            EncPlanParams ep;
+            std::memset(&ep, 0, sizeof(ep));
+            ep.in = x, ep.W = blob + hdr.enc0_rowmajor, ep.part = part;
+            ep.M = N, ep.K = l0.in_dim, ep.O = l0.out_dim, ep.kslice = kslice;
+            ep.vec_ok = (l0.in_dim % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+            ep.nrt = (N + 31) / 32;
+            ep.nks = ks0;
+            ep.gemm_blocks = ep.nrt * ks0 * ((l0.out_dim + 127) / 128);
+            hipLaunchKernelGGL(enc_gemm_plan_kernel, dim3(ep.gemm_blocks), dim3(256), 0, st, ep);
+            HIP_TRY(hipGetLastError());
+            tq.part = part, tq.ks = ks0, tq.first_layer = 1;
+        } else {
+            tq.part = nullptr, tq.ks = 0, tq.first_layer = 0;
+            wenc = std::max(wenc, d->node_in);
+        }
+        tq.wmax_enc = wenc;
+        const size_t tl = (size_t)2 * wenc * sizeof(float);
+        if (tl > 64 * 1024)
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gen_node_tail_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tl));
+        hipLaunchKernelGGL(gen_node_tail_kernel, dim3((unsigned)N + 1), dim3(256), tl, st, gp, tq);
+        HIP_TRY(hipGetLastError());
+    } else if (d->enc_node.n_layers > 0 && ks0 > 0) {
         // first layer (the wide one: 2048-d embeddings) on the MFMA family's split-K fp32 GEMM + its reduce kernel,
         // the remaining layers on the tiled dense kernel
         const gnncca_layer& l0 = d->enc_node.layers[0];
@@ -281,7 +340,7 @@ static int forward_generic(const gnncca_mpn_dims* d, const void* packed_dev, con
     } else {
         HIP_TRY(hipMemcpyAsync(h0, x, (size_t)N * H * sizeof(float), hipMemcpyDeviceToDevice, st));
     }
-    if (trace && trace->h_enc) HIP_TRY(hipMemcpyAsync(trace->h_enc, h0, (size_t)N * H * 4, hipMemcpyDeviceToDevice, st));
+    if (!use_fused && trace && trace->h_enc) HIP_TRY(hipMemcpyAsync(trace->h_enc, h0, (size_t)N * H * 4, hipMemcpyDeviceToDevice, st));
     if (E == 0) return GNNCCA_OK;
     if (d->enc_edge.n_layers > 0) {
         s = gen_run_mlp(d->enc_edge, blob, hdr.w[1], hdr.b[1], GenSeg{edge_attr, nullptr, d->edge_in, d->edge_in}, none, none, E,
@@ -309,31 +368,10 @@ static int forward_generic(const gnncca_mpn_dims* d, const void* packed_dev, con
     if (L == 0) return classify_edges(e0, EF);
     // ---- the fused form: one launch per step (generic_fused.cuh) when every width fits its per-thread LDS budget -----------------------
     if (use_fused) {
-        GenStepParams gp;
-        std::memset(&gp, 0, sizeof(gp));
-        gp.blob = blob;
-        gp.seg_ptr = seg_ptr, gp.col32 = col32, gp.perm = perm, gp.flags = flags;
-        gp.N = N, gp.E = E;
-        gen_fill_mlp(&gp.edge, d->edge_mlp, hdr.w[2], hdr.b[2]);
-        gen_fill_mlp(&gp.node, d->node_mlp, hdr.w[3], hdr.b[3]);
-        gen_fill_mlp(&gp.cls, d->cls_edge, hdr.w[4], hdr.b[4]);
-        gp.H = H, gp.EF = EF, gp.agg = d->agg;
-        gp.hin_w = d->reattach_nodes ? 2 * H : H;
-        gp.h0 = d->reattach_nodes ? h0 : nullptr;
-        gp.o1e = d->edge_mlp.layers[0].out_dim, gp.o1n = d->node_mlp.layers[0].out_dim;
-        gp.tab_ld = 2 * gp.o1e + gp.o1n;
-        gp.k0_edge = 2 * gp.hin_w, gp.k0_node = gp.hin_w;
-        gp.lds_stride = fT + 1;
-        gp.wmax = fW;
         const int parts = std::max(1, fT / std::max(H, 1));
-        const size_t lds = ((size_t)2 * fW * (fT + 1) + gp.hin_w + (size_t)parts * H) * sizeof(float);
+        const size_t lds = ((size_t)2 * fW * (fT + 1) + gp.w_floats + (gp.tab_ld + 3) / 4 * 4 + gp.hin_w + (size_t)parts * H) * sizeof(float);
         if (lds > 64 * 1024)
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gen_step_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        float* tab[2] = {reinterpret_cast<float*>(base + ws.tab[0]), reinterpret_cast<float*>(base + ws.tab[1])};
-        // step 1's tables from the encoder's node features
-        gp.tab_out = tab[0];
-        hipLaunchKernelGGL(gen_project_kernel, dim3((unsigned)N), dim3(256), (size_t)gp.hin_w * sizeof(float), st, gp, (const float*)h0);
-        HIP_TRY(hipGetLastError());
         for (int step = 1; step <= L; ++step) {
             float* e_new = eb[2 + (step & 1)];
             const bool need_h = step < L || (trace && trace->h_steps);

@@ -24,6 +24,8 @@ namespace gnncca {
 // ============================================================================================================
 struct GenLayerDesc {
     int woff, boff, in, out, op, relu;   // Wt at blob + woff: [in][op]; b at blob + boff: [op]
+    int k0, kn;                          // the rows of Wt this kernel uses per edge (first layers of the edge / node MLP: the e block only)
+    int lw, lb;                          // where the workgroup stages them in LDS (float offsets into s_w): [kn][op] weights, [op] bias
 };
 struct GenMlpDesc {
     int n;
@@ -52,26 +54,55 @@ struct GenStepParams {
     int H, EF, hin_w, agg;
     int lds_stride;         // T + 1
     int wmax;               // widest activation vector a thread keeps in LDS (gen_fused_ok)
+    int w_floats;           // LDS floats of the staged weights and biases (all layers of the three MLPs)
 };
 
-// one dense layer on the tile: s_out[o][t] = act(init(o) + sum_k Wt[k0 + k][o] * s_in[k][t]), four outputs per pass
+// one dense layer on the tile: s_out[o][t] = act(init(o) + sum_k W[k][o] * s_in[k][t]), four outputs per pass; the layer's weights were
+// staged in LDS by the workgroup (s_w + L.lw: [kn][op]) and are read as 16-byte broadcasts -- straight from the blob every pass was a
+// dependent L2 round trip per (k, four outputs): 38 us per step at node latent 64 where this form takes a few
 template <typename Init>
-__device__ __forceinline__ void gen_layer_lds(const float* __restrict__ blob, const GenLayerDesc& L, int k0, int K, const float* s_in,
-                                              float* s_out, int TS, int t, Init init) {
-    const float* __restrict__ Wt = blob + L.woff + (size_t)k0 * L.op;
-    for (int o0 = 0; o0 < L.out; o0 += 4) {
+__device__ __forceinline__ void gen_layer_lds(const float* s_w, const GenLayerDesc& L, const float* s_in, float* s_out, int TS, int t, Init init) {
+    const float* Wl = s_w + L.lw;
+    const int K = L.kn, op = L.op, O = L.out;
+    const bool relu = L.relu != 0;
+    if (K <= 16) {
+        // short inputs (the e block of a first layer: <= 16 columns): the thread's inputs in registers, EIGHT outputs per pass --
+        // per pass K x (two 16-byte weight broadcasts + 8 FMAs) and no activation reads at all
+        float xr[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) xr[q] = q < K ? s_in[q * TS + t] : 0.f;
+        for (int o0 = 0; o0 < O; o0 += 8) {   // op is a multiple of 8: the padded weight columns are zeros
+            float acc[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = init(o0 + j);
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                if (k < K) {
+                    const f32x4 w0 = *reinterpret_cast<const f32x4*>(Wl + k * op + o0);
+                    const f32x4 w1 = *reinterpret_cast<const f32x4*>(Wl + k * op + o0 + 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[j] = fmaf(w0[j], xr[k], acc[j]), acc[4 + j] = fmaf(w1[j], xr[k], acc[4 + j]);
+                }
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (o0 + j < O) s_out[(o0 + j) * TS + t] = relu ? fmaxf(acc[j], 0.f) : acc[j];
+        }
+        return;
+    }
+    for (int o0 = 0; o0 < O; o0 += 4) {
         float acc[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[j] = init(o0 + j);
+#pragma unroll 4
         for (int k = 0; k < K; ++k) {
             const float x = s_in[k * TS + t];
-            const f32x4 w = *reinterpret_cast<const f32x4*>(Wt + (size_t)k * L.op + o0);   // wave-uniform address; op is a multiple of 8
+            const f32x4 w = *reinterpret_cast<const f32x4*>(Wl + k * op + o0);   // wave-uniform address: a broadcast; op is a multiple of 8
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[j] = fmaf(w[j], x, acc[j]);
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            if (o0 + j < L.out) s_out[(o0 + j) * TS + t] = L.relu ? fmaxf(acc[j], 0.f) : acc[j];
+            if (o0 + j < O) s_out[(o0 + j) * TS + t] = relu ? fmaxf(acc[j], 0.f) : acc[j];
     }
 }
 
@@ -92,7 +123,17 @@ __device__ __forceinline__ void gen_project_node(const GenStepParams& p, const f
         } else {                         // Q = W_n[:, 0:hin] hin + b_n
             o = s - 2 * p.o1e, op = Ln.op, Wt = p.blob + Ln.woff, acc = p.blob[Ln.boff + o];
         }
-        for (int k = 0; k < p.hin_w; ++k) acc = fmaf(Wt[(size_t)k * op + o], s_hin[k], acc);
+        // (sixteen weight loads in flight per batch: one load per iteration behind the FMA chain was a dependent L2 round trip per k --
+        // 64 of them at node latent 64, most of a step launch's time)
+        int k = 0;
+        for (; k + 16 <= p.hin_w; k += 16) {
+            float w[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) w[u] = Wt[(size_t)(k + u) * op + o];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) acc = fmaf(w[u], s_hin[k + u], acc);
+        }
+        for (; k < p.hin_w; ++k) acc = fmaf(Wt[(size_t)k * op + o], s_hin[k], acc);
         dst[s] = acc;
     }
 }
@@ -107,6 +148,92 @@ __global__ __launch_bounds__(256) void gen_project_kernel(const GenStepParams p,
     gen_project_node(p, smem, node);
 }
 
+// The node side of the encoder behind the first-layer GEMM, the step-1 projection tables and the plan's flag fold in ONE launch
+// (rounds 1-3: reduce_bias_act_kernel, one gen_dense_kernel per further layer, gen_plan_finish_kernel; round 4's first fused form added
+// gen_project_kernel): workgroup = one node -- split-K slab sum + bias + ReLU (or the raw feature row when the first layer did not go
+// through the GEMM), the remaining encoder layers with a thread per output, h0 to HBM, then gen_project_node; the LAST workgroup of the
+// launch folds the plan's per-block findings and repairs an unsorted plan (plan_finish), as the MFMA family's tails do.
+struct GenTailParams {
+    const float* x;          // [N][node_in]
+    const float* part;       // [ks][N][O0] split-K partials of the first layer, or null: start from x with layer 0
+    int ks, first_layer;     // first_layer: index of the first encoder layer this kernel computes (1 behind the GEMM, else 0)
+    GenMlpDesc enc;          // encoder.node_mlp, all layers
+    int node_in, wmax_enc;   // widest vector of the chain (LDS ping-pong buffers)
+    float* h0;               // [N][H]
+    float* trace_h;          // or null
+    const long long* ei;     // plan_finish
+    int* seg_ptr;
+    int* col32;
+    int* perm;
+    int* cursor;
+    unsigned* flags;
+    const unsigned* blockflags;
+    int E;
+};
+__global__ __launch_bounds__(256) void gen_node_tail_kernel(const GenStepParams p, const GenTailParams q) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int t = threadIdx.x;
+    if ((int)blockIdx.x == p.N) {   // the plan workgroup
+        plan_finish(q.ei, q.E, p.N, q.seg_ptr, q.col32, q.perm, q.cursor, q.flags, q.blockflags, reinterpret_cast<unsigned*>(smem));
+        return;
+    }
+    const int node = blockIdx.x;
+    float* a = smem;
+    float* b = smem + q.wmax_enc;
+    int w;
+    if (q.part) {   // slab sum in slab order + bias + activation of the GEMM's layer
+        const GenLayerDesc& L0 = q.enc.l[0];
+        w = L0.out;
+        for (int o = t; o < w; o += 256) {
+            float v = p.blob[L0.boff + o];
+            int s = 0;
+            for (; s + 8 <= q.ks; s += 8) {   // eight slabs in flight, summed in slab order
+                float pv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) pv[u] = q.part[((size_t)(s + u) * p.N + node) * w + o];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v += pv[u];
+            }
+            for (; s < q.ks; ++s) v += q.part[((size_t)s * p.N + node) * w + o];
+            a[o] = L0.relu ? fmaxf(v, 0.f) : v;
+        }
+    } else {
+        w = q.node_in;
+        for (int k = t; k < w; k += 256) a[k] = q.x[(size_t)node * w + k];
+    }
+    __syncthreads();
+    for (int l = q.first_layer; l < q.enc.n; ++l) {
+        const GenLayerDesc& L = q.enc.l[l];
+        const float* __restrict__ Wt = p.blob + L.woff;
+        for (int o = t; o < L.out; o += 256) {
+            float acc = p.blob[L.boff + o];
+            int k = 0;
+            for (; k + 16 <= w; k += 16) {   // sixteen weight loads in flight per batch (see gen_project_node)
+                float wv[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) wv[u] = Wt[(size_t)(k + u) * L.op + o];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) acc = fmaf(wv[u], a[k + u], acc);
+            }
+            for (; k < w; ++k) acc = fmaf(Wt[(size_t)k * L.op + o], a[k], acc);
+            b[o] = L.relu ? fmaxf(acc, 0.f) : acc;
+        }
+        __syncthreads();
+        float* tmp = a;
+        a = b, b = tmp;
+        w = L.out;
+    }
+    // a = the encoder's node output [H] (w == H)
+    for (int c = t; c < p.H; c += 256) {
+        q.h0[(size_t)node * p.H + c] = a[c];
+        if (q.trace_h) q.trace_h[(size_t)node * p.H + c] = a[c];
+    }
+    float* s_hin = b;   // (wmax_enc >= hin_w: the host sizes it so)
+    for (int k = t; k < p.hin_w; k += 256) s_hin[k] = a[k < p.H ? k : k - p.H];   // before step 1 initial == latent (mpn.py:271-285)
+    __syncthreads();
+    gen_project_node(p, s_hin, node);
+}
+
 __global__ __launch_bounds__(256) void gen_step_fused_kernel(const GenStepParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int T = blockDim.x, TS = p.lds_stride, t = threadIdx.x;
@@ -115,7 +242,9 @@ __global__ __launch_bounds__(256) void gen_step_fused_kernel(const GenStepParams
     const int wmax = p.wmax;
     float* s_a = smem;
     float* s_b = s_a + (size_t)wmax * TS;
-    float* s_x = s_b + (size_t)wmax * TS;       // [hin_w] then [parts][H]
+    float* s_w = s_b + (size_t)wmax * TS;       // staged weights and biases of every layer used per edge
+    float* s_tab = s_w + p.w_floats;            // this node's row of the projection table: P_src | P_dst | Q
+    float* s_x = s_tab + (p.tab_ld + 3) / 4 * 4;   // [hin_w] then [parts][H]
     const unsigned fl = p.flags[0];
     if (fl & GNNCCA_GRAPH_BAD_INDEX) {   // the plan is not trustworthy: poison what this workgroup would have written, touch nothing else
         if (p.logits)
@@ -126,7 +255,22 @@ __global__ __launch_bounds__(256) void gen_step_fused_kernel(const GenStepParams
     }
     const bool unsorted = (fl & GNNCCA_GRAPH_UNSORTED) != 0;
     const int seg_s = p.seg_ptr[node], seg_t = p.seg_ptr[node + 1];
-    const float* __restrict__ tab = p.tab_in + (size_t)node * p.tab_ld;   // this node's P_src | . | Q (wave-uniform reads)
+    {   // stage the weights: contiguous [kn][op] blocks and [op] biases out of the blob
+        const GenMlpDesc* mlps[3] = {&p.edge, &p.node, &p.cls};
+        for (int m = 0; m < 3; ++m) {
+            if ((m == 1 && !p.h_new) || (m == 2 && !p.logits)) continue;
+            for (int l = 0; l < mlps[m]->n; ++l) {
+                const GenLayerDesc& L = mlps[m]->l[l];
+                const float* __restrict__ src = p.blob + L.woff + (size_t)L.k0 * L.op;
+                for (int i = t; i < L.kn * L.op; i += T) s_w[L.lw + i] = src[i];
+                for (int i = t; i < L.op; i += T) s_w[L.lb + i] = p.blob[L.boff + i];
+            }
+        }
+        for (int i = t; i < p.tab_ld; i += T) s_tab[i] = p.tab_in[(size_t)node * p.tab_ld + i];
+        __syncthreads();
+    }
+    const float* tab = s_tab;   // this node's P_src | . | Q, staged below (read once per output pass: from HBM / L2 that was a dependent
+                                // round trip per pass -- sixteen per tile at node latent 64)
     const int ein_w = p.e_a_w + p.e_b_w;
     // aggregation roles: thread (channel c, part pt) for c < H; parts split the T edges of a tile evenly
     const int parts = max(1, T / max(p.H, 1));
@@ -147,15 +291,17 @@ __global__ __launch_bounds__(256) void gen_step_fused_kernel(const GenStepParams
         const float* __restrict__ pdst = p.tab_in + (size_t)j * p.tab_ld + p.o1e;
         float* cur = s_a;
         float* nxt = s_b;
-        gen_layer_lds(p.blob, p.edge.l[0], p.k0_edge, ein_w, cur, nxt, TS, t,
-                      [&](int o) { return o < p.o1e ? tab[o] + pdst[o] : 0.f; });
+        // the gathered P_dst[col] row parks in the OUTPUT buffer's own slots (all loads in flight at once); every output pass reads its
+        // four slots before it overwrites them
+        for (int o = 0; o < p.o1e; ++o) nxt[o * TS + t] = pdst[o];
+        gen_layer_lds(s_w, p.edge.l[0], cur, nxt, TS, t, [&](int o) { return o < p.o1e ? tab[o] + nxt[o * TS + t] : 0.f; });
         {
             float* tmp = cur;
             cur = nxt, nxt = tmp;
         }
         for (int l = 1; l < p.edge.n; ++l) {
             const GenLayerDesc& L = p.edge.l[l];
-            gen_layer_lds(p.blob, L, 0, L.in, cur, nxt, TS, t, [&](int o) { return p.blob[L.boff + o]; });
+            gen_layer_lds(s_w, L, cur, nxt, TS, t, [&](int o) { return s_w[L.lb + min(o, L.op - 1)]; });
             float* tmp = cur;
             cur = nxt, nxt = tmp;
         }
@@ -165,8 +311,7 @@ __global__ __launch_bounds__(256) void gen_step_fused_kernel(const GenStepParams
         const float* e_lds = cur;   // e' [EF][T]: read by the node MLP's first layer and by the classifier before anything overwrites it
         // ---- node MLP, first layer (models/mpn.py:97-98): Q[row] + W_e e' -> the free buffer ---------------------------------------
         if (p.h_new)
-            gen_layer_lds(p.blob, p.node.l[0], p.k0_node, p.EF, e_lds, nxt, TS, t,
-                          [&](int o) { return o < p.o1n ? tab[2 * p.o1e + o] : 0.f; });
+            gen_layer_lds(s_w, p.node.l[0], e_lds, nxt, TS, t, [&](int o) { return o < p.o1n ? tab[2 * p.o1e + o] : 0.f; });
         // ---- classifier on e' (models/mpn.py:290-293): widths <= 16 (gen_fused_ok), the thread's activations in registers ------------
         if (p.logits) {
             float va[16], vb[16];
@@ -175,15 +320,15 @@ __global__ __launch_bounds__(256) void gen_step_fused_kernel(const GenStepParams
             int wv = p.EF;
             for (int l = 0; l < p.cls.n; ++l) {
                 const GenLayerDesc& L = p.cls.l[l];
-                const float* __restrict__ Wt = p.blob + L.woff;
+                const float* Wt = s_w + L.lw;
 #pragma unroll
                 for (int o = 0; o < 16; ++o) {
                     float acc = 0.f;
                     if (o < L.out) {
-                        acc = p.blob[L.boff + o];
+                        acc = s_w[L.lb + o];
 #pragma unroll
                         for (int q = 0; q < 16; ++q)
-                            if (q < wv) acc = fmaf(Wt[(size_t)q * L.op + o], va[q], acc);
+                            if (q < wv) acc = fmaf(Wt[q * L.op + o], va[q], acc);
                         if (L.relu) acc = fmaxf(acc, 0.f);
                     }
                     vb[o] = acc;
@@ -200,7 +345,7 @@ __global__ __launch_bounds__(256) void gen_step_fused_kernel(const GenStepParams
             float* b = cur;     // e' is dead now
             for (int l = 1; l < p.node.n; ++l) {
                 const GenLayerDesc& L = p.node.l[l];
-                gen_layer_lds(p.blob, L, 0, L.in, a, b, TS, t, [&](int o) { return p.blob[L.boff + o]; });
+                gen_layer_lds(s_w, L, a, b, TS, t, [&](int o) { return s_w[L.lb + min(o, L.op - 1)]; });
                 float* tmp = a;
                 a = b, b = tmp;
             }
@@ -241,33 +386,57 @@ __global__ __launch_bounds__(256) void gen_step_fused_kernel(const GenStepParams
 
 // can the fused step run this configuration?  (every width it keeps per thread in LDS within the budget; at least one layer in
 // the two message-passing MLPs; H <= T so that every channel has a reducer thread)
-static bool gen_fused_ok(const gnncca_mpn_dims* d, int* T_out, int* wmax_out) {
+static bool gen_fused_ok(const gnncca_mpn_dims* d, int64_t n_nodes, int* T_out, int* wmax_out) {
     if (d->edge_mlp.n_layers < 1 || d->node_mlp.n_layers < 1 || d->num_enc_steps < 1) return false;
     int wmax = std::max(std::max((d->reattach_edges ? 2 : 1) * d->edge_dim, d->node_dim), 4);
     for (int l = 0; l < d->edge_mlp.n_layers; ++l) wmax = std::max(wmax, (int)d->edge_mlp.layers[l].out_dim);
     for (int l = 0; l < d->node_mlp.n_layers; ++l) wmax = std::max(wmax, (int)d->node_mlp.layers[l].out_dim);
     for (int l = 0; l < d->cls_edge.n_layers; ++l) wmax = std::max(wmax, (int)d->cls_edge.layers[l].out_dim);
     if (wmax > 128 || d->edge_dim > 16) return false;
+    if (d->node_in > 8192) return false;   // (the encoder tail keeps a node's widest vector twice in LDS)
+    for (int l = 0; l < d->enc_node.n_layers; ++l)
+        if (d->enc_node.layers[l].out_dim > 8192) return false;
     for (int l = 0; l < d->cls_edge.n_layers; ++l)
         if (d->cls_edge.layers[l].out_dim > 16) return false;   // the classifier's hidden layers live in 16 registers per thread
     if (d->edge_mlp.layers[d->edge_mlp.n_layers - 1].out_dim != d->edge_dim || d->node_mlp.layers[d->node_mlp.n_layers - 1].out_dim != d->node_dim)
         return false;
-    const int T = wmax <= 32 ? 256 : 128;
+    // edges per tile = threads per workgroup.  A single frame-sized graph has one workgroup per CU at most: everything is exposed
+    // latency there and the widest tile (one pass over a dense-256 node's 255 edges) is the fastest -- 132 KB of LDS at width 64;
+    // batches want two workgroups per CU instead (66 KB)
+    const int T = (wmax <= 32 || (wmax <= 64 && n_nodes <= 1024)) ? 256 : 128;
     if (d->node_dim > T) return false;
+    {   // the weights every edge uses must fit their LDS stage (40 KB) next to the activations
+        const int ef_in = (d->reattach_edges ? 2 : 1) * d->edge_dim;
+        size_t wf = 0;
+        auto add = [&](const gnncca_mlp& m, int kn_first) {
+            for (int l = 0; l < m.n_layers; ++l)
+                wf += (size_t)((l == 0 && kn_first >= 0 ? kn_first : m.layers[l].in_dim) + 1) * (size_t)((m.layers[l].out_dim + 7) / 8 * 8);
+        };
+        add(d->edge_mlp, ef_in), add(d->node_mlp, d->edge_dim), add(d->cls_edge, -1);
+        if (wf > 10240) return false;
+    }
     *T_out = T;
-    *wmax_out = wmax;
+    *wmax_out = (wmax + 3) / 4 * 4;   // keeps the LDS regions behind the activation buffers 16-byte aligned
     return true;
 }
 
-static void gen_fill_mlp(GenMlpDesc* m, const gnncca_mlp& mlp, const int32_t* woff, const int32_t* boff) {
+// descriptors of one MLP; `k0_first` / `kn_first`: the rows of the FIRST layer's weight used per edge (-1: all of them)
+static void gen_fill_mlp(GenMlpDesc* m, const gnncca_mlp& mlp, const int32_t* woff, const int32_t* boff, int k0_first, int kn_first, int* lds_floats) {
     m->n = mlp.n_layers;
     for (int l = 0; l < mlp.n_layers; ++l) {
-        m->l[l].woff = woff[l];
-        m->l[l].boff = boff[l];
-        m->l[l].in = mlp.layers[l].in_dim;
-        m->l[l].out = mlp.layers[l].out_dim;
-        m->l[l].op = (mlp.layers[l].out_dim + 7) / 8 * 8;
-        m->l[l].relu = mlp.layers[l].relu;
+        GenLayerDesc& L = m->l[l];
+        L.woff = woff[l];
+        L.boff = boff[l];
+        L.in = mlp.layers[l].in_dim;
+        L.out = mlp.layers[l].out_dim;
+        L.op = (mlp.layers[l].out_dim + 7) / 8 * 8;
+        L.relu = mlp.layers[l].relu;
+        L.k0 = (l == 0 && k0_first >= 0) ? k0_first : 0;
+        L.kn = (l == 0 && k0_first >= 0) ? kn_first : L.in;
+        L.lw = *lds_floats;
+        *lds_floats += L.kn * L.op;
+        L.lb = *lds_floats;
+        *lds_floats += L.op;
     }
 }
 
