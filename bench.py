@@ -644,7 +644,7 @@ def main():
         mode_used = api[best] + (" (auto: fastest of " + ", ".join(sorted(by_mode)) + ")" if args.mode == "auto" else "")
         run = forms[best][0] or eager_run
         t = blocks[len(blocks) // 2]      # median block of K steps (max over ranks inside every block)
-        # S forwards in flight: GraphedForward(streams=S).submit -- every stream replays its own one-forward HIP graph on its own static
+        # S forwards in flight: GraphedForward(streams=S).replay_slot -- every stream replays its own one-forward HIP graph on its own static
         # inputs and workspace, round robin, the host launching -- whole-job throughput of independent frames, reported beside
         # `value`, never as `value`.  (K forwards as S big graphs on S streams, GraphedForward.block(..., chains=S), barely overlap:
         # 26.1 vs 27.5 us -- the host-side launch of a 400-kernel graph takes as long as a third of its run.)
@@ -658,15 +658,15 @@ def main():
                 torch.cuda.synchronize()
 
                 def run_streams():
-                    pend = None
                     for i in range(args.steps):
-                        pend = gfs.submit(slots[i % args.streams], after_current=False)
-                    return pend.result()
+                        gfs.replay_slot(i % args.streams)
+                    gfs.join()
+                    return gfs.slot_outputs((args.steps - 1) % args.streams)
                 blocks_s, out_s = timed_blocks(None, args.steps, args.warmup, None, device, args.backend, min_blocks=args.min_blocks,
                                                run_block=run_streams)
                 t_s = blocks_s[len(blocks_s) // 2]
                 same = all(torch.equal(a_, b_) for a_, b_ in zip(out_s["classified_edges"], out["classified_edges"]))
-                pipelined = {"api": f"gnn_cca_amd.inference.GraphedForward(streams={args.streams}).submit", "streams": args.streams,
+                pipelined = {"api": f"gnn_cca_amd.inference.GraphedForward(streams={args.streams}).replay_slot / join", "streams": args.streams,
                              "ms_per_forward": t_s / args.steps * 1e3, "value": E * args.steps / t_s, "unit": "edges/s",
                              "bitwise_equal_to_value_mode": bool(same),
                              "note": f"{args.steps} forwards per block, round robin over {args.streams} streams, each replaying its one-forward HIP "

@@ -22,7 +22,8 @@ replayed: `GraphedForward` does that, in three forms.
     deals the K forwards onto S graphs replayed on S streams (S frames in flight, one workspace per chain).
   * `streams=S`: S independent forwards in flight, each stream replaying its own graph on its own workspace (the module keeps a
     workspace per stream; the packed weights are shared and read-only).  `gf.submit(data)` returns a `Pending` whose
-    `.result()` makes the CURRENT stream wait for that forward only.
+    `.result()` makes the CURRENT stream wait for that forward only; a producer that writes its frames into the slots' own static
+    inputs (`gf.slot_inputs`) drives them with `gf.replay_slot(i)` / `gf.join()` -- one graph launch of host work per frame.
 
 Replays are bitwise the eager forward (same kernels, same launch parameters, same order: tests/test_gpu_inference_graph.py).
 No CPU fallback, no caching of results: every replay runs every kernel of every forward it holds.
@@ -127,6 +128,7 @@ class GraphedForward:
         self._chain_streams = []   # streams of block(..., chains=S): one graph and one workspace each
         self._streams = [torch.cuda.Stream() for _ in range(int(streams))] if int(streams) > 1 else []
         self._next_slot = 0
+        self._slot_last, self._slot_out = {}, {}   # slot -> (graph, stream) / outputs of the shape last used on it (replay_slot)
 
     # -- what a captured graph depends on besides the input shapes: the packed weight blob's address and the module's options ------
     def _stamp(self, device):
@@ -273,7 +275,26 @@ class GraphedForward:
             static = _clone(data)
             graph, outs, ws = self._capture([static], stream=self._streams[slot])
             entry = self._graphs[key] = (graph, static, outs[0], stamp, ws)
+        self._slot_last[slot], self._slot_out[slot] = (entry[0], self._streams[slot]), entry[2]
         return entry
+
+    def replay_slot(self, slot):
+        """The lean form of `submit` for a producer that keeps every slot's static inputs filled (`slot_inputs`) and orders itself:
+        replay slot `slot`'s graph of the shape last handed out / submitted on it, on the slot's stream -- no checks, no copies, no
+        fork, no event (one graph launch of host work).  Order the results with `join()`."""
+        graph, st = self._slot_last[slot]
+        with torch.cuda.stream(st):
+            graph.replay()
+
+    def slot_outputs(self, slot):
+        """The (static) outputs of the graph `replay_slot(slot)` replays."""
+        return self._slot_out[slot]
+
+    def join(self):
+        """The CURRENT stream waits for everything enqueued on the S streams so far (no host synchronisation)."""
+        cur = torch.cuda.current_stream()
+        for st in self._streams:
+            cur.wait_stream(st)
 
     def submit(self, data, after_current=True):
         """Enqueue this frame's forward on one of the S streams and return at once: the stream whose static inputs `data` IS

@@ -172,6 +172,15 @@ def test_forwards_in_flight_on_several_streams():
     pend = [gf.submit(s, after_current=False) for s in slots]
     for i, p in enumerate(pend):
         assert _eq(p.result()["classified_edges"], want[i]), i
+    # the lean form: the producer refills the slots and replays them; join() orders the current stream behind all of them
+    for i, s in enumerate(slots):
+        s.x.copy_(frames[3 + i].x), s.edge_attr.copy_(frames[3 + i].edge_attr)
+    torch.cuda.synchronize()
+    for i in range(3):
+        gf.replay_slot(i)
+    gf.join()
+    for i in range(3):
+        assert _eq(gf.slot_outputs(i)["classified_edges"], want[3 + i]), i
     with pytest.raises(RuntimeError):
         GraphedForward(m).submit(frames[0])
 
