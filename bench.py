@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the MI355X message-passing path on BASELINE.json's headline workload.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--nodes 256] [--graphs 1] [--L 4] [--mode auto|eager|graph|graphk]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--nodes 256] [--graphs 1] [--L 4] [--mode auto|eager|graph|graphk|graphs]
 
 A "step" is one MOTMPNet.forward (encoder + L message-passing steps + the classifier on the last 3 steps, eval
 mode, no grad) over one batch of synthetic input already resident in HBM: `--graphs` independent fully-connected
@@ -18,9 +18,13 @@ sharded 512/N per rank through gnn_cca_amd.sharding.forward_sharded, timed the s
 
 Timing: >= 10 blocks of exactly `--steps` steps, each block bracketed by barrier + synchronize on both sides and reduced
 with MAX over ranks; the MEDIAN block is reported (ms_per_step = median block / steps), so a short `--steps` run is not
-one sub-millisecond sample.  How the K steps of a block are issued is `--mode`: K eager C-ABI calls, K replays of a one-forward
-HIP graph, or ONE replay of a HIP graph that holds the K forwards back to back (every launch of every forward; nothing cached or
-skipped) -- `auto` keeps the fastest and says so in `config.mode`.
+one sub-millisecond sample.  How the K steps of a block are issued is `--mode`, each form through the package API a caller of the
+reference's per-frame loop (inference.py:173-283) would use: K eager calls of MOTMPNet.forward; K replays of
+gnn_cca_amd.inference.GraphedForward's one-forward HIP graph; ONE replay of GraphedForward.block -- the K forwards, every launch of
+each, nothing cached or skipped, captured back to back in one HIP graph; or the same K forwards as HIP graphs of four frames round
+robin on `--streams` streams (GraphedForward.block(chains=S): independent frames in flight).  `auto` times every form with the same
+block protocol, lists each in `config.ms_per_step_by_mode`, keeps the fastest as `value` and names it in `config.mode`
+(`config.frames_in_flight` says whether forwards overlapped; `pipelined` puts the one-at-a-time and the in-flight figure side by side).
 
 Prints ONE JSON line (rank 0) with the driver's contract plus `roofline` (dominant kernel mpn_step_kernel, per-launch
 algorithmic bytes / HIP-event duration) and `cpu_baseline` (the reference-shaped torch CPU
@@ -518,9 +522,10 @@ def main():
     ap.add_argument("--nodes", type=int, default=256)
     ap.add_argument("--graphs", type=int, default=1, help="independent graphs per GPU per step")
     ap.add_argument("--L", type=int, default=4)
-    ap.add_argument("--mode", choices=["auto", "eager", "graph", "graphk"], default="auto",
+    ap.add_argument("--mode", choices=["auto", "eager", "graph", "graphk", "graphs"], default="auto",
                     help="eager: one C-ABI call per step; graph: the same call captured once in a HIP graph and replayed per step; "
                          "graphk: the K forwards of a timed block captured back to back in one HIP graph, replayed once per block; "
+                         "graphs: the K forwards as HIP graphs of four frames round robin on --streams streams (frames in flight); "
                          "auto: time each form after warm-up and keep the fastest (reported in config.mode)")
     ap.add_argument("--edge-state", choices=["fp32", "bf16"], default="fp32",
                     help="storage of the edge latents between steps (bf16: GNNCCA_OPT_EDGE_STATE_BF16; arithmetic stays fp32)")
@@ -607,7 +612,7 @@ def main():
         # `value`.  `pipelined` (extra object) is GraphedForward(streams=S).submit: S forwards in flight; never `value`.
         forms = {"eager": (eager_run, None)}
         gf = GraphedForward(model, warmup=0)
-        if args.mode in ("graph", "graphk", "auto"):
+        if args.mode in ("graph", "graphk", "graphs", "auto"):
             try:
                 static = gf.static_inputs(data)
                 static.x.copy_(data.x), static.edge_index.copy_(data.edge_index), static.edge_attr.copy_(data.edge_attr)
@@ -617,7 +622,7 @@ def main():
                 print(f"[bench] HIP graph capture failed ({type(exc).__name__}: {exc}); using eager launches", file=sys.stderr)
                 torch.cuda.synchronize()
             out_bytes = 4 * min(args.L, 3) * E
-            if "graph" in forms and args.mode in ("graphk", "auto") and args.steps * out_bytes <= (1 << 30):
+            if "graph" in forms and args.mode in ("graphk", "graphs", "auto") and args.steps * out_bytes <= (1 << 30):
                 try:
                     blk = gf.block([data] * args.steps, adopt_inputs=True)
                     blk.replay()
@@ -625,7 +630,23 @@ def main():
                 except Exception as exc:  # noqa: BLE001
                     print(f"[bench] HIP graph capture of a {args.steps}-step block failed ({type(exc).__name__}: {exc})", file=sys.stderr)
                     torch.cuda.synchronize()
-        want = {"eager": ["eager"], "graph": ["graph"], "graphk": ["graph_block"], "auto": ["eager", "graph", "graph_block"]}[args.mode]
+            # graph_block_chains: the same K forwards cut into HIP graphs of four frames, replayed round robin on S streams
+            # (GraphedForward.block(..., chains=S, depth=4)): S independent frames in flight, a workspace per stream, every forward
+            # complete with its own outputs -- the throughput form of the per-frame loop.  (Measured on the way: S parallel branches
+            # inside ONE graph 25.8 us, one big graph per stream 26.1 us -- the host-side launch of a 400-kernel graph takes a third
+            # of its run --, one-forward graphs round robin 15.9-26 us depending on how the streams land on the hardware queues.)
+            if "graph_block" in forms and args.streams > 1 and args.mode in ("graphs", "auto"):
+                try:
+                    # frames per graph: four on long blocks; two / one on short ones so that every stream gets the same number of groups
+                    depth_s = 4 if args.steps >= 16 * args.streams else (2 if args.steps >= 4 * args.streams else 1)
+                    blk_s = gf.block([data] * args.steps, adopt_inputs=True, chains=args.streams, depth=depth_s)
+                    blk_s.replay()
+                    forms["graph_block_chains"] = (None, lambda: blk_s.replay()[-1])
+                except Exception as exc:  # noqa: BLE001
+                    print(f"[bench] capture of the {args.streams}-stream block failed ({type(exc).__name__}: {exc})", file=sys.stderr)
+                    torch.cuda.synchronize()
+        want = {"eager": ["eager"], "graph": ["graph"], "graphk": ["graph_block"], "graphs": ["graph_block_chains"],
+                "auto": ["eager", "graph", "graph_block", "graph_block_chains"]}[args.mode]
         timed = {}
         for name in want:
             if name not in forms:
@@ -640,41 +661,21 @@ def main():
         blocks, out = timed[best]
         api = {"eager": "gnn_cca_amd.MOTMPNet.forward, one call per step (eager)",
                "graph": "gnn_cca_amd.inference.GraphedForward.__call__, one HIP-graph replay per step (static inputs, no copies)",
-               "graph_block": f"gnn_cca_amd.inference.GraphedForward.block, one HIP graph of {args.steps} forwards per block"}
+               "graph_block": f"gnn_cca_amd.inference.GraphedForward.block, one HIP graph of {args.steps} forwards per block",
+               "graph_block_chains": f"gnn_cca_amd.inference.GraphedForward.block(chains={args.streams}), the {args.steps} forwards of a block "
+                                     f"as small HIP graphs (1-4 frames each) round robin on {args.streams} streams ({args.streams} frames in flight)"}
         mode_used = api[best] + (" (auto: fastest of " + ", ".join(sorted(by_mode)) + ")" if args.mode == "auto" else "")
         run = forms[best][0] or eager_run
         t = blocks[len(blocks) // 2]      # median block of K steps (max over ranks inside every block)
-        # S forwards in flight: GraphedForward(streams=S).replay_slot -- every stream replays its own one-forward HIP graph on its own static
-        # inputs and workspace, round robin, the host launching -- whole-job throughput of independent frames, reported beside
-        # `value`, never as `value`.  (K forwards as S big graphs on S streams, GraphedForward.block(..., chains=S), barely overlap:
-        # 26.1 vs 27.5 us -- the host-side launch of a 400-kernel graph takes as long as a third of its run.)
+        # one frame at a time vs frames in flight, side by side (both are in ms_per_step_by_mode; `value` is the faster)
         pipelined = None
-        if world == 1 and args.streams > 1 and args.mode == "auto" and "graph" in forms:
-            try:
-                gfs = GraphedForward(model, streams=args.streams)
-                slots = [gfs.slot_inputs(data, i) for i in range(args.streams)]
-                for sl in slots:
-                    sl.x.copy_(data.x), sl.edge_index.copy_(data.edge_index), sl.edge_attr.copy_(data.edge_attr)
-                torch.cuda.synchronize()
-
-                def run_streams():
-                    for i in range(args.steps):
-                        gfs.replay_slot(i % args.streams)
-                    gfs.join()
-                    return gfs.slot_outputs((args.steps - 1) % args.streams)
-                blocks_s, out_s = timed_blocks(None, args.steps, args.warmup, None, device, args.backend, min_blocks=args.min_blocks,
-                                               run_block=run_streams)
-                t_s = blocks_s[len(blocks_s) // 2]
-                same = all(torch.equal(a_, b_) for a_, b_ in zip(out_s["classified_edges"], out["classified_edges"]))
-                pipelined = {"api": f"gnn_cca_amd.inference.GraphedForward(streams={args.streams}).replay_slot / join", "streams": args.streams,
-                             "ms_per_forward": t_s / args.steps * 1e3, "value": E * args.steps / t_s, "unit": "edges/s",
-                             "bitwise_equal_to_value_mode": bool(same),
-                             "note": f"{args.steps} forwards per block, round robin over {args.streams} streams, each replaying its one-forward HIP "
-                                     "graph on its own static inputs and workspace (frames resident, no copies); every forward complete; not `value`"}
-                del gfs, slots, out_s
-            except Exception as exc:  # noqa: BLE001
-                pipelined = {"error": f"{type(exc).__name__}: {exc}"}
-                torch.cuda.synchronize()
+        if "graph_block_chains" in by_mode and "graph_block" in by_mode:
+            same = all(torch.equal(a_, b_) for a_, b_ in zip(timed["graph_block_chains"][1]["classified_edges"],
+                                                             timed["graph_block"][1]["classified_edges"]))
+            pipelined = {"frames_in_flight": args.streams, "ms_per_forward_in_flight": by_mode["graph_block_chains"],
+                         "ms_per_forward_one_at_a_time": by_mode["graph_block"], "bitwise_equal_outputs": bool(same),
+                         "note": "one at a time = the latency of a forward inside a HIP-graph block; in flight = whole-job throughput of "
+                                 "independent frames (every forward complete, its own outputs, a workspace per stream)"}
         # every rank's OWN time per step (no barrier inside), gathered: how evenly the ranks run
         rank_ms = None
         if world > 1:
@@ -792,7 +793,8 @@ def main():
             "config": {"workload": f"{args.graphs} x dense{args.nodes} graph(s) per GPU per step "
                                    f"(N={N}, E={E}), feat 2048, L={args.L}, 3 classified steps, fp32 arithmetic, "
                                    f"{args.edge_state} edge state, eval",
-                       "mode": mode_used, "ms_per_step_by_mode": by_mode, "edge_state": args.edge_state, "edge_state_storage": "bf16" if args.edge_state == "bf16" else "f32",
+                       "mode": mode_used, "ms_per_step_by_mode": by_mode,
+                       "frames_in_flight": args.streams if best == "graph_block_chains" else 1, "edge_state": args.edge_state, "edge_state_storage": "bf16" if args.edge_state == "bf16" else "f32",
                        "encoder_products": args.enc_products, "encoder_unsplit": args.enc_unsplit,
                        "outputs_finite": bool(ok),
                        "edge_steps_per_s": world * E * args.L * args.steps / t,

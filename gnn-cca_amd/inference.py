@@ -18,8 +18,8 @@ replayed: `GraphedForward` does that, in three forms.
     step) skips the copies: `gf(static)` sees its own tensors and replays at once.
   * `gf.block(frames)`: K frames captured BACK TO BACK in one HIP graph (K whole forwards, every launch of each, each with its own
     outputs) -- the K-deep form: one graph launch per K frames, the launch-bound loop runs without the host in it.
-    `blk.replay()` -> list of K output dicts; `blk.inputs[i]` are the static buffers of frame i.  `gf.block(frames, chains=S)`
-    deals the K forwards onto S graphs replayed on S streams (S frames in flight, one workspace per chain).
+    `blk.replay()` -> list of K output dicts; `blk.inputs[i]` are the static buffers of frame i.  `gf.block(frames, chains=S, depth=D)`
+    cuts them into graphs of D frames replayed round robin on S streams (S frames in flight, one workspace per stream).
   * `streams=S`: S independent forwards in flight, each stream replaying its own graph on its own workspace (the module keeps a
     workspace per stream; the packed weights are shared and read-only).  `gf.submit(data)` returns a `Pending` whose
     `.result()` makes the CURRENT stream wait for that forward only; a producer that writes its frames into the slots' own static
@@ -70,6 +70,7 @@ class GraphedBlock:
 
     def __init__(self, graphs, streams, inputs, outputs, stamp, workspaces):
         self._graphs, self._streams, self.inputs, self.outputs, self._stamp, self._workspaces = graphs, streams, inputs, outputs, stamp, workspaces
+        self._uniq_streams = [st for i, st in enumerate(streams) if st is not None and st not in streams[:i]]
 
     def __len__(self):
         return len(self.inputs)
@@ -92,13 +93,13 @@ class GraphedBlock:
         cur = torch.cuda.current_stream()
         fork = torch.cuda.Event()
         fork.record(cur)
-        for g, st in zip(self._graphs, self._streams):
+        for st in self._uniq_streams:
             st.wait_event(fork)
+        for g, st in zip(self._graphs, self._streams):   # groups of `depth` frames, round robin over the S streams
             with torch.cuda.stream(st):
                 g.replay()
-            done = torch.cuda.Event()
-            done.record(st)
-            cur.wait_event(done)
+        for st in self._uniq_streams:
+            cur.wait_stream(st)
         return self.outputs
 
 
@@ -149,7 +150,12 @@ class GraphedForward:
         m = self.model
         if stream is None:
             if self._cap_stream is None:
-                self._cap_stream = torch.cuda.Stream()
+                # ONE stream serves the sequential forms and chain 0: this device maps streams onto four hardware queues in the order
+                # they are first used, the caller's stream holds one, and a chain stream that lands on an occupied queue does not
+                # overlap (measured: chains = 3 after a capture on a stream of its own 26 us per forward, with the shared stream 16)
+                if not self._chain_streams:
+                    self._chain_streams.append(torch.cuda.Stream())
+                self._cap_stream = self._chain_streams[0]
             stream = self._cap_stream
         with torch.no_grad():
             stream.wait_stream(torch.cuda.current_stream())
@@ -209,14 +215,16 @@ class GraphedForward:
         return outs[0]
 
     # -- K frames per graph launch -----------------------------------------------------------------------------------------------------
-    def block(self, frames, adopt_inputs=False, chains=1):
+    def block(self, frames, adopt_inputs=False, chains=1, depth=4):
         """Capture (once per sequence of shapes) the forwards of `frames` in one HIP graph.  `adopt_inputs=True`: the given
         tensors ARE the static buffers (they stay resident in HBM and the producer overwrites them in place); otherwise they are
         cloned.  The same object may appear several times (one forward per appearance, each with its own outputs).
-        `chains=S` > 1: the forwards are dealt round robin onto S graphs, each replayed on its own stream and workspace -- S
-        independent frames in flight instead of one chain in frame order (a frame-sized forward is six dependent launches that
-        leave most of the chip idle; parallel branches inside ONE HIP graph were measured too and barely overlap: 25.8 vs 27.6 us
-        per forward at three branches)."""
+        `chains=S` > 1: S independent frames in flight instead of one chain in frame order (a frame-sized forward is six dependent
+        launches that leave most of the chip idle): the frames are cut into groups of `depth` consecutive frames, every group is one
+        HIP graph, and the groups are replayed round robin on S streams (a workspace per stream).  `depth` trades host launches
+        (one per group: ~15 us each, which is what a frame-sized forward takes on the GPU) against how soon the streams overlap:
+        one graph per stream (depth = K / S) barely overlaps -- the host-side launch of a 400-kernel graph takes a third of its run
+        -- and so do parallel branches inside ONE graph (25.8 vs 27.6 us per forward at three branches)."""
         frames = list(frames)
         if not frames:
             raise ValueError("empty block")
@@ -227,7 +235,7 @@ class GraphedForward:
         dev = frames[0].x.device
         stamp = self._stamp(dev)
         self._drop_stale(stamp)
-        key = (tuple(_key(f) for f in frames), tuple(f.x.data_ptr() for f in frames) if adopt_inputs else None, int(chains))
+        key = (tuple(_key(f) for f in frames), tuple(f.x.data_ptr() for f in frames) if adopt_inputs else None, int(chains), int(depth))
         blk = self._blocks.get(key)
         if blk is None:
             clones = {}
@@ -243,18 +251,21 @@ class GraphedForward:
             if chains == 1:
                 graph, outs, ws = self._capture(inputs)
                 blk = GraphedBlock([graph], [None], inputs, outs, stamp, [ws])
-            else:   # chain c = frames c, c + S, c + 2 S, ... as one graph on its own stream (its own workspace of the module)
+            else:   # groups of `depth` consecutive frames, one graph each, group g on stream g % S (its own workspace of the module)
                 while len(self._chain_streams) < chains:
                     self._chain_streams.append(torch.cuda.Stream())
-                graphs, wss, outs = [], [], [None] * len(inputs)
-                for c in range(chains):
-                    idx = list(range(c, len(inputs), chains))
-                    g, o, ws = self._capture([inputs[i] for i in idx], stream=self._chain_streams[c])
+                depth = max(1, int(depth))
+                graphs, streams, wss, outs = [], [], [], [None] * len(inputs)
+                for gi, lo in enumerate(range(0, len(inputs), depth)):
+                    idx = list(range(lo, min(lo + depth, len(inputs))))
+                    st = self._chain_streams[gi % chains]
+                    g, o, ws = self._capture([inputs[i] for i in idx], stream=st)
                     graphs.append(g)
+                    streams.append(st)
                     wss.append(ws)
                     for i, oi in zip(idx, o):
                         outs[i] = oi
-                blk = GraphedBlock(graphs, self._chain_streams[:chains], inputs, outs, stamp, wss)
+                blk = GraphedBlock(graphs, streams, inputs, outs, stamp, wss)
             self._blocks[key] = blk
         return blk
 
