@@ -260,6 +260,10 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
                 // plan's queue one per CU behind the GEMM tiles, 29 -> 45 us at N = 8192.  Inside the GEMM waves, a 1024-edge block per wave
                 // under the first operands' round trip: the block's own two dependent round trips are then exposed in every workgroup,
                 // 29.5 + 6.4 -> 37.6 us.  profiles/r03_logs/r3_ride2.log, r3_ride4.log.)
+                // (Round 4 re-measured the plan BESIDE this GEMM on a side stream, fork / join by events, now under HIP-graph replay: 64 x dense128
+                // 98 -> 108 us per forward, 96 x dense128 130 -> 140, 64 x dense256 239 -> 244 -- both kernels slow each other down (GEMM 26.5 ->
+                // 29, plan 5.9 -> 10 us) and the cross-queue hand-offs cost more than the plan's launch; round 1 had found the same with eager
+                // launches.  profiles/r04_logs/ab_planfork1.log)
                 const dim3 fgrid((N + 255) / 256 + 1, 1), sgrid((N + 255) / 256, ks_split);
                 static const bool gemm_pipe = diag_env("GNNCCA_GEMM_NOPIPE") == nullptr;   // diagnostics: A/B against the barrier-per-chunk form (encoder.cuh: PIPE)
                 if (gemm_pipe && fused_tail && split3)
