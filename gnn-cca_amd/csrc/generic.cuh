@@ -255,6 +255,9 @@ static int forward_generic(const gnncca_mpn_dims* d, const void* packed_dev, con
         gen_fill_mlp(&gp.node, d->node_mlp, hdr.w[3], hdr.b[3], gp.hin_w, EF, &wfl);                                  // the e' block of cat[x[row] | e']
         gen_fill_mlp(&gp.cls, d->cls_edge, hdr.w[4], hdr.b[4], -1, 0, &wfl);
         gp.w_floats = (wfl + 3) / 4 * 4;
+        gp.w_used = wfl;
+        gp.step_w = hdr.step_w;
+        if (hdr.step_w == 0 || hdr.step_w_floats != wfl) return GNNCCA_ERR_UNSUPPORTED;   // (the packer and gen_fill_mlp lay the stage image out alike)
         gp.h0 = d->reattach_nodes ? h0 : nullptr;
         gp.o1e = d->edge_mlp.layers[0].out_dim, gp.o1n = d->node_mlp.layers[0].out_dim;
         gp.tab_ld = 2 * gp.o1e + gp.o1n;

@@ -54,7 +54,8 @@ struct GenStepParams {
     int H, EF, hin_w, agg;
     int lds_stride;         // T + 1
     int wmax;               // widest activation vector a thread keeps in LDS (gen_fused_ok)
-    int w_floats;           // LDS floats of the staged weights and biases (all layers of the three MLPs)
+    int w_floats;           // LDS floats of the staged weights and biases (all layers of the three MLPs), padded to 4
+    int w_used, step_w;     // ... unpadded; float offset of the stage image in the blob (GenBlobHeader::step_w)
 };
 
 // one dense layer on the tile: s_out[o][t] = act(init(o) + sum_k W[k][o] * s_in[k][t]), four outputs per pass; the layer's weights were
@@ -123,15 +124,22 @@ __device__ __forceinline__ void gen_project_node(const GenStepParams& p, const f
         } else {                         // Q = W_n[:, 0:hin] hin + b_n
             o = s - 2 * p.o1e, op = Ln.op, Wt = p.blob + Ln.woff, acc = p.blob[Ln.boff + o];
         }
-        // (sixteen weight loads in flight per batch: one load per iteration behind the FMA chain was a dependent L2 round trip per k --
+        // (the weight loads in flight in batches of 32: one load per iteration behind the FMA chain was a dependent L2 round trip per k --
         // 64 of them at node latent 64, most of a step launch's time)
         int k = 0;
-        for (; k + 16 <= p.hin_w; k += 16) {
-            float w[16];
+        for (; k + 32 <= p.hin_w; k += 32) {
+            float w[32];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) w[u] = Wt[(size_t)(k + u) * op + o];
+            for (int u = 0; u < 32; ++u) w[u] = Wt[(size_t)(k + u) * op + o];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) acc = fmaf(w[u], s_hin[k + u], acc);
+            for (int u = 0; u < 32; ++u) acc = fmaf(w[u], s_hin[k + u], acc);
+        }
+        for (; k + 8 <= p.hin_w; k += 8) {
+            float w[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) w[u] = Wt[(size_t)(k + u) * op + o];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = fmaf(w[u], s_hin[k + u], acc);
         }
         for (; k < p.hin_w; ++k) acc = fmaf(Wt[(size_t)k * op + o], s_hin[k], acc);
         dst[s] = acc;
@@ -255,17 +263,10 @@ __global__ __launch_bounds__(256) void gen_step_fused_kernel(const GenStepParams
     }
     const bool unsorted = (fl & GNNCCA_GRAPH_UNSORTED) != 0;
     const int seg_s = p.seg_ptr[node], seg_t = p.seg_ptr[node + 1];
-    {   // stage the weights: contiguous [kn][op] blocks and [op] biases out of the blob
-        const GenMlpDesc* mlps[3] = {&p.edge, &p.node, &p.cls};
-        for (int m = 0; m < 3; ++m) {
-            if ((m == 1 && !p.h_new) || (m == 2 && !p.logits)) continue;
-            for (int l = 0; l < mlps[m]->n; ++l) {
-                const GenLayerDesc& L = mlps[m]->l[l];
-                const float* __restrict__ src = p.blob + L.woff + (size_t)L.k0 * L.op;
-                for (int i = t; i < L.kn * L.op; i += T) s_w[L.lw + i] = src[i];
-                for (int i = t; i < L.op; i += T) s_w[L.lb + i] = p.blob[L.boff + i];
-            }
-        }
+    {   // stage the weights and this node's table row: ONE coalesced copy of the blob's stage image (pack.cpp: gen_step_block keeps it in the order
+        // and shape gen_fill_mlp assigns the LDS offsets in), every load in flight before the first store
+        const float* __restrict__ src = p.blob + p.step_w;
+        for (int i = t; i < p.w_used; i += T) s_w[i] = src[i];
         for (int i = t; i < p.tab_ld; i += T) s_tab[i] = p.tab_in[(size_t)node * p.tab_ld + i];
         __syncthreads();
     }
@@ -320,18 +321,32 @@ __global__ __launch_bounds__(256) void gen_step_fused_kernel(const GenStepParams
             int wv = p.EF;
             for (int l = 0; l < p.cls.n; ++l) {
                 const GenLayerDesc& L = p.cls.l[l];
-                const float* Wt = s_w + L.lw;
+                const float* Wl = s_w + L.lw;
+                const int op = L.op;
+                const bool relu = L.relu != 0;
 #pragma unroll
-                for (int o = 0; o < 16; ++o) {
-                    float acc = 0.f;
-                    if (o < L.out) {
-                        acc = s_w[L.lb + o];
+                for (int o0 = 0; o0 < 16; o0 += 8) {   // eight outputs per pass, weights as 16-byte broadcasts (op is a multiple of 8)
+                    float acc[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+                    if (o0 < L.out) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) acc[j] = s_w[L.lb + o0 + j];
 #pragma unroll
                         for (int q = 0; q < 16; ++q)
-                            if (q < wv) acc = fmaf(Wt[q * L.op + o], va[q], acc);
-                        if (L.relu) acc = fmaxf(acc, 0.f);
+                            if (q < wv) {
+                                const f32x4 w0 = *reinterpret_cast<const f32x4*>(Wl + q * op + o0);
+                                const f32x4 w1 = *reinterpret_cast<const f32x4*>(Wl + q * op + o0 + 4);
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) acc[j] = fmaf(w0[j], va[q], acc[j]), acc[4 + j] = fmaf(w1[j], va[q], acc[4 + j]);
+                            }
+                        if (relu) {
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) acc[j] = fmaxf(acc[j], 0.f);
+                        }
                     }
-                    vb[o] = acc;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) vb[o0 + j] = acc[j];   // (columns beyond L.out: padded weights and bias are zero)
                 }
 #pragma unroll
                 for (int q = 0; q < 16; ++q) va[q] = vb[q];

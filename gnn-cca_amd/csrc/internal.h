@@ -16,7 +16,7 @@ extern thread_local int g_last_hip_error;  // hipError_t of the last failed HIP 
 const char* diag_env(const char* name);
 int diag_env_int(const char* name, int fallback, int lo, int hi);
 
-constexpr uint32_t kBlobMagic = 0x4D504E34u;  // "MPN4": bumped with every change of the blob layout (a blob is only
+constexpr uint32_t kBlobMagic = 0x4D504E35u;  // "MPN5": bumped with every change of the blob layout (a blob is only
                                               // valid for the library build that packed it; load_packed_blob checks)
 constexpr int kH = 32;        // node latent width the MFMA step kernel is built for (node_out_dim)
 constexpr int kEF = 6;        // edge latent width (edge_out_dim): 3 k-steps of v_mfma_f32_32x32x2_f32
@@ -102,7 +102,8 @@ struct GenBlobHeader {
     int32_t w[5][GNNCCA_MAX_LAYERS];   // transposed, padded: [in][ceil8(out)]
     int32_t b[5][GNNCCA_MAX_LAYERS];   // [ceil8(out)]
     int32_t enc0_rowmajor;             // first node-encoder weight also as [out][in] (input of the MFMA GEMM), or 0
-    int32_t pad[3];
+    int32_t step_w, step_w_floats;     // the fused step's per-edge weights in the order and shape it stages them in LDS (generic_fused.cuh), or 0
+    int32_t pad[1];
 };
 int gen_enc0_ksplit(const gnncca_mpn_dims* d, int64_t n_nodes);  // split-K factor of that GEMM (0: not used)
 bool gen_blob_header(const gnncca_mpn_dims* d, GenBlobHeader* out);

@@ -85,6 +85,23 @@ struct GenBlobPlan {
     size_t total_floats;
 };
 
+// layers of the fused step's weight block in stage order: fn(mlp index, layer, first row, rows, padded width)
+template <typename F>
+static void gen_step_block(const gnncca_mpn_dims* d, F fn) {
+    const int hin = (d->reattach_nodes ? 2 : 1) * d->node_dim, ein = (d->reattach_edges ? 2 : 1) * d->edge_dim;
+    const int mlps[3] = {2, 3, 4};
+    for (int m : mlps) {
+        const gnncca_mlp& mlp = mlp_by_index(d, m);
+        for (int l = 0; l < mlp.n_layers; ++l) {
+            const int op = (mlp.layers[l].out_dim + 7) / 8 * 8;
+            int k0 = 0, kn = mlp.layers[l].in_dim;
+            if (l == 0 && m == 2) k0 = 2 * hin, kn = ein;            // cat[x[row] | x[col] | e] (models/mpn.py:68)
+            if (l == 0 && m == 3) k0 = hin, kn = d->edge_dim;        // cat[x[row] | e'] (models/mpn.py:97)
+            fn(m, l, k0, kn, op);
+        }
+    }
+}
+
 static GenBlobPlan plan_gen_blob(const gnncca_mpn_dims* d) {
     GenBlobPlan p;
     std::memset(&p, 0, sizeof(p));
@@ -106,6 +123,15 @@ static GenBlobPlan plan_gen_blob(const gnncca_mpn_dims* d) {
     // row-major too
     if (d->enc_node.n_layers > 0 && d->enc_node.layers[0].in_dim >= 256 && d->enc_node.layers[0].in_dim % 64 == 0)
         p.h.enc0_rowmajor = take((size_t)d->enc_node.layers[0].in_dim * d->enc_node.layers[0].out_dim);
+    // the fused step kernel (generic_fused.cuh) stages, per workgroup, the weights every EDGE uses: of the edge and node MLPs' first layers only
+    // the rows of the e block (the x[row] / x[col] blocks became per-node projection tables), every further layer whole, the classifier,
+    // each followed by its bias -- here once more, contiguous and in that order, so that the stage is ONE coalesced copy
+    if (d->edge_mlp.n_layers > 0 && d->node_mlp.n_layers > 0) {
+        size_t n = 0;
+        gen_step_block(d, [&](int, int, int, int kn, int op) { n += (size_t)(kn + 1) * op; });
+        p.h.step_w = take(n);
+        p.h.step_w_floats = (int32_t)n;
+    }
     p.total_floats = off;
     p.h.total_floats = (uint32_t)off;
     return p;
@@ -530,6 +556,15 @@ static int pack_generic(const gnncca_mpn_dims* d, const float* const* params, vo
             if (m == 0 && l == 0 && p.h.enc0_rowmajor)
                 std::memcpy(blob + p.h.enc0_rowmajor, f.w.data(), f.w.size() * sizeof(float));
         }
+    }
+    if (p.h.step_w) {   // the fused step's stage image: copies of the rows above
+        size_t o = (size_t)p.h.step_w;
+        gen_step_block(d, [&](int m, int l, int k0, int kn, int op) {
+            std::memcpy(blob + o, blob + p.h.w[m][l] + (size_t)k0 * op, (size_t)kn * op * sizeof(float));
+            o += (size_t)kn * op;
+            std::memcpy(blob + o, blob + p.h.b[m][l], (size_t)op * sizeof(float));
+            o += (size_t)op;
+        });
     }
     return GNNCCA_OK;
 }

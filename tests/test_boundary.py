@@ -176,7 +176,7 @@ def blob_forward(blob_u8, params, arch, x, edge_index, edge_attr):
     raw = blob_u8.numpy().tobytes()
     h = BlobHeader.from_buffer_copy(raw[:C.sizeof(BlobHeader)])
     f = np.frombuffer(raw, dtype=np.float32)
-    assert h.magic == 0x4D504E34 and h.total_floats * 4 == len(raw)
+    assert h.magic == 0x4D504E35 and h.total_floats * 4 == len(raw)
     enc = params["encoder_feats_dict"]["nodes"][arch]
     dims = [enc["node_in_dim"]] + list(enc["node_fc_dims"]) + [enc["node_out_dim"]]
     nf = 2 if params["reattach_initial_nodes"] else 1
