@@ -68,8 +68,9 @@ def _copy_into(static, data):
 class GraphedBlock:
     """K forwards captured in ONE HIP graph back to back, or (chains = S) in S graphs replayed on S streams (GraphedForward.block)."""
 
-    def __init__(self, graphs, streams, inputs, outputs, stamp, workspaces):
+    def __init__(self, graphs, streams, inputs, outputs, stamp, workspaces, owner=None, blob=None):
         self._graphs, self._streams, self.inputs, self.outputs, self._stamp, self._workspaces = graphs, streams, inputs, outputs, stamp, workspaces
+        self._owner, self._blob = owner, blob   # the packed weights the graphs address stay alive with them
         self._uniq_streams = [st for i, st in enumerate(streams) if st is not None and st not in streams[:i]]
 
     def __len__(self):
@@ -80,6 +81,10 @@ class GraphedBlock:
         forked from and joined back into the current stream by events (no host synchronisation).  `frames`: K new frames to copy into
         the static inputs first (same shapes as at capture; omit when the producer wrote them there).  Returns the K output dicts --
         static tensors, valid until the next replay."""
+        if self._owner is not None and self._owner._stamp(self.inputs[0].x.device) != self._stamp:
+            # (a weight update repacks into the SAME buffer and is seen by the replay; what invalidates a block is another packed buffer --
+            # the generic family's host packer, .to() -- or another option / step count: other kernels, other addresses)
+            raise RuntimeError("the module's packed weights or options changed since this block was captured: ask GraphedForward.block() again")
         if frames is not None:
             if len(frames) != len(self.inputs):
                 raise ValueError(f"this block holds {len(self.inputs)} frames, got {len(frames)}")
@@ -211,7 +216,7 @@ class GraphedForward:
         _copy_into(static, data)
         graph, outs, ws = self._capture([static])
         graph.replay()   # capture records, it does not execute: this replay is this call's forward
-        self._graphs[key] = (graph, static, outs[0], stamp, ws)
+        self._graphs[key] = (graph, static, outs[0], stamp, ws, self.model._packed[1])
         return outs[0]
 
     # -- K frames per graph launch -----------------------------------------------------------------------------------------------------
@@ -250,7 +255,7 @@ class GraphedForward:
             chains = max(1, min(int(chains), len(inputs)))
             if chains == 1:
                 graph, outs, ws = self._capture(inputs)
-                blk = GraphedBlock([graph], [None], inputs, outs, stamp, [ws])
+                blk = GraphedBlock([graph], [None], inputs, outs, stamp, [ws], self, self.model._packed[1])
             else:   # groups of `depth` consecutive frames, one graph each, group g on stream g % S (its own workspace of the module)
                 while len(self._chain_streams) < chains:
                     self._chain_streams.append(torch.cuda.Stream())
@@ -265,7 +270,7 @@ class GraphedForward:
                     wss.append(ws)
                     for i, oi in zip(idx, o):
                         outs[i] = oi
-                blk = GraphedBlock(graphs, streams, inputs, outs, stamp, wss)
+                blk = GraphedBlock(graphs, streams, inputs, outs, stamp, wss, self, self.model._packed[1])
             self._blocks[key] = blk
         return blk
 
@@ -285,7 +290,7 @@ class GraphedForward:
             self._drop_stale(stamp)
             static = _clone(data)
             graph, outs, ws = self._capture([static], stream=self._streams[slot])
-            entry = self._graphs[key] = (graph, static, outs[0], stamp, ws)
+            entry = self._graphs[key] = (graph, static, outs[0], stamp, ws, self.model._packed[1])
         self._slot_last[slot], self._slot_out[slot] = (entry[0], self._streams[slot]), entry[2]
         return entry
 

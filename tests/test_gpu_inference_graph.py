@@ -128,6 +128,14 @@ def test_block_of_k_frames_in_one_graph():
         assert _eq(o["classified_edges"], w)
     with pytest.raises(ValueError):
         blk.replay(frames2[:3])
+    # a block notices that it was captured for other kernels (an option that changes the dispatch) instead of replaying them
+    m.edge_state_dtype = "bf16"
+    with pytest.raises(RuntimeError):
+        blk.replay()
+    m.edge_state_dtype = "fp32"
+    outs = blk.replay(frames2)
+    for o, w in zip(outs, want2):
+        assert _eq(o["classified_edges"], w)
     # the bench form: ONE resident frame K times, inputs adopted (no copies), every forward with its own outputs
     d = _dense(64, 1)
     blk = gf.block([d] * 6, adopt_inputs=True)
