@@ -26,6 +26,7 @@ for it in range(n_graphs):
         for k in list(s):
             if k.startswith("MPNet.node_model"): s[k] = (s[k] * np.float32(0.05 if agg == "sum" else 4.0)).astype(np.float32)
         m = MOTMPNet(copy.deepcopy(p), None, arch); m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in s.items()})
+        m.column_ranges = bool(os.environ.get("SOAK_RANGES"))   # the column-range option (off by default) on the same graphs
         models[key] = (m.cuda().eval(), NumpyOracle(p, arch, s, np.float32))
     m, orc = models[key]
     m.edge_state_dtype = "bf16" if bf16 else "fp32"
