@@ -254,6 +254,7 @@ static int forward_generic(const gnncca_mpn_dims* d, const void* packed_dev, con
         gen_fill_mlp(&gp.edge, d->edge_mlp, hdr.w[2], hdr.b[2], 2 * gp.hin_w, (d->reattach_edges ? 2 : 1) * EF, &wfl);   // the e block of cat[x[row] | x[col] | e]
         gen_fill_mlp(&gp.node, d->node_mlp, hdr.w[3], hdr.b[3], gp.hin_w, EF, &wfl);                                  // the e' block of cat[x[row] | e']
         gen_fill_mlp(&gp.cls, d->cls_edge, hdr.w[4], hdr.b[4], -1, 0, &wfl);
+        gen_fill_mlp(&gp.enc, d->enc_edge, hdr.w[1], hdr.b[1], -1, 0, &wfl);   // the edge encoder rides in step 1
         gp.w_floats = (wfl + 3) / 4 * 4;
         gp.w_used = wfl;
         gp.step_w = hdr.step_w;
@@ -345,14 +346,17 @@ static int forward_generic(const gnncca_mpn_dims* d, const void* packed_dev, con
     }
     if (!use_fused && trace && trace->h_enc) HIP_TRY(hipMemcpyAsync(trace->h_enc, h0, (size_t)N * H * 4, hipMemcpyDeviceToDevice, st));
     if (E == 0) return GNNCCA_OK;
-    if (d->enc_edge.n_layers > 0) {
+    const bool enc_in_step1 = use_fused && d->enc_edge.n_layers > 0;   // the fused step 1 encodes the raw edge attributes itself
+    if (enc_in_step1) {
+        // nothing: e0 reaches HBM from step 1 only when a later step or the trace reads it
+    } else if (d->enc_edge.n_layers > 0) {
         s = gen_run_mlp(d->enc_edge, blob, hdr.w[1], hdr.b[1], GenSeg{edge_attr, nullptr, d->edge_in, d->edge_in}, none, none, E,
                         e0, EF, eb[0], eb[1], ew, st);
         if (s != GNNCCA_OK) return s;
     } else {
         HIP_TRY(hipMemcpyAsync(e0, edge_attr, (size_t)E * EF * sizeof(float), hipMemcpyDeviceToDevice, st));
     }
-    if (trace && trace->e_enc) HIP_TRY(hipMemcpyAsync(trace->e_enc, e0, (size_t)E * EF * 4, hipMemcpyDeviceToDevice, st));
+    if (!enc_in_step1 && trace && trace->e_enc) HIP_TRY(hipMemcpyAsync(trace->e_enc, e0, (size_t)E * EF * 4, hipMemcpyDeviceToDevice, st));
 
     const int L = d->num_enc_steps, first_cls = L - d->num_class_steps + 1;
     const float* h_cur = h0;  // latent node feats (== initial before step 1); every h buffer is dense [N][H]
@@ -373,8 +377,16 @@ static int forward_generic(const gnncca_mpn_dims* d, const void* packed_dev, con
     if (use_fused) {
         const int parts = std::max(1, fT / std::max(H, 1));
         const size_t lds = ((size_t)2 * fW * (fT + 1) + gp.w_floats + (gp.tab_ld + 3) / 4 * 4 + gp.hin_w + (size_t)parts * H) * sizeof(float);
-        if (lds > 64 * 1024)
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gen_step_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        {   // (once per device and size: the call costs tens of microseconds of host time)
+            static thread_local int attr_dev = -1;
+            static thread_local size_t attr_lds = 0;
+            int dev = 0;
+            HIP_TRY(hipGetDevice(&dev));
+            if (lds > 64 * 1024 && (attr_dev != dev || attr_lds < lds)) {
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gen_step_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                attr_dev = dev, attr_lds = lds;
+            }
+        }
         for (int step = 1; step <= L; ++step) {
             float* e_new = eb[2 + (step & 1)];
             const bool need_h = step < L || (trace && trace->h_steps);
@@ -386,6 +398,12 @@ static int forward_generic(const gnncca_mpn_dims* d, const void* packed_dev, con
                 gp.e_a = e_cur, gp.e_a_ld = e_ld, gp.e_a_w = EF;
                 gp.e_b = nullptr, gp.e_b_ld = 0, gp.e_b_w = 0;
             }
+            if (step == 1 && enc_in_step1) {
+                gp.edge_attr = edge_attr, gp.edge_in = d->edge_in;
+                gp.e0_out = (d->reattach_edges || (trace && trace->e_enc)) ? e0 : nullptr;
+            } else {
+                gp.edge_attr = nullptr, gp.e0_out = nullptr;
+            }
             gp.tab_in = tab[(step - 1) & 1];
             gp.tab_out = step < L ? tab[step & 1] : nullptr;
             gp.e_new = e_new, gp.e_new_ld = ew;
@@ -395,6 +413,8 @@ static int forward_generic(const gnncca_mpn_dims* d, const void* packed_dev, con
             HIP_TRY(hipGetLastError());
             e_cur = e_new;
             e_ld = ew;
+            if (step == 1 && enc_in_step1 && trace && trace->e_enc)
+                HIP_TRY(hipMemcpyAsync(trace->e_enc, e0, (size_t)E * EF * 4, hipMemcpyDeviceToDevice, st));
             if (trace && trace->e_steps)
                 HIP_TRY(hipMemcpy2DAsync(trace->e_steps + (size_t)(step - 1) * E * EF, (size_t)EF * 4, e_new, (size_t)ew * 4,
                                          (size_t)EF * 4, E, hipMemcpyDeviceToDevice, st));

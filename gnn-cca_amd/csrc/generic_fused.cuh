@@ -44,7 +44,10 @@ struct GenStepParams {
     const float* tab_in;    // [N][tab_ld]: P_src (+ bias) | P_dst | Q (+ bias) of this step
     float* tab_out;         // the next step's, or null
     int tab_ld, o1e, o1n;   // widths of the first edge / node layer
-    GenMlpDesc edge, node, cls;
+    GenMlpDesc edge, node, cls, enc;   // enc: encoder.edge_mlp (models/mpn.py:137), run by step 1 on the raw edge attributes when `edge_attr` is set
+    const float* edge_attr;   // [E][edge_in] or null: the edge input comes from e_a / e_b
+    int edge_in;
+    float* e0_out;            // [E][EF] encoded edge features to HBM (reattach_initial_edges, debug trace), or null
     int k0_edge, k0_node;   // first column of the e block in the first layer's weight (2 * hin_w, hin_w)
     float* e_new;           // [E][e_new_ld] latent edge features after this step (caller's edge order)
     int e_new_ld;
@@ -286,12 +289,27 @@ __global__ __launch_bounds__(256) void gen_step_fused_kernel(const GenStepParams
         const int pc = live ? pos : seg_t - 1;
         const int k = unsorted ? p.perm[pc] : pc;      // the caller's id of this thread's edge
         const int j = p.col32[pc];                      // its target node
-        // ---- edge MLP (models/mpn.py:68-69): inputs cat(e0, e) or e into s_a, k-major --------------------------------------------
-        for (int q = 0; q < p.e_a_w; ++q) s_a[q * TS + t] = p.e_a[(size_t)k * p.e_a_ld + q];
-        for (int q = 0; q < p.e_b_w; ++q) s_a[(p.e_a_w + q) * TS + t] = p.e_b[(size_t)k * p.e_b_ld + q];
-        const float* __restrict__ pdst = p.tab_in + (size_t)j * p.tab_ld + p.o1e;
         float* cur = s_a;
         float* nxt = s_b;
+        if (p.edge_attr) {
+            // ---- step 1: the edge encoder on the raw attributes (models/mpn.py:137), then cat(e0, e0) when reattaching (initial == latent) ----
+            for (int q = 0; q < p.edge_in; ++q) cur[q * TS + t] = p.edge_attr[(size_t)k * p.edge_in + q];
+            for (int l = 0; l < p.enc.n; ++l) {
+                const GenLayerDesc& L = p.enc.l[l];
+                gen_layer_lds(s_w, L, cur, nxt, TS, t, [&](int o) { return s_w[L.lb + min(o, L.op - 1)]; });
+                float* tmp = cur;
+                cur = nxt, nxt = tmp;
+            }
+            if (p.e0_out && live)
+                for (int q = 0; q < p.EF; ++q) p.e0_out[(size_t)k * p.EF + q] = cur[q * TS + t];
+            if (p.e_b_w > 0)
+                for (int q = 0; q < p.EF; ++q) cur[(p.EF + q) * TS + t] = cur[q * TS + t];
+        } else {
+            // ---- edge MLP (models/mpn.py:68-69): inputs cat(e0, e) or e, k-major ---------------------------------------------------
+            for (int q = 0; q < p.e_a_w; ++q) cur[q * TS + t] = p.e_a[(size_t)k * p.e_a_ld + q];
+            for (int q = 0; q < p.e_b_w; ++q) cur[(p.e_a_w + q) * TS + t] = p.e_b[(size_t)k * p.e_b_ld + q];
+        }
+        const float* __restrict__ pdst = p.tab_in + (size_t)j * p.tab_ld + p.o1e;
         // the gathered P_dst[col] row parks in the OUTPUT buffer's own slots (all loads in flight at once); every output pass reads its
         // four slots before it overwrites them
         for (int o = 0; o < p.o1e; ++o) nxt[o * TS + t] = pdst[o];
@@ -407,6 +425,8 @@ static bool gen_fused_ok(const gnncca_mpn_dims* d, int64_t n_nodes, int* T_out, 
     for (int l = 0; l < d->edge_mlp.n_layers; ++l) wmax = std::max(wmax, (int)d->edge_mlp.layers[l].out_dim);
     for (int l = 0; l < d->node_mlp.n_layers; ++l) wmax = std::max(wmax, (int)d->node_mlp.layers[l].out_dim);
     for (int l = 0; l < d->cls_edge.n_layers; ++l) wmax = std::max(wmax, (int)d->cls_edge.layers[l].out_dim);
+    wmax = std::max(wmax, (int)d->edge_in);
+    for (int l = 0; l < d->enc_edge.n_layers; ++l) wmax = std::max(wmax, (int)d->enc_edge.layers[l].out_dim);
     if (wmax > 128 || d->edge_dim > 16) return false;
     if (d->node_in > 8192) return false;   // (the encoder tail keeps a node's widest vector twice in LDS)
     for (int l = 0; l < d->enc_node.n_layers; ++l)
@@ -427,7 +447,7 @@ static bool gen_fused_ok(const gnncca_mpn_dims* d, int64_t n_nodes, int* T_out, 
             for (int l = 0; l < m.n_layers; ++l)
                 wf += (size_t)((l == 0 && kn_first >= 0 ? kn_first : m.layers[l].in_dim) + 1) * (size_t)((m.layers[l].out_dim + 7) / 8 * 8);
         };
-        add(d->edge_mlp, ef_in), add(d->node_mlp, d->edge_dim), add(d->cls_edge, -1);
+        add(d->edge_mlp, ef_in), add(d->node_mlp, d->edge_dim), add(d->cls_edge, -1), add(d->enc_edge, -1);
         if (wf > 10240) return false;
     }
     *T_out = T;

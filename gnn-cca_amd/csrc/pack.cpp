@@ -89,7 +89,7 @@ struct GenBlobPlan {
 template <typename F>
 static void gen_step_block(const gnncca_mpn_dims* d, F fn) {
     const int hin = (d->reattach_nodes ? 2 : 1) * d->node_dim, ein = (d->reattach_edges ? 2 : 1) * d->edge_dim;
-    const int mlps[3] = {2, 3, 4};
+    const int mlps[4] = {2, 3, 4, 1};   // edge MLP, node MLP, classifier, then the edge ENCODER (step 1 runs it on the raw edge attributes)
     for (int m : mlps) {
         const gnncca_mlp& mlp = mlp_by_index(d, m);
         for (int l = 0; l < mlp.n_layers; ++l) {
