@@ -130,6 +130,13 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
     int ks_last = 1;
     bool fused_tail = false;   // the GEMM launch already produced h0 and the step-1 projections
     const bool split3 = (options & GNNCCA_OPT_ENC_SPLIT3) != 0;
+    // graphs and batches whose GEMM ran split-K: the tail on the matrix pipe, 32 nodes per workgroup, from 2560 nodes (round 3 lowered this
+    // from 6144: 8.7 -> 6.9 us at N = 4096, 10.3 -> 7.5 at 5120, 10.4 -> 7.0 at 4000, 9.2 -> 7.2 at 3000, 8.6 -> 6.4 at 3072; equal at 2048
+    // (6.2), the register-resident tail ahead at 1024 (5.0 vs 7.6); profiles/r03_logs/r3_thresh1.log, r3_thresh2.log)
+    static const bool no_mfma_tail = diag_env("GNNCCA_NO_MFMA_TAIL") != nullptr;  // diagnostics: A/B the two tails
+    static const int kTailMfmaMin = diag_env("GNNCCA_TAIL_MFMA_MIN") ? std::atoi(diag_env("GNNCCA_TAIL_MFMA_MIN")) : 2560;
+    const bool tail_mfma_ok = !dropping && !no_mfma_tail && N >= kTailMfmaMin && nl == 2 && d->enc_node.layers[0].out_dim == 128 &&
+                              !d->reattach_nodes && (reinterpret_cast<uintptr_t>(part) & 15) == 0;
     for (int g = 0; g < n_gemm; ++g) {
         const gnncca_layer& l = d->enc_node.layers[g];
         const int K = l.in_dim, O = l.out_dim;
@@ -264,6 +271,11 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
                 // 98 -> 108 us per forward, 96 x dense128 130 -> 140, 64 x dense256 239 -> 244 -- both kernels slow each other down (GEMM 26.5 ->
                 // 29, plan 5.9 -> 10 us) and the cross-queue hand-offs cost more than the plan's launch; round 1 had found the same with eager
                 // launches.  profiles/r04_logs/ab_planfork1.log)
+                // (Round 4 also let the plan ride in the TAIL launch of this regime -- plan workgroups behind enc_tail_mfma_kernel's, the last one
+                // to arrive folding: the bare co-run, with no arrival count at all, takes 14.4 us against 5.9 + 9.7 at N = 8192 and 35-37 against
+                // 17.6 + 14.8 at 64 x dense256 (the plan's stream at the tail's 192-VGPR occupancy); the arrival count costs ~15 ns per plan
+                // workgroup (one address, eight L2s: 22.9 us) and the release fence in front of it ~95 ns (an L2 write-back each: 117-120 us).
+                // profiles/r04_logs/ab_tailride{1,2,3}.log)
                 const dim3 fgrid((N + 255) / 256 + 1, 1), sgrid((N + 255) / 256, ks_split);
                 static const bool gemm_pipe = diag_env("GNNCCA_GEMM_NOPIPE") == nullptr;   // diagnostics: A/B against the barrier-per-chunk form (encoder.cuh: PIPE)
                 if (gemm_pipe && fused_tail && split3)
@@ -375,13 +387,7 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
         const unsigned blocks = (unsigned)std::min<size_t>(((size_t)N + 3) / 4, 2048) + 1;  // + plan-repair workgroup
         // register-resident tail in the latency-bound regime only: on big batches it is VALU-bound (readlane traffic) and
         // measured 15 % slower than the LDS form (72 vs 62 us at N = 65 536)
-        // graphs and batches whose GEMM ran split-K: the tail on the matrix pipe, 32 nodes per workgroup, from 2560 nodes (round 3 lowered this
-        // from 6144: 8.7 -> 6.9 us at N = 4096, 10.3 -> 7.5 at 5120, 10.4 -> 7.0 at 4000, 9.2 -> 7.2 at 3000, 8.6 -> 6.4 at 3072; equal at 2048
-        // (6.2), the register-resident tail ahead at 1024 (5.0 vs 7.6); profiles/r03_logs/r3_thresh1.log, r3_thresh2.log)
-        static const bool no_mfma_tail = diag_env("GNNCCA_NO_MFMA_TAIL") != nullptr;  // diagnostics: A/B the two tails
-        static const int kTailMfmaMin = diag_env("GNNCCA_TAIL_MFMA_MIN") ? std::atoi(diag_env("GNNCCA_TAIL_MFMA_MIN")) : 2560;
-        const bool tail_mfma = !dropping && !fused_tail && !no_mfma_tail && N >= kTailMfmaMin && tp.F == 128 && tp.has_last && nl == 2 && !tp.reatt_n &&
-                               (reinterpret_cast<uintptr_t>(part) & 15) == 0;
+        const bool tail_mfma = tail_mfma_ok && !fused_tail;
         const bool tail_fast = !tail_mfma && !dropping && N < 4096 && tp.F == 128 && tp.has_last && !tp.reatt_n && tp.trace_h == nullptr && tp.vec_reduce &&
                                (reinterpret_cast<uintptr_t>(part) & 15) == 0;
         if (fused_tail) {
@@ -583,6 +589,20 @@ int gnncca_gather_cat(const float* a, const int64_t* ia, int wa, int64_t rows_a,
     hipLaunchKernelGGL(tr_cat64_kernel, grid1((size_t)rows * (wa + wb + wc), 256), dim3(256), 0, static_cast<hipStream_t>(stream), a,
                        reinterpret_cast<const long long*>(ia), wa, (long long)rows_a, b, reinterpret_cast<const long long*>(ib), wb,
                        (long long)rows_b, c, reinterpret_cast<const long long*>(ic), wc, (long long)rows_c, out, (long long)rows);
+    HIP_TRY(hipGetLastError());
+    return GNNCCA_OK;
+}
+
+int gnncca_pad_frame(const float* x, int64_t n_nodes, const int64_t* edge_index, const float* edge_attr, int64_t n_edges, float* x_pad,
+                     int64_t n_real_max, int n_dummy, int64_t* edge_index_pad, float* edge_attr_pad, int64_t e_pad, int node_in, int edge_in,
+                     gnncca_stream_t stream) {
+    if (n_nodes < 0 || n_edges < 0 || n_real_max < n_nodes || e_pad < n_edges || n_dummy < 1 || node_in < 1 || edge_in < 1) return GNNCCA_ERR_INVALID_ARG;
+    if (!x_pad || !edge_index_pad || !edge_attr_pad || (n_nodes > 0 && !x) || (n_edges > 0 && (!edge_index || !edge_attr))) return GNNCCA_ERR_INVALID_ARG;
+    const long long total = (n_real_max + n_dummy) * (long long)node_in + e_pad * (2ll + edge_in);
+    const unsigned blocks = (unsigned)std::min<long long>((total + 255) / 256, 4096);
+    hipLaunchKernelGGL(pad_frame_kernel, dim3(std::max(blocks, 1u)), dim3(256), 0, static_cast<hipStream_t>(stream), x, (long long)n_nodes,
+                       reinterpret_cast<const long long*>(edge_index), edge_attr, (long long)n_edges, x_pad, (long long)n_real_max, n_dummy,
+                       reinterpret_cast<long long*>(edge_index_pad), edge_attr_pad, (long long)e_pad, node_in, edge_in);
     HIP_TRY(hipGetLastError());
     return GNNCCA_OK;
 }

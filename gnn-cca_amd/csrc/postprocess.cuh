@@ -100,4 +100,32 @@ __global__ __launch_bounds__(1024) void post_cc_kernel(const long long* __restri
     if (mine) atomicAdd(n_clusters, mine);
 }
 
+// ---- frame padding for the one-graph-fits-all-frames replay (gnn_cca_amd.inference.GraphedForward(pad_to=...)) ---------------------------
+// The per-frame loop of inference.py:173-283 sees another (N, E) every frame; a HIP graph is captured for ONE shape.  Independent components of
+// a disjoint union do not influence each other (Batch.from_data_list semantics, inference.py:279), so a frame can be padded to a canonical
+// shape with a DUMMY component: `n_dummy` extra nodes behind the real ones that carry every padding edge as a self loop (rows stay sorted: the
+// dummy ids are the largest; the loops are dealt over the dummy nodes in order so that no single segment holds them all).  One launch copies
+// the frame into the padded buffers and writes the padding: x rows beyond N are zeroed, padding edges get zero attributes.
+__global__ __launch_bounds__(256) void pad_frame_kernel(const float* __restrict__ x, long long n, const long long* __restrict__ ei,
+                                                        const float* __restrict__ ea, long long e, float* __restrict__ x_pad,
+                                                        long long n_real_max, int n_dummy, long long* __restrict__ ei_pad,
+                                                        float* __restrict__ ea_pad, long long e_pad, int node_in, int edge_in) {
+    const long long n_pad = n_real_max + n_dummy;
+    const long long nx = n_pad * node_in, na = e_pad * edge_in;
+    const long long total = nx + 2 * e_pad + na;
+    const long long per = (e_pad - e + n_dummy - 1) / max(n_dummy, 1);   // padding loops per dummy node
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
+        if (t < nx) {
+            const long long r = t / node_in;
+            x_pad[t] = r < n ? x[t] : 0.f;
+        } else if (t < nx + 2 * e_pad) {
+            const long long u = t - nx, side = u / e_pad, k = u - side * e_pad;
+            ei_pad[u] = k < e ? ei[side * e + k] : n_real_max + (per > 0 ? (k - e) / per : 0);
+        } else {
+            const long long u = t - nx - 2 * e_pad, k = u / edge_in;
+            ea_pad[u] = k < e ? ea[u] : 0.f;
+        }
+    }
+}
+
 }  // namespace gnncca

@@ -30,6 +30,8 @@ No CPU fallback, no caching of results: every replay runs every kernel of every 
 """
 import torch
 
+from .mpn import _raw_stream
+
 
 class _Frame:
     """Duck-typed `data` of MOTMPNet.forward (models/mpn.py:266 reads .x, .edge_index, .edge_attr only)."""
@@ -343,3 +345,106 @@ class GraphedForward:
             ev = torch.cuda.Event()
             ev.record(st)
         return Pending(outs, ev)
+
+
+class PaddedForward:
+    """ONE HIP graph for every frame of the per-frame loop (inference.py:173-283), whatever its (N, E).
+
+    `GraphedForward` keeps a graph per input shape; a camera sequence has hundreds of shapes (the 4816 Terrace frames:
+    tests/golden/terrace_topology.npz).  Here every frame is padded to ONE canonical shape instead -- `n_max` real nodes plus
+    `n_dummy` dummy nodes behind them, `e_max` edges -- by one kernel launch (`gnncca_pad_frame`, include/gnncca_mpn.h): rows beyond
+    N are zero, the missing edges are self loops with zero attributes on the dummy nodes.  The dummy nodes are a component of
+    their own, and models/mpn.py has no term that crosses components (what Batch.from_data_list relies on, inference.py:279): the
+    logits of the frame's own edges are those of the frame alone (to rounding: the encoder's reduction order depends on the row
+    count).  Per frame the host enqueues the pad kernel and one graph launch; the outputs are VIEWS of the first E rows of the
+    graph's static logits, valid until the slot's next frame.
+
+        pf = PaddedForward(model, n_max=40, e_max=1200)          # streams=S: S frames in flight, round robin
+        for data in frames:
+            preds = pf(data)['classified_edges'][-1].view(-1)     # inference.py:283-286
+
+    A frame that does not fit (N > n_max or E > e_max) runs the eager forward; so does an empty one."""
+
+    def __init__(self, model, n_max, e_max, n_dummy=8, streams=1):
+        from . import _native as nat
+        self._nat = nat
+        self.model, self.n_max, self.e_max, self.n_dummy = model, int(n_max), int(e_max), max(1, int(n_dummy))
+        self._gf = GraphedForward(model, warmup=0, streams=streams)
+        self._s = max(1, int(streams))
+        self._slots, self._stamp0 = None, None
+        self._next = 0
+        self.padded, self.eager = 0, 0   # frames served by the graph / by the eager forward (did not fit)
+
+    def _template(self, data):
+        n, e = self.n_max + self.n_dummy, self.e_max
+        x = torch.zeros((n, data.x.shape[1]), dtype=data.x.dtype, device=data.x.device)
+        ea = torch.zeros((e, data.edge_attr.shape[1]), dtype=data.edge_attr.dtype, device=data.x.device)
+        ei = torch.full((2, e), self.n_max, dtype=torch.int64, device=data.x.device)   # a valid graph for the capture: loops on one dummy node
+        return _Frame(x, ei, ea)
+
+    def _make_slots(self, data):
+        t = self._template(data)
+        gf = self._gf
+        if self._s == 1:
+            # capture now (GraphedForward(warmup=0) captures on the first call of a shape); the template's buffers become the static inputs
+            static = gf.static_inputs(t)
+            gf(static)
+            graph, _, outs = gf._graphs[(_key(static), 0)][:3]
+            self._slots = [(static, graph, outs, None)]
+        else:
+            self._slots = []
+            for i in range(self._s):
+                static = gf.slot_inputs(t, i)
+                graph, st = gf._slot_last[i]
+                self._slots.append((static, graph, gf._slot_out[i], st))
+        self._node_in, self._edge_in = int(data.x.shape[1]), int(data.edge_attr.shape[1])
+        self._pad_fn = self._nat.lib().gnncca_pad_frame
+        torch.cuda.synchronize()
+
+    def __call__(self, data):
+        """Returns the dict of model(data) -- for streams > 1 a `Pending` (`.result()` orders the current stream behind that frame)."""
+        _check(self.model, data)
+        n, e = data.x.shape[0], data.edge_index.shape[1]
+        if n == 0 or e == 0 or n > self.n_max or e > self.e_max:
+            self.eager += 1
+            with torch.no_grad():
+                out = self.model(data)
+            if self._s > 1:
+                ev = torch.cuda.Event()
+                ev.record()
+                return Pending(out, ev)
+            return out
+        stamp = self._gf._stamp(data.x.device)
+        if self._slots is None or stamp != self._stamp0:   # first frame, or the graphs address other weights / kernels now: capture again
+            self._gf._drop_stale(stamp)
+            self._make_slots(data)
+            self._stamp0 = stamp
+        self.padded += 1
+        x, ei, ea = data.x, data.edge_index, data.edge_attr
+        if not (x.is_contiguous() and ei.is_contiguous() and ea.is_contiguous()):
+            x, ei, ea = x.contiguous(), ei.contiguous(), ea.contiguous()
+        i = self._next
+        static, graph, outs, st = self._slots[i]
+        if st is None:
+            self._pad(x, ei, ea, static, n, e, _raw_stream(x.device))
+            graph.replay()
+            return {"classified_edges": [t[:e] for t in outs["classified_edges"]]}
+        self._next = i + 1 if i + 1 < self._s else 0
+        st.wait_stream(torch.cuda.current_stream())     # the producer of `data`
+        self._pad(x, ei, ea, static, n, e, st.cuda_stream)
+        with torch.cuda.stream(st):
+            graph.replay()
+        ev = torch.cuda.Event()
+        ev.record(st)
+        for t in (x, ei, ea):
+            t.record_stream(st)
+        return Pending({"classified_edges": [t[:e] for t in outs["classified_edges"]]}, ev)
+
+    def _pad(self, x, ei, ea, static, n, e, raw_stream):
+        status = self._pad_fn(x.data_ptr(), n, ei.data_ptr(), ea.data_ptr(), e, static.x.data_ptr(), self.n_max, self.n_dummy,
+                              static.edge_index.data_ptr(), static.edge_attr.data_ptr(), self.e_max, self._node_in, self._edge_in, raw_stream)
+        if status:
+            self._nat.check(status, "gnncca_pad_frame")
+
+    def join(self):
+        self._gf.join()

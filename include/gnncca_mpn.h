@@ -360,6 +360,15 @@ GNNCCA_API size_t gnncca_aggregate_workspace_bytes(int64_t n_nodes, int64_t n_ed
 GNNCCA_API int gnncca_aggregate(const float* messages, const int64_t* edge_index, int64_t n_nodes, int64_t n_edges, int width, int agg,
                                 float* out, void* workspace, size_t workspace_bytes, gnncca_stream_t stream);
 
+/* One launch that copies a frame (x [N][node_in], edge_index [2][E] int64, edge_attr [E][edge_in]) into buffers of a canonical shape
+ * (x_pad [n_real_max + n_dummy][node_in], edge_index_pad [2][e_pad], edge_attr_pad [e_pad][edge_in]) and writes the padding: zero rows,
+ * and e_pad - E self loops with zero attributes on the n_dummy extra nodes behind the real ones (a disjoint dummy component: the logits of
+ * the frame's own edges are those of the frame alone, models/mpn.py has no cross-component term; rows stay sorted).  What lets ONE captured
+ * HIP graph serve every frame of the per-frame loop of inference.py:173-283 (gnn_cca_amd.inference.GraphedForward(pad_to=...)). */
+GNNCCA_API int gnncca_pad_frame(const float* x, int64_t n_nodes, const int64_t* edge_index, const float* edge_attr, int64_t n_edges,
+                                float* x_pad, int64_t n_real_max, int n_dummy, int64_t* edge_index_pad, float* edge_attr_pad,
+                                int64_t e_pad, int node_in, int edge_in, gnncca_stream_t stream);
+
 /* Synchronises `stream` and returns the flag word of the last forward that used `workspace`. */
 GNNCCA_API int gnncca_read_graph_flags(const void* workspace, uint32_t* flags_out, gnncca_stream_t stream);
 /* The same plus, in flags_out[1], the column-range verdict of that forward: 0 = every node's target ids were <= 2 contiguous runs (or
