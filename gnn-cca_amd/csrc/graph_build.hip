@@ -16,6 +16,12 @@
 // for a 256-detection frame -- and 8+8+16+4 B are written per edge; the kernel is L2/latency bound, not HBM bound.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <climits>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
 #include "internal.h"
 #include "wave_reduce.cuh"
 
@@ -290,6 +296,107 @@ int gnncca_build_edges(const gnncca_frames* fr, const float* reid, int32_t reid_
     }
     HIP_TRY_GB(hipGetLastError());
     return GNNCCA_OK;
+}
+
+// ---- host side of row N1: the edge enumeration of a batch of frames (inference.py:207-212), written straight into the staging image ----
+// Layout of `staging` (what gnn_cca_amd.graph_build uploads in ONE transfer; 8-byte fields first):
+//   f64 xw[n], yw[n], max_dist[g];  i64 ids[n];  i32 person[n], cam[n], graph_of[n], graph_ptr[g + 1], src_order[n], edge_ptr[n + 1],
+//   edge_ptr_g[g + 1]
+size_t gnncca_plan_frames_bytes(int64_t n, int64_t g) {
+    if (n < 0 || g < 0) return 0;
+    return (size_t)(8 * (3 * n + g) + 4 * (5 * n + 2 * g + 3));
+}
+
+int64_t gnncca_plan_frames(const double* xw, const double* yw, const int64_t* ids, const int64_t* id_cam, int64_t n,
+                           const int64_t* graph_sizes, const double* max_dist, int64_t g, void* staging, size_t staging_bytes) {
+    if (n < 0 || g < 0 || !staging || staging_bytes < gnncca_plan_frames_bytes(n, g)) return -(int64_t)GNNCCA_ERR_INVALID_ARG;
+    if ((n > 0 && (!xw || !yw || !ids || !id_cam)) || (g > 0 && (!graph_sizes || !max_dist))) return -(int64_t)GNNCCA_ERR_INVALID_ARG;
+    if (n >= (1ll << 31) - 64 || g >= (1ll << 31) - 64) return -(int64_t)GNNCCA_ERR_UNSUPPORTED;
+    long long total = 0;
+    for (int64_t q = 0; q < g; ++q) {
+        if (graph_sizes[q] < 0) return -(int64_t)GNNCCA_ERR_INVALID_ARG;
+        total += graph_sizes[q];
+    }
+    if (total != n) return -(int64_t)GNNCCA_ERR_INVALID_ARG;   // id_cam length does not match graph_sizes
+    char* base = static_cast<char*>(staging);
+    double* o_xw = reinterpret_cast<double*>(base);
+    double* o_yw = o_xw + n;
+    double* o_md = o_yw + n;
+    int64_t* o_ids = reinterpret_cast<int64_t*>(o_md + g);
+    int32_t* o_person = reinterpret_cast<int32_t*>(o_ids + n);
+    int32_t* o_cam = o_person + n;
+    int32_t* o_graph_of = o_cam + n;
+    int32_t* o_graph_ptr = o_graph_of + n;
+    int32_t* o_src = o_graph_ptr + g + 1;
+    int32_t* o_edge_ptr = o_src + n;
+    int32_t* o_edge_ptr_g = o_edge_ptr + n + 1;
+    if (n) {
+        std::memcpy(o_xw, xw, 8 * (size_t)n);
+        std::memcpy(o_yw, yw, 8 * (size_t)n);
+        std::memcpy(o_ids, ids, 8 * (size_t)n);
+    }
+    if (g) std::memcpy(o_md, max_dist, 8 * (size_t)g);
+    // cameras: np.unique order (ascending camera id) inside every frame = the rank among the batch's distinct camera ids
+    std::vector<int64_t> cams;
+    for (int64_t i = 0; i < n; ++i) {
+        if (id_cam[i] < INT32_MIN || id_cam[i] > INT32_MAX) return -(int64_t)GNNCCA_ERR_UNSUPPORTED;
+        bool seen = false;
+        for (int64_t c : cams) seen = seen || c == id_cam[i];
+        if (!seen) {
+            if (cams.size() >= 4096) return -(int64_t)GNNCCA_ERR_UNSUPPORTED;
+            cams.push_back(id_cam[i]);
+        }
+    }
+    std::sort(cams.begin(), cams.end());
+    const int64_t n_cam = std::max<int64_t>((int64_t)cams.size(), 1);
+    // person ids: any relabelling that preserves equality (gnncca_frames::person_id) -- first appearance, open addressing
+    {
+        size_t cap = 16;
+        while (cap < (size_t)(2 * n + 1)) cap <<= 1;
+        std::vector<int64_t> keys(cap);
+        std::vector<int32_t> vals(cap, -1);
+        int32_t next = 0;
+        for (int64_t i = 0; i < n; ++i) {
+            const uint64_t hsh = (uint64_t)ids[i] * 0x9E3779B97F4A7C15ull;
+            size_t slot = (size_t)(hsh >> 20) & (cap - 1);
+            while (vals[slot] >= 0 && keys[slot] != ids[i]) slot = (slot + 1) & (cap - 1);
+            if (vals[slot] < 0) keys[slot] = ids[i], vals[slot] = next++;
+            o_person[i] = vals[slot];
+        }
+    }
+    // stable counting sort by (frame, camera rank): frame-major, camera order inside a frame, node id ascending inside a camera
+    std::vector<int32_t> key((size_t)n);
+    std::vector<int32_t> count((size_t)(g * n_cam) + 1, 0);
+    {
+        int64_t i = 0;
+        o_graph_ptr[0] = 0;
+        for (int64_t q = 0; q < g; ++q) {
+            for (int64_t k = 0; k < graph_sizes[q]; ++k, ++i) {
+                const int32_t rank = (int32_t)(std::lower_bound(cams.begin(), cams.end(), id_cam[i]) - cams.begin());
+                o_graph_of[i] = (int32_t)q;
+                o_cam[i] = (int32_t)id_cam[i];
+                key[(size_t)i] = (int32_t)(q * n_cam + rank);
+                ++count[(size_t)key[(size_t)i]];
+            }
+            o_graph_ptr[q + 1] = (int32_t)i;
+        }
+    }
+    std::vector<int32_t> start((size_t)(g * n_cam) + 1, 0);
+    for (size_t k = 0; k + 1 < start.size(); ++k) start[k + 1] = start[k] + count[k];
+    {
+        std::vector<int32_t> cursor(start);
+        for (int64_t i = 0; i < n; ++i) o_src[cursor[(size_t)key[(size_t)i]]++] = (int32_t)i;
+    }
+    long long e = 0;
+    for (int64_t pos = 0; pos < n; ++pos) {
+        const int32_t node = o_src[pos];
+        o_edge_ptr[pos] = (int32_t)e;
+        e += graph_sizes[o_graph_of[node]] - count[(size_t)key[(size_t)node]];   // every node of the frame's OTHER cameras
+        if (e >= (1ll << 31) - 64) return -(int64_t)GNNCCA_ERR_UNSUPPORTED;      // more than 2^31 edges in one batch
+    }
+    o_edge_ptr[n] = (int32_t)e;
+    for (int64_t q = 0; q <= g; ++q) o_edge_ptr_g[q] = o_edge_ptr[o_graph_ptr[q]];   // edges are emitted frame by frame
+    return (int64_t)e;
 }
 
 }  // extern "C"

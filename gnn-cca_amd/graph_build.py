@@ -51,18 +51,71 @@ def plan_frames(id_cam, graph_sizes):
     return FramePlan(src_order, edge_ptr.astype(np.int32), graph_ptr, graph_of, int(edge_ptr[-1]))
 
 
+def _raw_stream(dev):
+    return torch._C._cuda_getCurrentRawStream(dev.index)
+
+
+class _on:
+    """`with torch.cuda.device(dev)` only when `dev` is not the current device already (the context manager costs ~5 us of host
+    time per use, more than a launch)."""
+
+    def __init__(self, dev):
+        self._ctx = None if torch.cuda.current_device() == dev.index else torch.cuda.device(dev)
+
+    def __enter__(self):
+        if self._ctx is not None:
+            self._ctx.__enter__()
+
+    def __exit__(self, *a):
+        if self._ctx is not None:
+            self._ctx.__exit__(*a)
+
+
 def normalize_columns(x):
     """F.normalize(x, p=2, dim=0) (inference.py:189-190) as a HIP kernel pair; returns a new tensor."""
     if not x.is_cuda:
         raise RuntimeError("gnn_cca_amd.graph_build runs on MI355X only (no CPU fallback)")
-    x = x.float().contiguous()
+    if x.dtype != torch.float32 or not x.is_contiguous():
+        x = x.float().contiguous()
     out = torch.empty_like(x)
     scratch = torch.empty(((x.shape[0] + 63) // 64 + 1) * x.shape[1], dtype=torch.float32, device=x.device)  # 64-row chunk sums + norms
-    with torch.cuda.device(x.device):
-        st = nat.lib().gnncca_normalize_columns(x.data_ptr(), x.shape[0], x.shape[1], scratch.data_ptr(), out.data_ptr(),
-                                                torch.cuda.current_stream(x.device).cuda_stream)
-    nat.check(st, "gnncca_normalize_columns")
+    with _on(x.device):
+        st = nat.lib().gnncca_normalize_columns(x.data_ptr(), x.shape[0], x.shape[1], scratch.data_ptr(), out.data_ptr(), _raw_stream(x.device))
+    if st:
+        nat.check(st, "gnncca_normalize_columns")
     return out
+
+
+class _Staging:
+    """Ring of pinned host buffers for the per-batch staging image (gnncca_plan_frames writes it, ONE non-blocking copy uploads
+    it): the host never waits for the GPU, so the graph of the next batch of frames is planned while this one's kernels run.
+    A slot is reused only after the copy that read it has completed (its event)."""
+    SLOTS = 8
+
+    def __init__(self):
+        self._bufs, self._events, self._next = [None] * self.SLOTS, [None] * self.SLOTS, 0
+
+    def take(self, nbytes):
+        i = self._next
+        self._next = (i + 1) % self.SLOTS
+        if self._events[i] is not None:
+            self._events[i].synchronize()
+        buf = self._bufs[i]
+        if buf is None or buf.numel() < nbytes:
+            buf = self._bufs[i] = torch.empty(max(2 * nbytes, 1 << 16), dtype=torch.uint8, pin_memory=True)
+        if self._events[i] is None:
+            self._events[i] = torch.cuda.Event()
+        return buf, self._events[i]
+
+
+_staging = {}
+
+
+def _as(a, dtype):
+    a = np.asarray(a)
+    if a.dtype != dtype or not a.flags.c_contiguous:
+        a = np.ascontiguousarray(a, dtype=dtype)
+    return a
 
 
 def build_graph_batch(xw, yw, ids, id_cam, graph_sizes, max_dist, node_embeds, reid_embeds, only_appearance=False,
@@ -70,52 +123,66 @@ def build_graph_batch(xw, yw, ids, id_cam, graph_sizes, max_dist, node_embeds, r
     """One call per batch of frames.  Host inputs (numpy, one entry per detection, frames concatenated): xw, yw, ids,
     id_cam; graph_sizes / max_dist per frame.  Device inputs: node_embeds [N, D], reid_embeds [N, R].
     Returns a GraphBatch (x, edge_index, edge_attr) with .edge_labels and .y, laid out exactly like the reference's
-    `Batch.from_data_list(batch)` (inference.py:279)."""
+    `Batch.from_data_list(batch)` (inference.py:279).
+    Host work: one native call that enumerates the edges (gnncca_plan_frames, include/gnncca_mpn.h) into a pinned staging buffer,
+    one non-blocking upload, four launches; the call never synchronises."""
     if not (node_embeds.is_cuda and reid_embeds.is_cuda):
         raise RuntimeError("gnn_cca_amd.graph_build runs on MI355X only (no CPU fallback)")
     dev = reid_embeds.device
-    plan = plan_frames(id_cam, graph_sizes)
-    n, e = len(plan.src_order), plan.n_edges
+    lib = nat.lib()
+    xw, yw, md = _as(xw, np.float64), _as(yw, np.float64), _as(max_dist, np.float64)
+    ids64, cam64, sizes = _as(ids, np.int64), _as(id_cam, np.int64), _as(graph_sizes, np.int64)
+    n, g = len(cam64), len(sizes)
+    if not (len(xw) == len(yw) == len(ids64) == n) or len(md) != g:
+        raise ValueError("per-detection / per-frame arrays disagree on their lengths")
     if reid_embeds.shape[0] != n or node_embeds.shape[0] != n:
         raise RuntimeError("embeddings and detections disagree on the number of nodes")
-    if normalize:
-        reid_embeds = normalize_columns(reid_embeds)
-        node_embeds = normalize_columns(node_embeds)
-    else:
-        reid_embeds = reid_embeds.float().contiguous()
-    mode = MODE_ONLY_APPEARANCE if only_appearance else (MODE_ONLY_DIST if only_dist else MODE_FULL)
-    n_attr = 4 if mode == MODE_FULL else 2
-    _, dense_ids = np.unique(np.asarray(ids), return_inverse=True)
-    # ONE host->device transfer with every per-node / per-graph array: 8-byte fields first, then the int32 ones
-    g = len(plan.graph_ptr) - 1
-    ids64 = np.ascontiguousarray(ids, dtype=np.int64)
-    f64 = np.concatenate([np.asarray(xw, np.float64), np.asarray(yw, np.float64), np.asarray(max_dist, np.float64)])
-    edge_ptr_g = plan.edge_ptr[plan.graph_ptr]  # edges are emitted graph by graph: graph g owns [edge_ptr_g[g], edge_ptr_g[g+1])
-    i32 = np.concatenate([dense_ids.astype(np.int32), np.asarray(id_cam).astype(np.int32), plan.graph_of, plan.graph_ptr,
-                          plan.src_order, plan.edge_ptr, edge_ptr_g.astype(np.int32)])
-    host = np.concatenate([f64.view(np.uint8), ids64.view(np.uint8), i32.view(np.uint8)])
-    staged = torch.from_numpy(host).to(dev)
-    fr = nat.Frames()
-    p0 = staged.data_ptr()
-    fr.xw, fr.yw, fr.max_dist = p0, p0 + 8 * n, p0 + 16 * n
-    y_off = 8 * (2 * n + g)
-    base, o = p0 + y_off + 8 * n, 0
-    for name, cnt in (("person_id", n), ("cam", n), ("graph_of", n), ("graph_ptr", g + 1), ("src_order", n), ("edge_ptr", n + 1)):
-        setattr(fr, name, base + 4 * o)
-        o += cnt
-    edge_index = torch.empty((2, e), dtype=torch.int64, device=dev)
-    edge_attr = torch.empty((e, n_attr), dtype=torch.float32, device=dev)
-    edge_labels = torch.empty(e, dtype=torch.float32, device=dev)
-    if e > 0:
-        with torch.cuda.device(dev):
-            st = nat.lib().gnncca_build_edges(C.byref(fr), reid_embeds.data_ptr(), reid_embeds.shape[1], n, e, mode,
-                                              edge_index.data_ptr(), edge_attr.data_ptr(), edge_labels.data_ptr(),
-                                              torch.cuda.current_stream(dev).cuda_stream)
-        nat.check(st, "gnncca_build_edges")
-    # per-graph edge ranges: edges are emitted graph by graph, so graph g owns edge_ptr[graph_ptr[g]] .. edge_ptr[graph_ptr[g+1]]
-    batch = GraphBatch(node_embeds, edge_index, edge_attr, edge_ptr_g.tolist(), plan.graph_ptr.tolist())
+    nbytes = lib.gnncca_plan_frames_bytes(n, g)
+    ring = _staging.get(dev.index)
+    if ring is None:
+        ring = _staging[dev.index] = _Staging()
+    pinned, event = ring.take(nbytes)
+    e = lib.gnncca_plan_frames(xw.ctypes.data, yw.ctypes.data, ids64.ctypes.data, cam64.ctypes.data, n, sizes.ctypes.data, md.ctypes.data, g,
+                               pinned.data_ptr(), nbytes)
+    if e < 0:
+        if -e == nat.ERR_INVALID_ARG:
+            raise ValueError("id_cam length does not match graph_sizes")
+        nat.check(int(-e), "gnncca_plan_frames")
+    with _on(dev):
+        staged = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        staged.copy_(pinned[:nbytes], non_blocking=True)
+        event.record()
+        if normalize:
+            reid_embeds = normalize_columns(reid_embeds)
+            node_embeds = normalize_columns(node_embeds)
+        elif reid_embeds.dtype != torch.float32 or not reid_embeds.is_contiguous():
+            reid_embeds = reid_embeds.float().contiguous()
+        mode = MODE_ONLY_APPEARANCE if only_appearance else (MODE_ONLY_DIST if only_dist else MODE_FULL)
+        n_attr = 4 if mode == MODE_FULL else 2
+        fr = nat.Frames()
+        p0 = staged.data_ptr()
+        fr.xw, fr.yw, fr.max_dist = p0, p0 + 8 * n, p0 + 16 * n
+        y_off = 8 * (2 * n + g)
+        i32_off = y_off + 8 * n
+        base = p0 + i32_off
+        fr.person_id, fr.cam, fr.graph_of = base, base + 4 * n, base + 8 * n
+        fr.graph_ptr, fr.src_order, fr.edge_ptr = base + 12 * n, base + 4 * (3 * n + g + 1), base + 4 * (4 * n + g + 1)
+        edge_index = torch.empty((2, e), dtype=torch.int64, device=dev)
+        edge_attr = torch.empty((e, n_attr), dtype=torch.float32, device=dev)
+        edge_labels = torch.empty(e, dtype=torch.float32, device=dev)
+        if e > 0:
+            st = lib.gnncca_build_edges(C.byref(fr), reid_embeds.data_ptr(), reid_embeds.shape[1], n, e, mode,
+                                        edge_index.data_ptr(), edge_attr.data_ptr(), edge_labels.data_ptr(), _raw_stream(dev))
+            if st:
+                nat.check(st, "gnncca_build_edges")
+    # per-graph ranges (host copies): graph g owns the nodes graph_ptr[g] .. graph_ptr[g+1] and, edges being emitted graph by graph,
+    # the edges edge_ptr_g[g] .. edge_ptr_g[g+1]
+    host_i32 = pinned[i32_off:nbytes].numpy().view(np.int32)
+    node_ptr = host_i32[3 * n:3 * n + g + 1].tolist()
+    edge_ptr = host_i32[5 * n + g + 2:5 * n + 2 * g + 3].tolist()
+    batch = GraphBatch(node_embeds, edge_index, edge_attr, edge_ptr, node_ptr)
     # device copies of the frame ranges (int32 [G + 1]) for the per-frame post-processing (postprocess.prune_and_cluster)
-    i32_dev = staged[y_off + 8 * n:].view(torch.int32)
+    i32_dev = staged[i32_off:].view(torch.int32)
     batch.node_ptr_dev = i32_dev[3 * n:3 * n + g + 1]
     batch.edge_ptr_dev = i32_dev[5 * n + g + 2:5 * n + 2 * g + 3]
     batch.edge_labels = edge_labels

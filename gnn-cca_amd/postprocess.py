@@ -10,20 +10,22 @@ import torch
 from . import _native as nat
 
 
-def _stream(dev):
-    return torch.cuda.current_stream(dev).cuda_stream
+from .graph_build import _on, _raw_stream as _stream   # the lean device guard / raw stream handle (host time matters here: ~6 launches)
 
 
 def threshold(logits):
     """logits: Tensor[E] or [E,1] on the GPU -> (probs float32 [E], predictions int64 [E])."""
     if not logits.is_cuda:
         raise RuntimeError("gnn_cca_amd.postprocess runs on MI355X only (no CPU fallback)")
-    x = logits.reshape(-1).float().contiguous()
+    x = logits.reshape(-1)
+    if x.dtype != torch.float32 or not x.is_contiguous():
+        x = x.float().contiguous()
     probs = torch.empty_like(x)
     preds = torch.empty(x.shape[0], dtype=torch.int64, device=x.device)
-    with torch.cuda.device(x.device):
-        nat.check(nat.lib().gnncca_post_threshold(x.data_ptr(), x.shape[0], probs.data_ptr(), preds.data_ptr(),
-                                                  _stream(x.device)), "gnncca_post_threshold")
+    with _on(x.device):
+        st = nat.lib().gnncca_post_threshold(x.data_ptr(), x.shape[0], probs.data_ptr(), preds.data_ptr(), _stream(x.device))
+    if st:
+        nat.check(st, "gnncca_post_threshold")
     return probs, preds
 
 
@@ -37,8 +39,10 @@ def prune_and_cluster(edge_index, predictions, n_nodes, node_ptr=None, edge_ptr=
     if not (edge_index.is_cuda and predictions.is_cuda):
         raise RuntimeError("gnn_cca_amd.postprocess runs on MI355X only (no CPU fallback)")
     dev = edge_index.device
-    ei = edge_index.long().contiguous()
-    pred = predictions.reshape(-1).long().contiguous()
+    ei = edge_index if edge_index.dtype == torch.int64 and edge_index.is_contiguous() else edge_index.long().contiguous()
+    pred = predictions.reshape(-1)
+    if pred.dtype != torch.int64 or not pred.is_contiguous():
+        pred = pred.long().contiguous()
     e = ei.shape[1]
     lib = nat.lib()
     ws = torch.empty(lib.gnncca_post_workspace_bytes(n_nodes, e) + 256, dtype=torch.uint8, device=dev)
@@ -53,19 +57,22 @@ def prune_and_cluster(edge_index, predictions, n_nodes, node_ptr=None, edge_ptr=
     if node_ptr is not None:
         def as_dev(v):
             if torch.is_tensor(v):
+                if v.dtype == torch.int32 and v.device == dev and v.is_contiguous():
+                    return v
                 return v.to(device=dev, dtype=torch.int32).contiguous()
             return torch.tensor(list(v), dtype=torch.int32).to(dev)
         np_dev, ep_dev = as_dev(node_ptr), as_dev(edge_ptr)
         n_frames = np_dev.numel() - 1
         if ep_dev.numel() != n_frames + 1 or n_frames < 1:
             raise ValueError("node_ptr / edge_ptr must both have G + 1 entries")
-    with torch.cuda.device(dev):
+    with _on(dev):
         st = lib.gnncca_post_prune_cluster_frames(ei.data_ptr(), pred.data_ptr(), n_nodes, e,
                                                   np_dev.data_ptr() if np_dev is not None else None,
                                                   ep_dev.data_ptr() if ep_dev is not None else None, n_frames,
                                                   ws.data_ptr(), ws.numel(), out["pruned"].data_ptr(),
                                                   out["flow_out"].data_ptr(), out["flow_in"].data_ptr(),
                                                   out["labels"].data_ptr(), out["n_clusters"].data_ptr(), _stream(dev))
-    nat.check(st, "gnncca_post_prune_cluster")
+    if st:
+        nat.check(st, "gnncca_post_prune_cluster")
     out["_workspace"] = (ws, np_dev, ep_dev)
     return out

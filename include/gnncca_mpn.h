@@ -234,6 +234,19 @@ enum { GNNCCA_EDGE_ATTR_FULL = 0, GNNCCA_EDGE_ATTR_ONLY_APPEARANCE = 1, GNNCCA_E
 GNNCCA_API int gnncca_normalize_columns(const float* x, int64_t n_rows, int64_t n_cols, float* scratch,
                                         float* out, gnncca_stream_t stream);
 
+/* HOST side of the graph construction: the edge enumeration of a batch of frames (inference.py:207-212: per frame, cameras in
+ * np.unique order, a camera's nodes in ascending id, each connected to every node of the OTHER cameras) and the staging image that
+ * gnncca_build_edges reads, written into host memory `staging` (pinned memory lets the caller upload it without blocking):
+ *   f64 xw[n], yw[n], max_dist[g];  i64 ids[n];  i32 person[n], cam[n], graph_of[n], graph_ptr[g+1], src_order[n], edge_ptr[n+1],
+ *   edge_ptr_g[g+1]  (first edge of each frame)
+ * -- the fields of gnncca_frames at those offsets once uploaded.  All inputs are host arrays, one entry per detection (frames
+ * concatenated) or per frame.  Returns the number of edges E >= 0, or -status (graph_sizes that do not sum to n: INVALID_ARG;
+ * 2^31 edges or more: UNSUPPORTED).  Replaces the Python list comprehensions of inference.py:199-216. */
+GNNCCA_API size_t gnncca_plan_frames_bytes(int64_t n_nodes, int64_t n_frames);
+GNNCCA_API int64_t gnncca_plan_frames(const double* xw, const double* yw, const int64_t* ids, const int64_t* id_cam, int64_t n_nodes,
+                                      const int64_t* graph_sizes, const double* max_dist, int64_t n_frames, void* staging,
+                                      size_t staging_bytes);
+
 /* edge_index [2][E] int64, edge_attr [E][4 or 2] fp32, edge_labels [E] fp32 in the reference's edge order:
  * cartesian_prod per camera (inference.py:207-212), ground-plane L2 and L1 distance / max_dist in float64 then
  * cast (229-242), F.pairwise_distance and F.cosine_similarity of the reid rows (222-226), same-identity labels
