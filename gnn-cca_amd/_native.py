@@ -122,6 +122,7 @@ _SIGNATURES = {
     "gnncca_train_backward": (C.c_int, [C.POINTER(MpnDims), C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_int64, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_void_p),
                                         C.POINTER(Dropout), C.c_void_p]),
+    "gnncca_normalize_columns2": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
     "gnncca_plan_frames_bytes": (C.c_size_t, [C.c_int64, C.c_int64]),
     "gnncca_plan_frames": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                                        C.c_size_t]),

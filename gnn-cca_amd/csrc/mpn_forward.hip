@@ -706,7 +706,10 @@ int gnncca_post_prune_cluster_frames(const int64_t* edge_index, const int64_t* p
     if ((node_ptr_dev == nullptr) != (edge_ptr_dev == nullptr) || (node_ptr_dev != nullptr && n_frames == 0))
         return GNNCCA_ERR_INVALID_ARG;
     if (n_nodes >= (1ll << 31) - 64 || n_edges >= (1ll << 31) - 64) return GNNCCA_ERR_UNSUPPORTED;
-    if (n_nodes == 0) return GNNCCA_OK;
+    if (n_nodes == 0) {
+        if (n_clusters_out) HIP_TRY(hipMemsetAsync(n_clusters_out, 0, sizeof(int32_t), static_cast<hipStream_t>(stream)));
+        return GNNCCA_OK;
+    }
     if (!workspace || !flow_out || !flow_in || !labels_out || !n_clusters_out) return GNNCCA_ERR_INVALID_ARG;
     if (n_edges > 0 && (!edge_index || !predictions || !pruned_out)) return GNNCCA_ERR_INVALID_ARG;
     if (workspace_bytes < gnncca_post_workspace_bytes(n_nodes, n_edges)) return GNNCCA_ERR_WORKSPACE;
@@ -728,8 +731,15 @@ int gnncca_post_prune_cluster_frames(const int64_t* edge_index, const int64_t* p
     const long long* ei = reinterpret_cast<const long long*>(edge_index);
     const long long* pred = reinterpret_cast<const long long*>(predictions);
     long long* pruned = reinterpret_cast<long long*>(pruned_out);
-    HIP_TRY(hipMemsetAsync(flow_out, 0, (size_t)N * 4, st));
-    HIP_TRY(hipMemsetAsync(flow_in, 0, (size_t)N * 4, st));
+    // zero the counters: one memset when the caller laid flow_out | flow_in | n_clusters out back to back (gnn_cca_amd.postprocess does)
+    const bool one_block = flow_in == flow_out + N && n_clusters_out == flow_in + N;
+    if (one_block) {
+        HIP_TRY(hipMemsetAsync(flow_out, 0, ((size_t)2 * N + 1) * 4, st));
+    } else {
+        HIP_TRY(hipMemsetAsync(flow_out, 0, (size_t)N * 4, st));
+        HIP_TRY(hipMemsetAsync(flow_in, 0, (size_t)N * 4, st));
+        HIP_TRY(hipMemsetAsync(n_clusters_out, 0, sizeof(int32_t), st));
+    }
     if (E > 0) {
         EncPlanParams ep;
         std::memset(&ep, 0, sizeof(ep));
@@ -747,13 +757,9 @@ int gnncca_post_prune_cluster_frames(const int64_t* edge_index, const int64_t* p
     HIP_TRY(hipGetLastError());
     if (E > 0) {
         hipLaunchKernelGGL(post_prune_kernel, grid1((size_t)E, 256), dim3(256), 0, st, ei, pred, (long long)E, (const int*)seg_ptr,
-                           (const int*)col32, (const int*)perm, (const unsigned*)flags, pruned);
-        HIP_TRY(hipGetLastError());
-        hipLaunchKernelGGL(post_flow_kernel, grid1((size_t)E, 256), dim3(256), 0, st, ei, (const long long*)pruned, (long long)E, N,
-                           flow_out, flow_in);
+                           (const int*)col32, (const int*)perm, (const unsigned*)flags, pruned, flow_out, flow_in);
         HIP_TRY(hipGetLastError());
     }
-    HIP_TRY(hipMemsetAsync(n_clusters_out, 0, sizeof(int32_t), st));
     hipLaunchKernelGGL(post_cc_kernel, dim3(node_ptr_dev ? (unsigned)n_frames : 1u), dim3(1024), 0, st, ei,
                        (const long long*)pruned, (long long)E, N, node_ptr_dev, edge_ptr_dev, labels_out, n_clusters_out);
     HIP_TRY(hipGetLastError());

@@ -21,7 +21,8 @@ __global__ __launch_bounds__(256) void post_threshold_kernel(const float* __rest
 __global__ __launch_bounds__(256) void post_prune_kernel(const long long* __restrict__ ei, const long long* __restrict__ pred,
                                                          long long E, const int* __restrict__ seg_ptr,
                                                          const int* __restrict__ col32, const int* __restrict__ perm,
-                                                         const unsigned* __restrict__ flags, long long* __restrict__ out) {
+                                                         const unsigned* __restrict__ flags, long long* __restrict__ out,
+                                                         int* __restrict__ flow_out, int* __restrict__ flow_in) {
     const long long k = (long long)blockIdx.x * 256 + threadIdx.x;
     if (k >= E) return;
     const unsigned fl = flags[0];
@@ -39,18 +40,14 @@ __global__ __launch_bounds__(256) void post_prune_kernel(const long long* __rest
                 break;
             }
         }
+        // the flow counts of the pruned edge set (libs/utils.py:54-59) in the same pass (a launch of its own until round 4);
+        // the indices are in range here (no BAD_INDEX).  Integer counts: order-independent.
+        if (keep && flow_out) {
+            atomicAdd(&flow_out[i], 1);
+            atomicAdd(&flow_in[j], 1);
+        }
     }
     out[k] = keep;
-}
-
-__global__ __launch_bounds__(256) void post_flow_kernel(const long long* __restrict__ ei, const long long* __restrict__ pred,
-                                                        long long E, int N, int* __restrict__ flow_out, int* __restrict__ flow_in) {
-    const long long k = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (k >= E || pred[k] != 1) return;
-    const long long i = ei[k], j = ei[E + k];
-    if (i < 0 || i >= N || j < 0 || j >= N) return;
-    atomicAdd(&flow_out[i], 1);  // integer counts: order-independent
-    atomicAdd(&flow_in[j], 1);
 }
 
 // Connected components of the active edges by hooking + pointer jumping inside one workgroup.  labels[v] = smallest

@@ -71,19 +71,40 @@ class _on:
             self._ctx.__exit__(*a)
 
 
-def normalize_columns(x):
-    """F.normalize(x, p=2, dim=0) (inference.py:189-190) as a HIP kernel pair; returns a new tensor."""
-    if not x.is_cuda:
+FUSED_NORMALIZE_MAX_ROWS = 4096   # gnncca_normalize_columns2: one launch for up to two matrices of a batch of frames
+
+
+def _f32c(x):
+    return x if x.dtype == torch.float32 and x.is_contiguous() else x.float().contiguous()
+
+
+def normalize_columns(x, other=None):
+    """F.normalize(x, p=2, dim=0) (inference.py:189-190) on the GPU; returns a new tensor -- or, given a second matrix with the same
+    number of rows (`other`: the reid and the node embeddings of a batch), the pair, normalised in one launch when the batch has at
+    most 4096 rows (same bits as the three-kernel form, which takes any size)."""
+    if not x.is_cuda or (other is not None and not other.is_cuda):
         raise RuntimeError("gnn_cca_amd.graph_build runs on MI355X only (no CPU fallback)")
-    if x.dtype != torch.float32 or not x.is_contiguous():
-        x = x.float().contiguous()
+    x = _f32c(x)
     out = torch.empty_like(x)
-    scratch = torch.empty(((x.shape[0] + 63) // 64 + 1) * x.shape[1], dtype=torch.float32, device=x.device)  # 64-row chunk sums + norms
+    if other is not None:
+        other = _f32c(other)
+        if other.shape[0] != x.shape[0]:
+            raise ValueError("normalize_columns(x, other): both matrices must have the same number of rows")
+        out2 = torch.empty_like(other)
+    lib = nat.lib()
     with _on(x.device):
-        st = nat.lib().gnncca_normalize_columns(x.data_ptr(), x.shape[0], x.shape[1], scratch.data_ptr(), out.data_ptr(), _raw_stream(x.device))
+        if x.shape[0] <= FUSED_NORMALIZE_MAX_ROWS and x.dim() == 2:
+            st = lib.gnncca_normalize_columns2(x.data_ptr(), x.shape[1], out.data_ptr(), other.data_ptr() if other is not None else None,
+                                               other.shape[1] if other is not None else 0, out2.data_ptr() if other is not None else None,
+                                               x.shape[0], _raw_stream(x.device))
+        else:
+            st = 0
+            for a, o in ((x, out),) + (((other, out2),) if other is not None else ()):
+                scratch = torch.empty(((a.shape[0] + 63) // 64 + 1) * a.shape[1], dtype=torch.float32, device=a.device)  # 64-row chunk sums + norms
+                st = st or lib.gnncca_normalize_columns(a.data_ptr(), a.shape[0], a.shape[1], scratch.data_ptr(), o.data_ptr(), _raw_stream(a.device))
     if st:
         nat.check(st, "gnncca_normalize_columns")
-    return out
+    return out if other is None else (out, out2)
 
 
 class _Staging:
@@ -153,8 +174,7 @@ def build_graph_batch(xw, yw, ids, id_cam, graph_sizes, max_dist, node_embeds, r
         staged.copy_(pinned[:nbytes], non_blocking=True)
         event.record()
         if normalize:
-            reid_embeds = normalize_columns(reid_embeds)
-            node_embeds = normalize_columns(node_embeds)
+            reid_embeds, node_embeds = normalize_columns(reid_embeds, node_embeds)
         elif reid_embeds.dtype != torch.float32 or not reid_embeds.is_contiguous():
             reid_embeds = reid_embeds.float().contiguous()
         mode = MODE_ONLY_APPEARANCE if only_appearance else (MODE_ONLY_DIST if only_dist else MODE_FULL)

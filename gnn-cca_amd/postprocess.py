@@ -46,11 +46,11 @@ def prune_and_cluster(edge_index, predictions, n_nodes, node_ptr=None, edge_ptr=
     e = ei.shape[1]
     lib = nat.lib()
     ws = torch.empty(lib.gnncca_post_workspace_bytes(n_nodes, e) + 256, dtype=torch.uint8, device=dev)
+    counters = torch.empty(2 * n_nodes + 1, dtype=torch.int32, device=dev)   # flow_out | flow_in | n_clusters: zeroed by ONE memset
     out = {"pruned": torch.empty(e, dtype=torch.int64, device=dev),
-           "flow_out": torch.empty(n_nodes, dtype=torch.int32, device=dev),
-           "flow_in": torch.empty(n_nodes, dtype=torch.int32, device=dev),
+           "flow_out": counters[:n_nodes], "flow_in": counters[n_nodes:2 * n_nodes],
            "labels": torch.empty(n_nodes, dtype=torch.int32, device=dev),
-           "n_clusters": torch.zeros(1, dtype=torch.int32, device=dev)}
+           "n_clusters": counters[2 * n_nodes:]}
     if (node_ptr is None) != (edge_ptr is None):
         raise ValueError("node_ptr and edge_ptr go together")
     n_frames, np_dev, ep_dev = 0, None, None

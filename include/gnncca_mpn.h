@@ -233,6 +233,11 @@ enum { GNNCCA_EDGE_ATTR_FULL = 0, GNNCCA_EDGE_ATTR_ONLY_APPEARANCE = 1, GNNCCA_E
  * scratch: (ceil(n_rows/64) + 1) * n_cols floats. */
 GNNCCA_API int gnncca_normalize_columns(const float* x, int64_t n_rows, int64_t n_cols, float* scratch,
                                         float* out, gnncca_stream_t stream);
+/* The same for up to TWO matrices of n_rows <= 4096 rows (the reid and the node embeddings of a batch of frames,
+ * inference.py:189-190) in ONE launch; bit for bit gnncca_normalize_columns' results.  x1 may be NULL (n_cols1 = 0).
+ * More rows: GNNCCA_ERR_UNSUPPORTED (use gnncca_normalize_columns). */
+GNNCCA_API int gnncca_normalize_columns2(const float* x0, int64_t n_cols0, float* out0, const float* x1, int64_t n_cols1,
+                                         float* out1, int64_t n_rows, gnncca_stream_t stream);
 
 /* HOST side of the graph construction: the edge enumeration of a batch of frames (inference.py:207-212: per frame, cameras in
  * np.unique order, a camera's nodes in ascending id, each connected to every node of the OTHER cameras) and the staging image that

@@ -81,3 +81,53 @@ def test_end_to_end_into_mpn():
                                                             a["edge_attr"])
     for o, r in zip(out, ref):
         assert np.abs(o.cpu().numpy() - r).max() <= 1e-5
+
+
+@pytest.mark.parametrize("rows,cols,cols2", [(1229, 2048, 256), (37, 512, 0), (4096, 130, 7), (1, 5, 3), (65, 33, 2048)])
+def test_one_launch_normalisation_is_bitwise_the_three_kernel_form(rows, cols, cols2):
+    """gnncca_normalize_columns2 (one launch, up to two matrices: what build_graph_batch uses for batches of <= 4096 detections) against
+    gnncca_normalize_columns (three launches, any size) on the same matrices: the same bits, and the oracle within rounding."""
+    from gnn_cca_amd import _native as nat
+    from gnn_cca_amd.graph_build import normalize_columns
+    g = torch.Generator().manual_seed(rows * 7 + cols)
+    a = (torch.randn((rows, cols), generator=g) * 3).cuda()
+    b = torch.rand((rows, cols2), generator=g).cuda() if cols2 else None
+    if b is not None and cols2 > 2:
+        b[:, 1] = 0.0                      # a zero column: the norm clamps at 1e-12, the column stays zero
+    lib = nat.lib()
+
+    def three(x):
+        out = torch.empty_like(x)
+        scratch = torch.empty(((rows + 63) // 64 + 1) * x.shape[1], dtype=torch.float32, device="cuda")
+        nat.check(lib.gnncca_normalize_columns(x.data_ptr(), rows, x.shape[1], scratch.data_ptr(), out.data_ptr(),
+                                               torch.cuda.current_stream().cuda_stream), "three-kernel form")
+        return out
+    if b is None:
+        got = normalize_columns(a)
+        assert torch.equal(got, three(a))
+    else:
+        got, got_b = normalize_columns(a, b)
+        assert torch.equal(got, three(a)) and torch.equal(got_b, three(b))
+        assert np.abs(got_b.cpu().numpy() - graph_oracle.normalize_columns(b.cpu().numpy())).max() <= 2.5e-7
+    assert np.abs(got.cpu().numpy() - graph_oracle.normalize_columns(a.cpu().numpy())).max() <= 2.5e-7
+    # an unaligned view (odd row offset of an odd-width matrix) takes the scalar path of both forms
+    if cols % 2 == 1 and rows > 2:
+        v = a.reshape(-1)[1:1 + (rows - 1) * cols].view(rows - 1, cols)
+        assert v.data_ptr() % 16 != 0
+        out = torch.empty((rows - 1, cols), device="cuda")
+        nat.check(lib.gnncca_normalize_columns2(v.data_ptr(), cols, out.data_ptr(), None, 0, None, rows - 1,
+                                                torch.cuda.current_stream().cuda_stream), "one-launch form")
+        assert np.abs(out.cpu().numpy() - graph_oracle.normalize_columns(v.cpu().numpy())).max() <= 2.5e-7
+
+
+def test_normalisation_beyond_4096_rows_takes_the_three_kernel_form():
+    from gnn_cca_amd import _native as nat
+    from gnn_cca_amd.graph_build import normalize_columns
+    a = torch.randn((5000, 64), generator=torch.Generator().manual_seed(1)).cuda()
+    b = torch.randn((5000, 16), generator=torch.Generator().manual_seed(2)).cuda()
+    got, got_b = normalize_columns(a, b)
+    assert np.abs(got.cpu().numpy() - graph_oracle.normalize_columns(a.cpu().numpy())).max() <= 2.5e-7
+    assert np.abs(got_b.cpu().numpy() - graph_oracle.normalize_columns(b.cpu().numpy())).max() <= 2.5e-7
+    out = torch.empty_like(a)
+    st = nat.lib().gnncca_normalize_columns2(a.data_ptr(), 64, out.data_ptr(), None, 0, None, 5000, torch.cuda.current_stream().cuda_stream)
+    assert st == nat.ERR_UNSUPPORTED

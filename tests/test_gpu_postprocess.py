@@ -95,3 +95,42 @@ def test_frames_mode_equals_single_workgroup():
         for k in ("pruned", "flow_out", "flow_in", "labels", "n_clusters"):
             assert torch.equal(out[k], ref[k]), k
     assert int(ref["n_clusters"]) >= frames
+
+
+def test_separate_counter_buffers_and_empty_inputs():
+    """The C entry zeroes flow_out / flow_in / n_clusters itself whether or not the caller laid them out back to back (one memset or
+    three), on buffers that held garbage; N = 0 gives zero clusters."""
+    import ctypes as C
+
+    from gnn_cca_amd import _native as nat
+    from gnn_cca_amd.postprocess import prune_and_cluster
+    from oracle import post_oracle as po
+    rng = np.random.default_rng(3)
+    n = 50
+    ei = np.array([(i, j) for i in range(n) for j in range(n) if i != j and (i + j) % 3], dtype=np.int64).T.copy()
+    pred = (rng.random(ei.shape[1]) < 0.4).astype(np.int64)
+    want_pruned = po.prune(ei, pred)
+    lab, k = po.clusters(ei, want_pruned, n)
+    fo = np.bincount(ei[0][want_pruned == 1], minlength=n)
+    fi = np.bincount(ei[1][want_pruned == 1], minlength=n)
+    d_ei, d_pred = torch.from_numpy(ei).cuda(), torch.from_numpy(pred).cuda()
+    out = prune_and_cluster(d_ei, d_pred, n)                    # the module's layout: one block, one memset
+    assert np.array_equal(out["flow_out"].cpu().numpy(), fo) and np.array_equal(out["flow_in"].cpu().numpy(), fi)
+    assert int(out["n_clusters"].item()) == k and np.array_equal(out["pruned"].cpu().numpy(), want_pruned)
+    lib = nat.lib()
+    e = ei.shape[1]
+    ws = torch.empty(lib.gnncca_post_workspace_bytes(n, e) + 256, dtype=torch.uint8, device="cuda")
+    bufs = [torch.full((m,), 12345, dtype=torch.int32, device="cuda") for m in (n, n, n, 1)]    # separate, dirty buffers
+    pruned = torch.empty(e, dtype=torch.int64, device="cuda")
+    st = lib.gnncca_post_prune_cluster_frames(d_ei.data_ptr(), d_pred.data_ptr(), n, e, None, None, 0, ws.data_ptr(), ws.numel(),
+                                              pruned.data_ptr(), bufs[0].data_ptr(), bufs[1].data_ptr(), bufs[2].data_ptr(),
+                                              bufs[3].data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert st == 0
+    assert np.array_equal(bufs[0].cpu().numpy(), fo) and np.array_equal(bufs[1].cpu().numpy(), fi) and int(bufs[3].item()) == k
+    assert po.same_partition(bufs[2].cpu().numpy(), lab)
+    # no nodes at all
+    out = prune_and_cluster(torch.zeros((2, 0), dtype=torch.int64, device="cuda"), torch.zeros(0, dtype=torch.int64, device="cuda"), 0)
+    assert int(out["n_clusters"].item()) == 0 and out["labels"].numel() == 0
+    # nodes without edges: every node its own cluster, zero flows
+    out = prune_and_cluster(torch.zeros((2, 0), dtype=torch.int64, device="cuda"), torch.zeros(0, dtype=torch.int64, device="cuda"), 7)
+    assert int(out["n_clusters"].item()) == 7 and int(out["flow_out"].abs().sum()) == 0 and int(out["flow_in"].abs().sum()) == 0
