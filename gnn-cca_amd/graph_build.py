@@ -55,6 +55,18 @@ def _raw_stream(dev):
     return torch._C._cuda_getCurrentRawStream(dev.index)
 
 
+_stream_objs = {}
+
+
+def _current_stream(dev):
+    """torch.cuda.current_stream(dev) through a cache keyed by the raw handle (the call itself costs ~10 us of host time)."""
+    raw = _raw_stream(dev)
+    hit = _stream_objs.get(dev.index)
+    if hit is None or hit[0] != raw:
+        hit = _stream_objs[dev.index] = (raw, torch.cuda.current_stream(dev))
+    return hit[1]
+
+
 class _on:
     """`with torch.cuda.device(dev)` only when `dev` is not the current device already (the context manager costs ~5 us of host
     time per use, more than a launch)."""
@@ -172,7 +184,7 @@ def build_graph_batch(xw, yw, ids, id_cam, graph_sizes, max_dist, node_embeds, r
     with _on(dev):
         staged = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         staged.copy_(pinned[:nbytes], non_blocking=True)
-        event.record()
+        event.record(_current_stream(dev))
         if normalize:
             reid_embeds, node_embeds = normalize_columns(reid_embeds, node_embeds)
         elif reid_embeds.dtype != torch.float32 or not reid_embeds.is_contiguous():
