@@ -419,6 +419,10 @@ class PaddedForward:
             self._gf._drop_stale(stamp)
             self._make_slots(data)
             self._stamp0 = stamp
+        if data.x.dim() != 2 or data.edge_attr.dim() != 2 or data.x.shape[1] != self._node_in or data.edge_attr.shape[1] != self._edge_in \
+                or data.edge_index.dim() != 2 or data.edge_index.shape[0] != 2 or data.edge_attr.shape[0] != e:
+            raise RuntimeError(f"shape mismatch: x {tuple(data.x.shape)}, edge_index {tuple(data.edge_index.shape)}, edge_attr "
+                               f"{tuple(data.edge_attr.shape)} for node_in={self._node_in}, edge_in={self._edge_in}")
         self.padded += 1
         x, ei, ea = data.x, data.edge_index, data.edge_attr
         if not (x.is_contiguous() and ei.is_contiguous() and ea.is_contiguous()):

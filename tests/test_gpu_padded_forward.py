@@ -123,3 +123,12 @@ def test_frames_that_do_not_fit_run_eagerly_and_weight_updates_are_seen():
     with pytest.raises(RuntimeError):
         pf(_gpu(small))
     m.eval()
+    # a frame of another feature width is refused, not padded from the wrong rows
+    bad = _gpu(small)
+    bad.x = bad.x[:, :100].contiguous()
+    with pytest.raises(RuntimeError):
+        pf(bad)
+    bad = _gpu(small)
+    bad.edge_attr = bad.edge_attr[:-1]
+    with pytest.raises(RuntimeError):
+        pf(bad)
