@@ -468,6 +468,11 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
         static const int force_wps = diag_env_int("GNNCCA_WPS", 0, 1, 4);  // diagnostics
         if (force_wps == 1 || force_wps == 2 || force_wps == 4) wps = std::min(force_wps, chunks >= 4 ? 4 : (chunks >= 2 ? 2 : 1));
         sp.wps = wps;
+        // two nodes per wave (step_pipe.cuh: NPW): batches whose nodes average one round (<= 128 edges) and that still fill the chip with
+        // half as many waves
+        static const int force_npw = diag_env_int("GNNCCA_NPW", 0, 1, 2);   // diagnostics: 1 / 2 = never / whenever eligible
+        static const int npw_min_n = diag_env_int("GNNCCA_NPW_MIN_N", 16384, 0, 0x7FFFFFFF);   // (8192 nodes: 14.9 -> 15.7 us; 16 384: 29.8 -> 28.2)
+        sp.npw = (wps == 1 && chunks <= 2 && (force_npw == 2 || (force_npw == 0 && N >= npw_min_n))) ? 2 : 1;
     }
     sp.hin = hin;
     // column ranges instead of the col32 stream on steps 2 ... L of the specialised kernels (StepParams::rng)

@@ -67,6 +67,7 @@ struct StepParams {
     const void* ws_base;
     unsigned long long ws_bytes;
     unsigned so_e, so_col, so_perm, so_pd;
+    int npw;                 // nodes per wave of mpn_step_pipe_kernel's message steps: 1, or 2 (step_pipe.cuh: NPW)
     int diag;                // GNNCCA_DIAG experiments (0 in production): bit 0 = timing-only run of mpn_step_pipe_kernel with
                              // zero-record stream descriptors (no HBM traffic: what the arithmetic alone costs)
 };

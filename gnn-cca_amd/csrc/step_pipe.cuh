@@ -41,13 +41,26 @@ static inline bool step_pipe_fits(long long N, long long E, long long e_stride, 
 }
 
 #define GNNCCA_SB() __builtin_amdgcn_sched_barrier(0)
+#ifndef GNNCCA_NPW2_CLS
+#define GNNCCA_NPW2_CLS 0         // 1: instantiate the two-nodes-per-wave form for the classifying steps as well (diagnostic builds)
+#endif
+#ifndef GNNCCA_NPW2_CLS_WAVES
+#define GNNCCA_NPW2_CLS_WAVES 3   // waves per SIMD the CLASSIFYING two-nodes-per-wave variants are compiled for (143-155 VGPRs; the others fit four)
+#endif
 
 // RNG: the column-range code is compiled in (StepParams::rng) -- step 1 derives the ranges, later steps compute target ids from them.  A
 // template parameter and not only a run-time switch because this kernel's scalar register file is full: the few SGPRs the ranges need
 // turn into v_readlane / v_writelane spill traffic on the VALU, which is what the issue-bound big batches are short of; the host
 // instantiates RNG for the latency-bound regime only (mpn_forward.hip).
-template <bool FIRST, bool CLS, bool MSG, bool PD_LDS, bool EBF16, int NT, bool RNG = false>
-__global__ __launch_bounds__(256) GNNCCA_FAST_ATTR void mpn_step_pipe_kernel(const StepParams p) {
+// NPW = 2 (round 4): a wave owns TWO consecutive nodes (one wave per node only; message steps; no LDS table, no range code).  Batches of
+// small dense graphs give a wave ONE round (<= 128 edges) per node: its whole life is the chain seg_ptr -> ids + state -> gather ->
+// arithmetic -> epilogue with nothing to overlap but the other three waves of the SIMD, and 64 x dense256 (two rounds per wave, the second
+// requested from inside the first) streams at 0.66 of HBM where 512 x dense128 reaches 0.57.  Here the second node's round takes the
+// place of "the second round": its ids are requested before the first node is computed, its edge state from inside the first node's
+// arithmetic (the hook), its gather before the first node's epilogue; weights, staging and the workgroup barrier are paid once for both.
+template <bool FIRST, bool CLS, bool MSG, bool PD_LDS, bool EBF16, int NT, bool RNG = false, int NPW = 1>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MSG ? (NPW == 2 && CLS ? GNNCCA_NPW2_CLS_WAVES : 4) : 1))) void mpn_step_pipe_kernel(const StepParams p) {
+    static_assert(NPW == 1 || (NPW == 2 && MSG && !PD_LDS && !RNG), "two nodes per wave: message steps without LDS table / range code");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_proj = smem;                                   // [32][48]   (MSG)
     float* s_part = s_proj + (MSG ? kH * kProjOut : 0);     // [4][32]
@@ -66,13 +79,16 @@ __global__ __launch_bounds__(256) GNNCCA_FAST_ATTR void mpn_step_pipe_kernel(con
     // ---- prologue: every independent load is issued before the first wait ----------------------------------
     const unsigned gflags = p.flags[0];
     const unsigned rbad = p.flags[1];
-    const int wps = p.wps;
-    const int node = blockIdx.x * (4 / wps) + wave / wps;
-    const int sub = wave % wps;
-    const bool active = node < p.N;
-    const int nclamp = active ? node : 0;
+    const int wps = NPW == 2 ? 1 : p.wps;
+    int node = NPW == 2 ? (blockIdx.x * 4 + wave) * 2 : blockIdx.x * (4 / wps) + wave / wps;
+    const int sub = NPW == 2 ? 0 : wave % wps;
+    bool active = node < p.N;
+    int nclamp = active ? node : 0;
     int seg_s = p.seg_ptr[nclamp];
     int seg_t = p.seg_ptr[nclamp + 1];
+    // NPW == 2: the second node is node + 1; its segment starts where the first one's ends
+    const bool active2 = NPW == 2 && node + 1 < p.N;
+    int seg_t2 = NPW == 2 ? p.seg_ptr[active2 ? node + 2 : 0] : 0;
     // steps 2 ... L: the node's column ranges as step 1 left them (wave-uniform: four SGPRs)
     const bool use_range = RNG && !FIRST && rbad == 0u;
     int rbk = 0, rA = 0, rB = 0;
@@ -88,6 +104,8 @@ __global__ __launch_bounds__(256) GNNCCA_FAST_ATTR void mpn_step_pipe_kernel(con
     for (int f = 0; f < kEF; ++f) psrc[f] = psq[f];
     MsgB mb;                // B operands of the message MFMAs (msg_bf16.cuh)
     float cinit = 0.f;
+    float cinit2 = 0.f;     // NPW == 2: Q[node + 1][ch]
+    if (NPW == 2) cinit2 = p.psq_in[(size_t)(active2 ? node + 1 : 0) * kPsQStride + 8 + ch];
     f32x4 stage_proj[2];
     f32x4 stage_pd[8];
     float projb_l = 0.f;
@@ -113,9 +131,12 @@ __global__ __launch_bounds__(256) GNNCCA_FAST_ATTR void mpn_step_pipe_kernel(con
     }
     const bool unsorted = (gflags & GNNCCA_GRAPH_UNSORTED) != 0;
     if (!active) seg_s = seg_t = 0;
+    if (NPW == 2 && !active2) seg_t2 = seg_t;   // (no second node: an empty segment)
     if (MSG) msg_b_bias(cinit, lane, mb);
     // padded layout: see mpn_step_fast_kernel
-    const int eoff = (p.ell_S > 0 && !(gflags & (GNNCCA_GRAPH_UNSORTED | GNNCCA_GRAPH_IRREGULAR))) ? nclamp * p.ell_S - seg_s : 0;
+    const bool padded = p.ell_S > 0 && !(gflags & (GNNCCA_GRAPH_UNSORTED | GNNCCA_GRAPH_IRREGULAR));
+    int eoff = padded ? nclamp * p.ell_S - seg_s : 0;
+    const int eoff2 = (NPW == 2 && padded) ? (node + 1) * p.ell_S - seg_t : 0;   // the second node's
     const unsigned plane_b = (unsigned)p.e_stride * 4u;                       // bytes between two feature planes
     const unsigned long long live = (p.diag & 1) ? 0ull : 1ull;               // timing-only diagnostic: every stream descriptor empty
     // ONE descriptor for everything this kernel streams out of the forward's workspace -- edge state, target ids, permutation, P_dst
@@ -161,6 +182,14 @@ __global__ __launch_bounds__(256) GNNCCA_FAST_ATTR void mpn_step_pipe_kernel(con
     // this into a silent race: GNNCCA_STEP_EARLYBAR (diag bit 3) restores the early barrier to bisect such a change.
     if (PD_LDS || (MSG && (wps == 1 || (p.diag & 8)))) __syncthreads();   // (diag bit 3: A/B with the early barrier of rounds 1-2)
     GNNCCA_STAMP(p.stamp_slot, 2);
+    auto round_compute = [&](int rb, Chunk& a, Chunk& b) {
+        if (rb + stride < seg_t) {
+            compute2(rb, a, rb + stride, b);
+        } else {
+            if (NPW == 2) hook_fire();   // (compute2 fires the hook from inside its arithmetic; a lone chunk fires it up front)
+            compute1(rb, a);
+        }
+    };
     auto round_body = [&](int rb, Chunk& a, Chunk& b, int sid, int sland, int sdone) {
         load_target(a);
         load_target(b);
@@ -174,52 +203,10 @@ __global__ __launch_bounds__(256) GNNCCA_FAST_ATTR void mpn_step_pipe_kernel(con
         GNNCCA_STAMP(p.stamp_slot, sland);
 #endif
         if (!MSG) hook_fire();   // the message-less last step has registers to spare: its second round's state goes out right away
-        if (rb + stride < seg_t)
-            compute2(rb, a, rb + stride, b);
-        else
-            compute1(rb, a);
+        round_compute(rb, a, b);
         GNNCCA_STAMP(p.stamp_slot, sdone);
     };
-    if (base < seg_t) {
-        // the SECOND round's target ids are requested before the first round is computed (see mpn_step_fast_kernel)
-        // The second round's edge state is requested from INSIDE the first round's arithmetic (hook_fire in compute2, right after the
-        // edge updates, when the first pair's loaded operands are dead): its HBM round trip runs under the message block instead
-        // of after it.  (First attempt, with three accumulator tiles: 133 registers, 46-47 -> 49-52 us, r3_ab_hook1.log; with two
-        // tiles it fits 127 registers: -1...-5 % on the message steps of 64 x dense256 / 200 x dense256, r3_ab_hook3.log.)
-        const int base2 = base + 2 * stride;
-        Chunk& n0 = hook_a;
-        Chunk& n1 = hook_b;
-        hook_stride = stride;
-        const bool use_hook = !PD_LDS && base2 < seg_t && base + stride < seg_t && !(p.diag & 4);   // (diag bit 2: A/B without it)
-        if (!PD_LDS) {
-            load_index(base2, n0);
-            load_index(base2 + stride, n1);
-            if (use_hook) hook_base = base2;
-        }
-        round_body(base, c0, c1, 3, 15, 4);
-        if (base2 < seg_t) {
-            if (PD_LDS) {
-                load_index(base2, n0);
-                load_index(base2 + stride, n1);
-            }
-            if (!use_hook) {
-                load_state(base2, n0);
-                load_state(base2 + stride, n1);
-            }
-            round_body(base2, n0, n1, 8, 10, 9);
-        }
-        base += 4 * stride;
-    }
-    for (; base < seg_t; base += 2 * stride) {
-        load_index(base, c0);
-        load_index(base + stride, c1);
-        load_state(base, c0);
-        load_state(base + stride, c1);
-        round_body(base, c0, c1, 11, 13, 12);
-    }
-    GNNCCA_STAMP(p.stamp_slot, 5);
-
-    if (MSG) {
+    auto finish_node = [&]() {
         float v = acc[0];
 #pragma unroll
         for (int i = 1; i < 16; ++i) v += acc[i];
@@ -270,31 +257,129 @@ __global__ __launch_bounds__(256) GNNCCA_FAST_ATTR void mpn_step_pipe_kernel(con
             else if (lane < kProjOut)
                 p.psq_out[(size_t)node * kPsQStride + lane - kPdStride] = pr;
         }
+    };
+    // NPW == 2: the wave's second node takes the first one's place -- same arithmetic, same order per node (logits and latents do not
+    // depend on NPW).  (The epilogue's LDS row of this wave is written again only after it was read: a wave's LDS operations execute in order.)
+    bool second = false;
+    auto switch_node = [&]() {
+        second = true;
+        node = node + 1, active = active2;
+        seg_s = seg_t, seg_t = seg_t2, eoff = eoff2;
+        const float* __restrict__ psq2 = p.psq_in + (size_t)(active ? node : 0) * kPsQStride;
+#pragma unroll
+        for (int f = 0; f < kEF; ++f) psrc[f] = psq2[f];
+        msg_b_bias(cinit2, lane, mb);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    };
+    if (base < seg_t) {
+        // the SECOND round's target ids are requested before the first round is computed (see mpn_step_fast_kernel)
+        // The second round's edge state is requested from INSIDE the first round's arithmetic (hook_fire in compute2, right after the
+        // edge updates, when the first pair's loaded operands are dead): its HBM round trip runs under the message block instead
+        // of after it.  (First attempt, with three accumulator tiles: 133 registers, 46-47 -> 49-52 us, r3_ab_hook1.log; with two
+        // tiles it fits 127 registers: -1...-5 % on the message steps of 64 x dense256 / 200 x dense256, r3_ab_hook3.log.)
+        const int base2 = base + 2 * stride;
+        Chunk& n0 = hook_a;
+        Chunk& n1 = hook_b;
+        hook_stride = stride;
+        if (NPW == 2 && base2 >= seg_t && seg_t < seg_t2) {
+            // ONE round for this node: the hooked round is the NEXT node's first (its segment starts at seg_t).  The whole hand-over sits in
+            // this branch so that the hooked chunks are live across nothing else (kept live across the loop below they cost 19 registers)
+            load_index_at(seg_t, n0, seg_t2);
+            load_index_at(seg_t + stride, n1, seg_t2);
+            hook_base = seg_t, hook_end = seg_t2, hook_eoff = eoff2;
+            round_body(base, c0, c1, 3, 15, 4);
+            // the second node's gather: before the first node's epilogue where the registers allow it (12 more across the epilogue)
+            if (!CLS) {
+                load_target(n0);
+                load_target(n1);
+            }
+            finish_node();
+            switch_node();
+            if (CLS) {
+                load_target(n0);
+                load_target(n1);
+            }
+            round_compute(seg_s, n0, n1);
+            base = seg_s + 2 * stride;
+        } else {
+            const bool use_hook = !PD_LDS && base2 < seg_t && base + stride < seg_t && !(p.diag & 4);   // (diag bit 2: A/B without it)
+            if (!PD_LDS) {
+                load_index(base2, n0);
+                load_index(base2 + stride, n1);
+                if (use_hook) hook_base = base2, hook_end = seg_t, hook_eoff = eoff;
+            }
+            round_body(base, c0, c1, 3, 15, 4);
+            if (base2 < seg_t) {
+                if (PD_LDS) {
+                    load_index(base2, n0);
+                    load_index(base2 + stride, n1);
+                }
+                if (!use_hook) {
+                    load_state(base2, n0);
+                    load_state(base2 + stride, n1);
+                }
+                round_body(base2, n0, n1, 8, 10, 9);
+            }
+            base += 4 * stride;
+        }
+    }
+    for (; base < seg_t; base += 2 * stride) {
+        load_index(base, c0);
+        load_index(base + stride, c1);
+        load_state(base, c0);
+        load_state(base + stride, c1);
+        round_body(base, c0, c1, 11, 13, 12);
+    }
+    GNNCCA_STAMP(p.stamp_slot, 5);
+    if (MSG) finish_node();   // (the first node's, or -- after the hand-over above -- the second one's)
+    if (NPW == 2 && !second) {   // the second node from a cold start (the first one had no edges or several rounds)
+        switch_node();
+        for (base = seg_s; base < seg_t; base += 2 * stride) {
+            load_index(base, c0);
+            load_index(base + stride, c1);
+            load_state(base, c0);
+            load_state(base + stride, c1);
+            round_body(base, c0, c1, 11, 13, 12);
+        }
+        finish_node();
     }
     GNNCCA_STAMP(p.stamp_slot, 7);
 }
 
-template <bool FIRST, bool CLS, bool MSG, bool PDL, bool EB, int NT, bool RNG = false>
+template <bool FIRST, bool CLS, bool MSG, bool PDL, bool EB, int NT, bool RNG = false, int NPW = 1>
 static hipError_t launch_pipe_t(const StepParams& sp, hipStream_t st) {
-    const int npg = 4 / sp.wps;
+    const int npg = NPW == 2 ? 8 : 4 / sp.wps;
     const unsigned blocks = (unsigned)((sp.N + npg - 1) / npg);
     const size_t lds = ((MSG ? (size_t)kH * kProjOut : 0) + 4 * kH + 16 + (PDL ? ((size_t)sp.N + 1) * kPdStride : 0)) * sizeof(float);
-    GNNCCA_LAUNCH((mpn_step_pipe_kernel<FIRST, CLS, MSG, PDL, EB, NT, RNG>), dim3(blocks), dim3(256), lds, st, sp);
+    GNNCCA_LAUNCH((mpn_step_pipe_kernel<FIRST, CLS, MSG, PDL, EB, NT, RNG, NPW>), dim3(blocks), dim3(256), lds, st, sp);
     return hipGetLastError();
+}
+
+// two nodes per wave (StepParams::npw == 2: the host's choice, mpn_forward.hip): message steps, one wave per node, no LDS table, no range code.
+// Only the steps that do not classify are instantiated: their two-node form fits four waves per SIMD (115-128 VGPRs) and gains 11-16 % on
+// batches of >= 32 768 nodes (512 x dense128 step 1: 117.7 -> 105.2 us; 1000 x dense64: 88.6 -> 74.3); the classifying variants need 143-155
+// registers, i.e. three waves per SIMD (or scratch: 2x slower), and come out at -7 ... +3 % (profiles/r04_logs/ab_npw{1,2,3,4}.log).
+template <bool FIRST, bool CLS, bool MSG, bool PDL, bool EB, int NT>
+static hipError_t launch_pipe_npw(const StepParams& sp, hipStream_t st) {
+    if constexpr (MSG && !PDL && (!CLS || GNNCCA_NPW2_CLS)) {
+        if (sp.npw == 2 && sp.wps == 1 && sp.rng == nullptr) return launch_pipe_t<FIRST, CLS, MSG, PDL, EB, NT, false, 2>(sp, st);
+    }
+    return launch_pipe_t<FIRST, CLS, MSG, PDL, EB, NT>(sp, st);
 }
 
 template <bool FIRST, bool CLS, bool MSG, bool PDL>
 static hipError_t launch_pipe(const StepParams& sp, hipStream_t st) {
     if (!PDL) {   // the non-temporal variants only exist beyond the LDS-resident gather table (N > 1024): big batches
         const int nt = sp.nt_load ? 2 : (sp.nt_store ? 1 : 0);
-        if (nt == 2) return sp.e_bf16 ? launch_pipe_t<FIRST, CLS, MSG, false, true, 2>(sp, st) : launch_pipe_t<FIRST, CLS, MSG, false, false, 2>(sp, st);
-        if (nt == 1) return sp.e_bf16 ? launch_pipe_t<FIRST, CLS, MSG, false, true, 1>(sp, st) : launch_pipe_t<FIRST, CLS, MSG, false, false, 1>(sp, st);
+        if (nt == 2) return sp.e_bf16 ? launch_pipe_npw<FIRST, CLS, MSG, false, true, 2>(sp, st) : launch_pipe_npw<FIRST, CLS, MSG, false, false, 2>(sp, st);
+        if (nt == 1) return sp.e_bf16 ? launch_pipe_npw<FIRST, CLS, MSG, false, true, 1>(sp, st) : launch_pipe_npw<FIRST, CLS, MSG, false, false, 1>(sp, st);
     }
     // the column-range variants (StepParams::rng != nullptr: the host's choice) exist for the default cache policy and where they do
     // something: step 1 when it derives (FIRST && MSG), every later step
     if (sp.rng != nullptr && (!FIRST || MSG))
         return sp.e_bf16 ? launch_pipe_t<FIRST, CLS, MSG, PDL, true, 0, true>(sp, st) : launch_pipe_t<FIRST, CLS, MSG, PDL, false, 0, true>(sp, st);
-    return sp.e_bf16 ? launch_pipe_t<FIRST, CLS, MSG, PDL, true, 0>(sp, st) : launch_pipe_t<FIRST, CLS, MSG, PDL, false, 0>(sp, st);
+    return sp.e_bf16 ? launch_pipe_npw<FIRST, CLS, MSG, PDL, true, 0>(sp, st) : launch_pipe_npw<FIRST, CLS, MSG, PDL, false, 0>(sp, st);
 }
 
 #ifndef GNNCCA_KERNELS_ONLY   // (tools: compile-only probes of single instantiations skip the dispatch tables)
