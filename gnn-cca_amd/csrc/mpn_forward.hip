@@ -512,6 +512,14 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
         PROF_MARK(GNNCCA_K_STEP_LAST);
         return GNNCCA_OK;
     }
+    // DEFERRED classification (step_pipe.cuh: CIN): a message step that produces a classified state does not classify it; the step that reads
+    // the state back does (the last step: its input and its output).  The classifying message steps then run the variant without the
+    // classifier -- lighter, and eligible for two nodes per wave.  Where it pays: forwards whose message steps run two nodes per wave
+    // (sp.npw == 2); fp32 edge state only (the bf16 state is rounded after its step classified it); logits bit for bit the same.
+    static const int force_defer = diag_env_int("GNNCCA_DEFER_CLS", -1, 0, 1);   // diagnostics: 0 / 1 = never / whenever possible
+    const bool can_defer = hdr.fast_consts != 0 && sp.attr_vec && !trace && d->agg != GNNCCA_AGG_MAX && !sp.msg_f32 && !sp.e_bf16 && !sp.pd_lds &&
+                           sp.rng == nullptr && first_cls < L && !dropping;
+    const bool defer = can_defer && (force_defer == 1 || (force_defer != 0 && sp.npw == 2));
     for (int step = 1; step <= L; ++step) {
         const bool want_h = trace && trace->h_steps;
         const bool msg = step < L || want_h;
@@ -521,8 +529,15 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
         sp.stamp_slot = 2 + (step - 1 < 6 ? step - 1 : 5);
         sp.update = 1;
         sp.store_e = step < L;
-        sp.cls_layers = step >= first_cls ? hdr.cls_layers : 0;
-        sp.logits = step >= first_cls ? logits_out + (size_t)(out_idx++) * E : nullptr;
+        if (defer) {   // slot of step s: s - first_cls
+            sp.cls_layers = step == L ? hdr.cls_layers : 0;
+            sp.logits = step == L ? logits_out + (size_t)(L - first_cls) * E : nullptr;
+            sp.logits_in = step - 1 >= first_cls ? logits_out + (size_t)(step - 1 - first_cls) * E : nullptr;
+        } else {
+            sp.cls_layers = step >= first_cls ? hdr.cls_layers : 0;
+            sp.logits = step >= first_cls ? logits_out + (size_t)(out_idx++) * E : nullptr;
+            sp.logits_in = nullptr;
+        }
         sp.pd_in = pd[(step - 1) & 1];
         sp.so_pd = (unsigned)ws.pd[(step - 1) & 1];
         sp.psq_in = psq[(step - 1) & 1];

@@ -36,6 +36,7 @@ struct StepParams {
     float* trace_e;
     float* trace_e_enc;
     float* logits;
+    float* logits_in;        // mpn_step_pipe_kernel<..., CIN>: where the logits of the PREVIOUS step go (classified from this step's input state)
     long long e_stride;
     int off_wee, off_wneb, off_projwT, off_projb, off_encw, off_encb, off_cw1, off_cb1, off_cw2, off_cb2;
     int off_fast;

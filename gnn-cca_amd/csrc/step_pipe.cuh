@@ -58,9 +58,14 @@ static inline bool step_pipe_fits(long long N, long long E, long long e_stride, 
 // requested from inside the first) streams at 0.66 of HBM where 512 x dense128 reaches 0.57.  Here the second node's round takes the
 // place of "the second round": its ids are requested before the first node is computed, its edge state from inside the first node's
 // arithmetic (the hook), its gather before the first node's epilogue; weights, staging and the workgroup barrier are paid once for both.
-template <bool FIRST, bool CLS, bool MSG, bool PD_LDS, bool EBF16, int NT, bool RNG = false, int NPW = 1>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MSG ? (NPW == 2 && CLS ? GNNCCA_NPW2_CLS_WAVES : 4) : 1))) void mpn_step_pipe_kernel(const StepParams p) {
+// CIN (round 4): this step classifies its INPUT edge state -- the latents the previous step left in HBM -- into the previous step's logit
+// slot (StepParams::logits_in).  Same classifier, same fp32 values, same bits as classifying them where they were produced; it moves the
+// classifier out of the message steps that produce a classified state and into the step that reads it back anyway, so that those steps
+// run the lighter variant (and its two-nodes-per-wave form).  fp32 edge state only: the bf16 state is rounded AFTER its step classified it.
+template <bool FIRST, bool CLS, bool MSG, bool PD_LDS, bool EBF16, int NT, bool RNG = false, int NPW = 1, bool CIN = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MSG ? (NPW == 2 && (CLS || CIN) ? GNNCCA_NPW2_CLS_WAVES : 4) : 1))) void mpn_step_pipe_kernel(const StepParams p) {
     static_assert(NPW == 1 || (NPW == 2 && MSG && !PD_LDS && !RNG), "two nodes per wave: message steps without LDS table / range code");
+    static_assert(!CIN || (!FIRST && !EBF16 && !RNG && !PD_LDS), "classifying the input state: later steps, fp32 edge state");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_proj = smem;                                   // [32][48]   (MSG)
     float* s_part = s_proj + (MSG ? kH * kProjOut : 0);     // [4][32]
@@ -124,9 +129,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MSG ? (NPW 
         for (int i = 0; i < 8; ++i) stage_pd[i] = g4[min(tid + i * 256, pd_n4 - 1)];
     }
     if (gflags & GNNCCA_GRAPH_BAD_INDEX) {
-        if (CLS)
-            for (size_t k = (size_t)blockIdx.x * 256 + tid; k < (size_t)p.E; k += (size_t)gridDim.x * 256)
-                p.logits[k] = __builtin_nanf("");
+        if (CLS || CIN)
+            for (size_t k = (size_t)blockIdx.x * 256 + tid; k < (size_t)p.E; k += (size_t)gridDim.x * 256) {
+                if (CLS) p.logits[k] = __builtin_nanf("");
+                if (CIN) p.logits_in[k] = __builtin_nanf("");
+            }
         return;
     }
     const bool unsorted = (gflags & GNNCCA_GRAPH_UNSORTED) != 0;
@@ -148,7 +155,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MSG ? (NPW 
     const unsigned so_e = p.so_e, so_col = p.so_col, so_perm = p.so_perm, so_pd = p.so_pd;
     const unsigned us_oob = unsorted ? 0u : kOobOffset;                       // sorted rows: the permutation is never fetched (its loads return 0)
     const rsrc_t r_attr = make_rsrc(p.edge_attr, live * (unsigned long long)p.E * 16);
-    const rsrc_t r_log = make_rsrc(p.logits, CLS ? live * (unsigned long long)p.E * 4 : 0ull);
+    // one descriptor for the logits: with CIN the previous step's slot, and -- when this step classifies its output as well (the last step) --
+    // its own slot right behind it (the host hands out consecutive slots of the [n_out][E] buffer)
+    const rsrc_t r_log = make_rsrc(CIN ? p.logits_in : p.logits, (CLS || CIN) ? live * (unsigned long long)p.E * (CLS && CIN ? 8 : 4) : 0ull);
+    const unsigned so_log_out = (CLS && CIN) ? (unsigned)p.E * 4u : 0u;
 
     f32x16 acc;  // 'sum' / 'mean' only: 'max' takes the general kernel
 #pragma unroll
@@ -347,13 +357,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MSG ? (NPW 
     GNNCCA_STAMP(p.stamp_slot, 7);
 }
 
-template <bool FIRST, bool CLS, bool MSG, bool PDL, bool EB, int NT, bool RNG = false, int NPW = 1>
+template <bool FIRST, bool CLS, bool MSG, bool PDL, bool EB, int NT, bool RNG = false, int NPW = 1, bool CIN = false>
 static hipError_t launch_pipe_t(const StepParams& sp, hipStream_t st) {
     const int npg = NPW == 2 ? 8 : 4 / sp.wps;
     const unsigned blocks = (unsigned)((sp.N + npg - 1) / npg);
     const size_t lds = ((MSG ? (size_t)kH * kProjOut : 0) + 4 * kH + 16 + (PDL ? ((size_t)sp.N + 1) * kPdStride : 0)) * sizeof(float);
-    GNNCCA_LAUNCH((mpn_step_pipe_kernel<FIRST, CLS, MSG, PDL, EB, NT, RNG, NPW>), dim3(blocks), dim3(256), lds, st, sp);
+    GNNCCA_LAUNCH((mpn_step_pipe_kernel<FIRST, CLS, MSG, PDL, EB, NT, RNG, NPW, CIN>), dim3(blocks), dim3(256), lds, st, sp);
     return hipGetLastError();
+}
+
+// A step of a forward with DEFERRED classification (forward_impl: StepParams::logits_in != nullptr) that classifies its input state:
+// a message step (never classifies its own output in that scheme) or the last step (classifies both).  fp32 state, no LDS table, no ranges.
+static hipError_t launch_pipe_cin(const StepParams& sp, bool msg, hipStream_t st) {
+    const int nt = sp.nt_load ? 2 : (sp.nt_store ? 1 : 0);
+    if (msg) {
+        if (nt == 2) return launch_pipe_t<false, false, true, false, false, 2, false, 1, true>(sp, st);
+        if (nt == 1) return launch_pipe_t<false, false, true, false, false, 1, false, 1, true>(sp, st);
+        return launch_pipe_t<false, false, true, false, false, 0, false, 1, true>(sp, st);
+    }
+    if (nt == 2) return launch_pipe_t<false, true, false, false, false, 2, false, 1, true>(sp, st);
+    if (nt == 1) return launch_pipe_t<false, true, false, false, false, 1, false, 1, true>(sp, st);
+    return launch_pipe_t<false, true, false, false, false, 0, false, 1, true>(sp, st);
 }
 
 // two nodes per wave (StepParams::npw == 2: the host's choice, mpn_forward.hip): message steps, one wave per node, no LDS table, no range code.
@@ -384,6 +408,7 @@ static hipError_t launch_pipe(const StepParams& sp, hipStream_t st) {
 
 #ifndef GNNCCA_KERNELS_ONLY   // (tools: compile-only probes of single instantiations skip the dispatch tables)
 static hipError_t launch_pipe_dispatch(const StepParams& sp, bool msg, hipStream_t st) {
+    if (sp.logits_in != nullptr) return launch_pipe_cin(sp, msg, st);
     const int key = (sp.first ? 8 : 0) | (sp.cls_layers ? 4 : 0) | (msg ? 2 : 0) | (sp.pd_lds ? 1 : 0);
     switch (key) {
 #define GNNCCA_PIPE_CASE(K, A, B, C, D) \

@@ -1,4 +1,6 @@
-"""The two-nodes-per-wave form of the buffer-addressed step kernel (step_pipe.cuh: NPW = 2; message steps that do not classify, batches
+"""(Also covers DEFERRED classification -- step_pipe.cuh: CIN -- which forwards of this size with the fp32 edge state use: a message step's
+classified state is classified by the step that reads it back; the comparison batches below are small enough to classify in place.)
+The two-nodes-per-wave form of the buffer-addressed step kernel (step_pipe.cuh: NPW = 2; message steps that do not classify, batches
 of >= 16 384 nodes whose nodes average <= 128 edges).  A wave computes its second node with the arithmetic and in the order a wave
 of its own would: with `encoder_unsplit` (a node's encoder output independent of the batch around it) the logits of a graph inside such
 a batch must be BIT FOR BIT those of the same graph inside a batch small enough for one node per wave -- and within rounding of the CPU
@@ -57,6 +59,8 @@ CASES = {
     "ragged_100_128": (None, 0.1, 5, {}, {}),                                                  # sizes drawn below; isolated first / second nodes
     "lone_chunks": ([60] * 300, 0.2, 7, {}, {}),                                               # <= 59 edges per node: compute1 + the hook fired up front
     "a_few_big_nodes": ([300] * 3 + [90] * 190, 0.0, 0, {}, {}),                               # nodes with 3 rounds between one-round nodes; odd N below
+    "six_steps_sum_fp32": ([120] * 140, 0.05, 9, {"num_enc_steps": 6}, {}),                    # deferred classification over steps 4, 5, 6
+    "one_class_step": ([120] * 140, 0.0, 0, {"num_class_steps": 1}, {}),                       # only the last step classifies: nothing to defer
     "six_steps_mean_bf16": ([120] * 140, 0.05, 9, {"num_enc_steps": 6, "node_agg_fn": "mean"}, {"edge_state_dtype": "bf16"}),   # non-first non-classifying steps
 }
 
@@ -116,3 +120,20 @@ def test_unsorted_rows_in_a_two_nodes_per_wave_batch():
     assert m.graph_flags() == 1
     for g, r in zip(got, ref):
         assert float((g.cpu() - r.cpu()[perm]).abs().max()) <= 2e-5
+
+
+def test_bad_index_poisons_every_logit_slot_with_deferred_classification():
+    """An out-of-range node id: every step returns early and every classified step's slot is NaN -- also the slots that the deferred
+    scheme fills from the NEXT step's launch."""
+    rng = np.random.default_rng(9)
+    ei, n, _ = _batch([128] * 130, rng)
+    ei = ei.copy()
+    ei[1, 12345] = n + 7
+    params, arch, sd = _default_model(1.0 / 127)
+    m = build(params, arch, sd)
+    x, ea = _inputs(n, ei.shape[1], 2)
+    d = Data(torch.from_numpy(x).cuda(), torch.from_numpy(ei).cuda(), torch.from_numpy(ea).cuda())
+    with torch.no_grad():
+        out = m(d)["classified_edges"]
+    assert m.graph_flags() & 2
+    assert len(out) == 3 and all(bool(torch.isnan(t).all()) for t in out)
