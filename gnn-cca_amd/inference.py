@@ -262,9 +262,18 @@ class GraphedForward:
                 while len(self._chain_streams) < chains:
                     self._chain_streams.append(torch.cuda.Stream())
                 depth = max(1, int(depth))
-                graphs, streams, wss, outs = [], [], [], [None] * len(inputs)
-                for gi, lo in enumerate(range(0, len(inputs), depth)):
-                    idx = list(range(lo, min(lo + depth, len(inputs))))
+                # groups of <= `depth` consecutive frames, their number a multiple of S and their sizes within one frame of each other, so
+                # that every stream carries the same number of frames (20 frames, depth 2, S = 3: 7 / 7 / 6 frames per stream; plain groups
+                # of two gave 8 / 6 / 6).  Measured at K = 20 (tools/chains_sweep.py 20): 19.7-20.7 us per forward for every depth from 1 to
+                # 7 -- a short block is bound by its fixed costs (fork, three staggered first launches, join: ~70 us), not by the cut)
+                k = len(inputs)
+                n_groups = min(k, chains * -(-k // (chains * depth)))
+                sizes = [k // n_groups + (1 if g < k % n_groups else 0) for g in range(n_groups)]
+                graphs, streams, wss, outs = [], [], [], [None] * k
+                lo = 0
+                for gi, size in enumerate(sizes):
+                    idx = list(range(lo, lo + size))
+                    lo += size
                     st = self._chain_streams[gi % chains]
                     g, o, ws = self._capture([inputs[i] for i in idx], stream=st)
                     graphs.append(g)

@@ -7,11 +7,11 @@ import torch, bench
 from gnn_cca_amd.inference import GraphedForward
 model = bench.build_model(copy.deepcopy(bench.graph_net_params()), 256).cuda()
 data = bench.make_data(256, 1, 1, "cuda")
-K = 240
+K = int(sys.argv[1]) if len(sys.argv) > 1 else 240
 with torch.no_grad():
     gf = GraphedForward(model, warmup=0)
     b1 = gf.block([data] * K, adopt_inputs=True)
-    for S, D in ((1, 0), (2, 4), (3, 4), (4, 4), (5, 4), (6, 4), (8, 4), (3, 1), (6, 2)):
+    for S, D in ((1, 0), (2, 4), (3, 4), (4, 4), (5, 4), (6, 4), (8, 4), (3, 1), (3, 2), (3, 3), (3, 7), (6, 2)):
         blk = gf.block([data] * K, adopt_inputs=True, chains=S, depth=D) if S > 1 else b1
         blk.replay(); torch.cuda.synchronize()
         ts = []
