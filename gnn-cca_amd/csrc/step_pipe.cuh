@@ -63,7 +63,7 @@ static inline bool step_pipe_fits(long long N, long long E, long long e_stride, 
 // classifier out of the message steps that produce a classified state and into the step that reads it back anyway, so that those steps
 // run the lighter variant (and its two-nodes-per-wave form).  fp32 edge state only: the bf16 state is rounded AFTER its step classified it.
 template <bool FIRST, bool CLS, bool MSG, bool PD_LDS, bool EBF16, int NT, bool RNG = false, int NPW = 1, bool CIN = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MSG ? (NPW == 2 && (CLS || CIN) ? GNNCCA_NPW2_CLS_WAVES : 4) : 1))) void mpn_step_pipe_kernel(const StepParams p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MSG ? (NPW == 2 && CLS ? GNNCCA_NPW2_CLS_WAVES : 4) : 1))) void mpn_step_pipe_kernel(const StepParams p) {
     static_assert(NPW == 1 || (NPW == 2 && MSG && !PD_LDS && !RNG), "two nodes per wave: message steps without LDS table / range code");
     static_assert(!CIN || (!FIRST && !EBF16 && !RNG && !PD_LDS), "classifying the input state: later steps, fp32 edge state");
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -297,16 +297,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MSG ? (NPW 
             // this branch so that the hooked chunks are live across nothing else (kept live across the loop below they cost 19 registers)
             load_index_at(seg_t, n0, seg_t2);
             load_index_at(seg_t + stride, n1, seg_t2);
-            hook_base = seg_t, hook_end = seg_t2, hook_eoff = eoff2;
+            // (the variant that classifies its input has no registers for the second node's edge state under the first node's arithmetic --
+            // 36 B of scratch at four waves per SIMD, and a kernel with ANY scratch starts its waves far more slowly; it requests the state
+            // after the hand-over, with the gather: one exposed round trip instead of three, 127 VGPRs)
+            if (!CIN) hook_base = seg_t, hook_end = seg_t2, hook_eoff = eoff2;
             round_body(base, c0, c1, 3, 15, 4);
             // the second node's gather: before the first node's epilogue where the registers allow it (12 more across the epilogue)
-            if (!CLS) {
+            if (!CLS && !CIN) {
                 load_target(n0);
                 load_target(n1);
             }
             finish_node();
             switch_node();
-            if (CLS) {
+            if (CIN) {
+                load_state(seg_s, n0);
+                load_state(seg_s + stride, n1);
+            }
+            if (CLS || CIN) {
                 load_target(n0);
                 load_target(n1);
             }
@@ -371,6 +378,11 @@ static hipError_t launch_pipe_t(const StepParams& sp, hipStream_t st) {
 static hipError_t launch_pipe_cin(const StepParams& sp, bool msg, hipStream_t st) {
     const int nt = sp.nt_load ? 2 : (sp.nt_store ? 1 : 0);
     if (msg) {
+        if (sp.npw == 2 && sp.wps == 1) {   // two nodes per wave; the second node's ids early, its state and gather after the hand-over (registers)
+            if (nt == 2) return launch_pipe_t<false, false, true, false, false, 2, false, 2, true>(sp, st);
+            if (nt == 1) return launch_pipe_t<false, false, true, false, false, 1, false, 2, true>(sp, st);
+            return launch_pipe_t<false, false, true, false, false, 0, false, 2, true>(sp, st);
+        }
         if (nt == 2) return launch_pipe_t<false, false, true, false, false, 2, false, 1, true>(sp, st);
         if (nt == 1) return launch_pipe_t<false, false, true, false, false, 1, false, 1, true>(sp, st);
         return launch_pipe_t<false, false, true, false, false, 0, false, 1, true>(sp, st);

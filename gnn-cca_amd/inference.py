@@ -102,9 +102,13 @@ class GraphedBlock:
         fork.record(cur)
         for st in self._uniq_streams:
             st.wait_event(fork)
-        for g, st in zip(self._graphs, self._streams):   # groups of `depth` frames, round robin over the S streams
-            with torch.cuda.stream(st):
+        try:   # groups of <= `depth` frames, round robin over the S streams (set_stream, not the context manager: a third of its host cost,
+            #    and a short block is bound by how fast its first launches go out)
+            for g, st in zip(self._graphs, self._streams):
+                torch.cuda.set_stream(st)
                 g.replay()
+        finally:
+            torch.cuda.set_stream(cur)
         for st in self._uniq_streams:
             cur.wait_stream(st)
         return self.outputs
