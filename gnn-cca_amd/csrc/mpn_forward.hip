@@ -453,6 +453,7 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
     // waves per source-node segment: split a segment over 2 or 4 waves only while that is needed to put ~4 waves on
     // every SIMD (small graphs are latency-bound); big batches keep one wave per node, which amortises the
     // per-node prologue / projection epilogue over all of the node's chunks
+    int npw_first = 1, npw_later = 1;   // nodes per wave of step 1 / of the later message steps (step_pipe.cuh: NPW)
     {
         // waves per node that would fill the chip; graphs whose nodes average >= 32 chunks (degree ~2000+) get four times that: the
         // tail of a launch is then a few long segments (dense3000: 0.4315 -> 0.4039 ms with four waves per node, dense2048 equal;
@@ -471,8 +472,14 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
         // two nodes per wave (step_pipe.cuh: NPW): batches whose nodes average one round (<= 128 edges) and that still fill the chip with
         // half as many waves
         static const int force_npw = diag_env_int("GNNCCA_NPW", 0, 1, 2);   // diagnostics: 1 / 2 = never / whenever eligible
-        static const int npw_min_n = diag_env_int("GNNCCA_NPW_MIN_N", 16384, 0, 0x7FFFFFFF);   // (8192 nodes: 14.9 -> 15.7 us; 16 384: 29.8 -> 28.2)
-        sp.npw = (wps == 1 && chunks <= 2 && (force_npw == 2 || (force_npw == 0 && N >= npw_min_n))) ? 2 : 1;
+        // thresholds: from 16 384 nodes (step 1 at 8192: 14.9 -> 15.7 us; at 16 384: 29.8 -> 28.2).  The later steps alone from 8192 nodes, with
+        // the classification deferred, move 64 x dense128 from 17.2 / 15.3 / 6.4 to 14.5 / 14.6 / 8.9 us per step: a tie per forward
+        // (profiles/r04_logs/ab_npw{6,7}.log), so one threshold serves both
+        static const int npw_min_n = diag_env_int("GNNCCA_NPW_MIN_N", 16384, 0, 0x7FFFFFFF);
+        static const int npw_min_n_first = diag_env_int("GNNCCA_NPW_MIN_N_FIRST", 16384, 0, 0x7FFFFFFF);
+        npw_later = (wps == 1 && chunks <= 2 && (force_npw == 2 || (force_npw == 0 && N >= npw_min_n))) ? 2 : 1;
+        npw_first = (npw_later == 2 && (force_npw == 2 || N >= npw_min_n_first)) ? 2 : 1;
+        sp.npw = npw_later;
     }
     sp.hin = hin;
     // column ranges instead of the col32 stream on steps 2 ... L of the specialised kernels (StepParams::rng)
@@ -519,11 +526,12 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
     static const int force_defer = diag_env_int("GNNCCA_DEFER_CLS", -1, 0, 1);   // diagnostics: 0 / 1 = never / whenever possible
     const bool can_defer = hdr.fast_consts != 0 && sp.attr_vec && !trace && d->agg != GNNCCA_AGG_MAX && !sp.msg_f32 && !sp.e_bf16 && !sp.pd_lds &&
                            sp.rng == nullptr && first_cls < L && !dropping;
-    const bool defer = can_defer && (force_defer == 1 || (force_defer != 0 && sp.npw == 2));
+    const bool defer = can_defer && (force_defer == 1 || (force_defer != 0 && npw_later == 2));
     for (int step = 1; step <= L; ++step) {
         const bool want_h = trace && trace->h_steps;
         const bool msg = step < L || want_h;
         sp.first = step == 1;
+        sp.npw = step == 1 ? npw_first : npw_later;
         sp.step_no = step;
         sp.cls_no = out_idx;
         sp.stamp_slot = 2 + (step - 1 < 6 ? step - 1 : 5);
