@@ -238,41 +238,45 @@ __global__ __launch_bounds__(256) void colnorm_apply_kernel(const float* __restr
 }
 
 // The three kernels above in ONE launch, for the matrices of a batch of frames (a few thousand rows: the launches, not the bytes, are
-// what the per-batch pipeline pays for) and for up to two matrices at once (reid and node embeddings).  A workgroup owns 32 adjacent
-// columns of one matrix: (1) chunk sums -- thread (chunk lane = tid / 8, four columns = tid % 8) runs colnorm_partial_kernel's fma chain
-// over its 64-row chunks -> LDS; (2) colnorm_finish_kernel's four ordered quarter sums and the clamp; (3) the division, rows strided
-// over the chunk lanes.  Same operations in the same order as the three-kernel form: the results are bit for bit the same.
+// what the per-batch pipeline pays for) and for up to two matrices at once (reid and node embeddings).  A workgroup owns 16 adjacent
+// columns of one matrix (144 workgroups for 2048 + 256 columns): (1) chunk sums -- thread (chunk lane = tid / 4, four columns = tid % 4)
+// runs colnorm_partial_kernel's fma chain over its 64-row chunks, sixteen rows requested before the first is used -> LDS;
+// (2) colnorm_finish_kernel's four ordered quarter sums and the clamp; (3) the division, rows strided over the chunk lanes, eight in
+// flight.  Same operations in the same order as the three-kernel form: the results are bit for bit the same.
+// (First form: 32 columns per workgroup, eight rows in flight, one row per iteration in (3): 23.6 us for a 1229-row batch, a quarter of
+// the Terrace pipeline's GPU time.)
 constexpr int kFusedMaxChunks = 64;   // rows <= 4096
+constexpr int kFusedCols = 16;
 struct ColnormJob {
     const float* x;
     float* out;
     long long n_cols;
-    int first_block;   // workgroups [first_block, first_block + ceil(n_cols / 32)) belong to this matrix
+    int first_block;   // workgroups [first_block, first_block + ceil(n_cols / 16)) belong to this matrix
 };
 __global__ __launch_bounds__(256) void colnorm_fused_kernel(const ColnormJob j0, const ColnormJob j1, long long n_rows) {
-    __shared__ float s_part[kFusedMaxChunks][32];
-    __shared__ float s_q[4][32];
-    __shared__ float s_norm[32];
+    __shared__ float s_part[kFusedMaxChunks][kFusedCols];
+    __shared__ float s_q[4][kFusedCols];
+    __shared__ float s_norm[kFusedCols];
     const bool second = j1.x != nullptr && (int)blockIdx.x >= j1.first_block;
     const ColnormJob& j = second ? j1 : j0;
     const long long n_cols = j.n_cols;
     const float* __restrict__ x = j.x;
-    const int tid = threadIdx.x, cl = tid >> 3, cg = tid & 7;
-    const long long c0 = (long long)((int)blockIdx.x - j.first_block) * 32;
+    const int tid = threadIdx.x, cl = tid >> 2, cg = tid & 3;
+    const long long c0 = (long long)((int)blockIdx.x - j.first_block) * kFusedCols;
     const long long c = c0 + 4 * cg;
     const int n_chunks = (int)((n_rows + kColChunk - 1) / kColChunk);
     const bool vec = (n_cols & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(j.out) & 15) == 0;
-    for (int ch = cl; ch < n_chunks; ch += 32) {
+    for (int ch = cl; ch < n_chunks; ch += 64) {
         const long long r0 = (long long)ch * kColChunk, r1 = min(r0 + kColChunk, n_rows);
         f32x4g s = {0.f, 0.f, 0.f, 0.f};
         if (vec) {
             if (c < n_cols)
-                for (long long r = r0; r < r1; r += 8) {
-                    f32x4g v[8];
+                for (long long r = r0; r < r1; r += 16) {
+                    f32x4g v[16];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4g*>(x + min(r + u, r1 - 1) * n_cols + c);
+                    for (int u = 0; u < 16; ++u) v[u] = *reinterpret_cast<const f32x4g*>(x + min(r + u, r1 - 1) * n_cols + c);
 #pragma unroll
-                    for (int u = 0; u < 8; ++u)
+                    for (int u = 0; u < 16; ++u)
                         if (r + u < r1)
 #pragma unroll
                             for (int q = 0; q < 4; ++q) s[q] = fmaf(v[u][q], v[u][q], s[q]);
@@ -289,29 +293,34 @@ __global__ __launch_bounds__(256) void colnorm_fused_kernel(const ColnormJob j0,
         for (int q = 0; q < 4; ++q) s_part[ch][4 * cg + q] = s[q];
     }
     __syncthreads();
-    if (tid < 128) {
-        const int q = tid >> 5, col = tid & 31;
+    if (tid < 4 * kFusedCols) {
+        const int q = tid / kFusedCols, col = tid % kFusedCols;
         const int per = (n_chunks + 3) / 4, k0 = min(q * per, n_chunks), k1 = min(k0 + per, n_chunks);
         float t = 0.f;
         for (int k = k0; k < k1; ++k) t += s_part[k][col];
         s_q[q][col] = t;
     }
     __syncthreads();
-    if (tid < 32) s_norm[tid] = fmaxf(sqrtf(((s_q[0][tid] + s_q[1][tid]) + s_q[2][tid]) + s_q[3][tid]), 1e-12f);
+    if (tid < kFusedCols) s_norm[tid] = fmaxf(sqrtf(((s_q[0][tid] + s_q[1][tid]) + s_q[2][tid]) + s_q[3][tid]), 1e-12f);
     __syncthreads();
     float* __restrict__ out = j.out;
     if (vec) {
         if (c < n_cols) {
             const f32x4g nv = {s_norm[4 * cg], s_norm[4 * cg + 1], s_norm[4 * cg + 2], s_norm[4 * cg + 3]};
-            for (long long r = cl; r < n_rows; r += 32) {
-                const f32x4g v = *reinterpret_cast<const f32x4g*>(x + r * n_cols + c);
-                *reinterpret_cast<f32x4g*>(out + r * n_cols + c) = f32x4g{v[0] / nv[0], v[1] / nv[1], v[2] / nv[2], v[3] / nv[3]};
+            for (long long r = cl; r < n_rows; r += 64 * 8) {
+                f32x4g v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4g*>(x + min(r + 64 * u, n_rows - 1) * n_cols + c);
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (r + 64 * u < n_rows)
+                        *reinterpret_cast<f32x4g*>(out + (r + 64 * u) * n_cols + c) = f32x4g{v[u][0] / nv[0], v[u][1] / nv[1], v[u][2] / nv[2], v[u][3] / nv[3]};
             }
         }
     } else {
         for (int q = 0; q < 4; ++q)
             if (c + q < n_cols)
-                for (long long r = cl; r < n_rows; r += 32) out[r * n_cols + c + q] = x[r * n_cols + c + q] / s_norm[4 * cg + q];
+                for (long long r = cl; r < n_rows; r += 64) out[r * n_cols + c + q] = x[r * n_cols + c + q] / s_norm[4 * cg + q];
     }
 }
 
@@ -329,7 +338,7 @@ int gnncca_normalize_columns2(const float* x0, int64_t n_cols0, float* out0, con
     if ((n_cols0 > 0 && (!x0 || !out0)) || (n_cols1 > 0 && (!x1 || !out1))) return GNNCCA_ERR_INVALID_ARG;
     if (n_cols0 == 0) x0 = x1, out0 = out1, n_cols0 = n_cols1, n_cols1 = 0;
     if (n_cols0 == 0) return GNNCCA_OK;
-    const long long b0 = (n_cols0 + 31) / 32, b1 = (n_cols1 + 31) / 32;
+    const long long b0 = (n_cols0 + kFusedCols - 1) / kFusedCols, b1 = (n_cols1 + kFusedCols - 1) / kFusedCols;
     if (b0 + b1 >= (1ll << 31)) return GNNCCA_ERR_UNSUPPORTED;
     ColnormJob j0{x0, out0, (long long)n_cols0, 0};
     ColnormJob j1{n_cols1 > 0 ? x1 : nullptr, out1, (long long)n_cols1, (int)b0};
