@@ -723,6 +723,21 @@ def main():
                     "graphs_per_rank": hi4 - lo4, "edges_rank0": e4_local, "steps": steps4, "blocks": len(blocks4),
                     "ms_per_step": t4 / steps4 * 1e3, "outputs_finite": bool(ok4),
                     "kernels_us_rank0": {k: float(np.mean(v)) * 1e3 for k, v in k4.items()}}
+            if "step" in k4 and e4_local > 0:
+                # this rank's message steps against HBM: the step kernel at its config-4 operating point (batches of >= 16 384 nodes of
+                # degree <= 128 run two nodes per wave with the classification deferred -- DESIGN.md section 5 -- so the message steps
+                # write ONE of the two classified states' logits; the last step, not in this mean, writes the other two)
+                n4 = (hi4 - lo4) * 128
+                deferred = n4 >= 16384
+                per = [b for b in step_algorithmic_bytes(e4_local, 4, 3)]
+                if deferred:
+                    per[1] -= 4 * e4_local
+                alg4 = float(np.mean(per))
+                us4 = float(np.mean(k4["step"])) * 1e3
+                cfg4["roofline_rank0"] = {"bound": "hbm", "kernel": "mpn_step_pipe_kernel, mean over the three message steps of this rank's forward",
+                                          "avg_launch_us": us4, "algorithmic_bytes_per_launch": alg4, "achieved": alg4 / (us4 * 1e-6) / 1e9,
+                                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": alg4 / (us4 * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                                          "two_nodes_per_wave_and_deferred_classification": bool(deferred)}
             # N = 1: the per-GPU share of the 8-GPU run of the same job (graphs [0, 512/8) of the SAME lazy sequence, as rank 0 of 8
             # would build it) timed on this GPU, same box, same run: the only strong-scaling evidence obtainable without an 8-GPU
             # node -- projected_8gpu_speedup = union ms / share ms (no collective on the data path; the broadcast is one-time)
