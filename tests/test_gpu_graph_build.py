@@ -131,3 +131,39 @@ def test_normalisation_beyond_4096_rows_takes_the_three_kernel_form():
     out = torch.empty_like(a)
     st = nat.lib().gnncca_normalize_columns2(a.data_ptr(), 64, out.data_ptr(), None, 0, None, 5000, torch.cuda.current_stream().cuda_stream)
     assert st == nat.ERR_UNSUPPORTED
+
+
+def test_many_batches_in_flight_reuse_the_pinned_staging_ring_safely():
+    """build_graph_batch never synchronises: the staging image goes through a ring of eight pinned buffers and one non-blocking upload.
+    Thirty batches of different sizes are enqueued back to back (the ring wraps three times, buffers grow on the way) with a long kernel
+    queue in front, and every one must come out right -- a slot must not be rewritten before the copy that reads it has run."""
+    from gnn_cca_amd.graph_build import build_graph_batch
+    rng = np.random.default_rng(11)
+    batches = []
+    for i in range(30):
+        g = int(rng.integers(1, 40)) if i != 17 else 300            # one batch far bigger than the others: its slot must grow
+        sizes = rng.integers(0, 24, size=g)
+        n = int(sizes.sum())
+        if n == 0:
+            sizes[0] = 5
+            n = 5
+        batches.append(dict(sizes=sizes, n=n, id_cam=rng.integers(0, 4, size=n), ids=rng.integers(0, 9, size=n), xw=rng.uniform(-10, 10, n),
+                            yw=rng.uniform(-10, 10, n), max_dist=rng.uniform(10, 90, g), reid=rng.standard_normal((n, 64)).astype(np.float32)))
+    busy = torch.randn(4096, 4096, device="cuda")
+    for _ in range(20):                                              # a queue of work in front: the uploads run late, the host runs ahead
+        busy = busy @ busy * 1e-4
+    outs = []
+    for b in batches:
+        outs.append(build_graph_batch(b["xw"], b["yw"], b["ids"], b["id_cam"], b["sizes"], b["max_dist"], torch.zeros(b["n"], 8).cuda(),
+                                      torch.from_numpy(b["reid"]).cuda()))
+    torch.cuda.synchronize()
+    for b, o in zip(batches, outs):
+        ei, attr, lab = graph_oracle.build(b["xw"], b["yw"], b["ids"], b["id_cam"], b["sizes"], b["max_dist"],
+                                           graph_oracle.normalize_columns(b["reid"]))
+        assert np.array_equal(o.edge_index.cpu().numpy(), ei)
+        assert np.array_equal(o.edge_labels.cpu().numpy(), lab)
+        assert np.array_equal(o.y.cpu().numpy(), np.asarray(b["ids"], np.int64))
+        if ei.shape[1]:
+            assert np.abs(o.edge_attr.cpu().numpy() - attr).max() <= 3e-6
+        assert o.node_ptr == np.concatenate([[0], np.cumsum(b["sizes"])]).tolist()
+        assert o.node_ptr_dev.cpu().tolist() == o.node_ptr and o.edge_ptr_dev.cpu().tolist() == o.edge_ptr
