@@ -659,6 +659,10 @@ static hipError_t launch_outer_multi(const float* A, int lda, const float* B, in
     const long long tiles = (long long)((K + 63) / 64) * ((O + 31) / 32);
     long long rows = ((long long)N * tiles / 1024 + 15) / 16 * 16;
     rows = std::max<long long>(16, std::min<long long>(rows, 256));
+    // ... but at most ~96 row chunks: every chunk adds its tile into the SAME output elements with atomics, and those serialise per address
+    // across the eight L2s (~15 ns each).  The layer-by-layer engine's edge-level gradients (19 200 rows into a 6 x 70 or 32 x 38 block) ran
+    // 600 chunks: 46-114 us per launch, a third of its training step
+    rows = std::max<long long>(rows, (((long long)N + 95) / 96 + 15) / 16 * 16);
     const dim3 grid((unsigned)((K + 63) / 64), (unsigned)((O + 31) / 32), (unsigned)((N + rows - 1) / rows));
     hipLaunchKernelGGL(bwd_outer_mfma_kernel, grid, dim3(64), 0, st, A, lda, B, ldb, out, colsum, N, O, K, (int)rows);
     return hipGetLastError();
