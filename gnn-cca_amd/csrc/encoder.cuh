@@ -277,6 +277,8 @@ struct EncFuseParams {
     unsigned* flags;
     const unsigned* blockflags;
     int E;
+    int diag_x_rows;   // GNNCCA_DIAG experiment (0 in production): > 0 = every workgroup streams rows [0, diag_x_rows) of x instead of its
+                       // own -- the same loads, conversions and MFMAs with x served from L2 (timing only: the results are garbage)
 };
 
 // Main loop: top of iteration kt = global loads of chunk kt + 1 (x: 4 x 16 B per thread, W pieces: 3 x 16 B), middle = the
@@ -319,7 +321,8 @@ __global__ __launch_bounds__(512) void enc_gemm_split_lds_kernel(const float* __
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const int q = tid + 512 * u, row = q >> 3, c4 = q & 7;
-        xsrc[u] = x + (size_t)min(row0 + row, M - 1) * K + kbeg + c4 * 4;
+        const int xrow = fp.diag_x_rows > 0 ? row % fp.diag_x_rows : min(row0 + row, M - 1);
+        xsrc[u] = x + (size_t)xrow * K + kbeg + c4 * 4;
         xdst[u] = row * BK + (((c4 >> 1) ^ ((row >> 2) & 3)) << 3) + ((c4 & 1) << 2);
     }
     int wdst[3];

@@ -199,6 +199,8 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
             fused_tail = (use_lds && fusable && ks_split == 1) || use_r32;
             EncFuseParams fp;
             std::memset(&fp, 0, sizeof(fp));
+            static const int gemm_x_l2 = diag_env_int("GNNCCA_GEMM_X_L2_ROWS", 0, 1, 256);   // diagnostics: x served from L2 (timing only)
+            fp.diag_x_rows = gemm_x_l2;
             if (fused_tail) {
                 fp.b1 = blob + hdr.enc_node_b[0];
                 fp.W2 = blob + hdr.enc_node_w[1];
