@@ -441,6 +441,10 @@ __global__ __launch_bounds__(512) void enc_gemm_split_lds_kernel(const float* __
                 }
         };
         auto mfma_half = [&](const Frag& f) {
+#ifdef GNNCCA_EXP_GEMM_NO_MFMA   // diagnostic twin build: the main loop without its MFMAs (the fragments stay used: their LDS reads remain)
+            asm volatile("" ::"v"(f.a[0][0]), "v"(f.a[1][2]), "v"(f.b[0][0]), "v"(f.b[1][2]));
+            return;
+#endif
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt)
 #pragma unroll

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """GPU box: per-kernel times (dispatch-attached HIP events, forward_profiled) for a list of GxN dense workloads.
-    python3 tools/exp_sizes.py 64x256 64x257 512x128 [--L 4] [--edge-state bf16]"""
+    python3 tools/exp_sizes.py 64x256 64x257 512x128 [--L 4] [--edge-state bf16] [--unsplit] [--products 3]"""
 import copy
 import os
 import sys
@@ -14,7 +14,7 @@ import bench  # noqa: E402
 
 
 def main():
-    L, es, specs, unsplit = 4, "fp32", [], False
+    L, es, specs, unsplit, products = 4, "fp32", [], False, 6
     a = sys.argv[1:]
     while a:
         t = a.pop(0)
@@ -24,6 +24,8 @@ def main():
             es = a.pop(0)
         elif t == "--unsplit":
             unsplit = True
+        elif t == "--products":
+            products = int(a.pop(0))
         else:
             specs.append(tuple(int(v) for v in t.split("x")))
     dev = torch.device("cuda", 0)
@@ -32,6 +34,7 @@ def main():
         model = bench.build_model(copy.deepcopy(params), n).to(dev)
         model.edge_state_dtype = es
         model.encoder_unsplit = unsplit
+        model.encoder_products = products
         data = bench.make_data(n, g, 1, dev)
         E = data.edge_index.shape[1]
         acc = {}
