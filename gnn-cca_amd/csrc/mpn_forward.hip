@@ -479,7 +479,8 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
         // (profiles/r04_logs/ab_npw{6,7}.log), so one threshold serves both
         static const int npw_min_n = diag_env_int("GNNCCA_NPW_MIN_N", 16384, 0, 0x7FFFFFFF);
         static const int npw_min_n_first = diag_env_int("GNNCCA_NPW_MIN_N_FIRST", 16384, 0, 0x7FFFFFFF);
-        npw_later = (wps == 1 && chunks <= 2 && (force_npw == 2 || (force_npw == 0 && N >= npw_min_n))) ? 2 : 1;
+        static const int npw_max_chunks = diag_env_int("GNNCCA_NPW_MAX_CHUNKS", 2, 1, 64);   // diagnostics: average 64-edge chunks per node up to which it is used
+        npw_later = (wps == 1 && chunks <= npw_max_chunks && (force_npw == 2 || (force_npw == 0 && N >= npw_min_n))) ? 2 : 1;
         npw_first = (npw_later == 2 && (force_npw == 2 || N >= npw_min_n_first)) ? 2 : 1;
         sp.npw = npw_later;
     }
