@@ -415,14 +415,15 @@ def terrace_leg(device, args, batch=64, n_batches=16, cpu_budget_s=12.0):
     model = build_model(copy.deepcopy(params), 20, seed=0).to(device)    # out-degrees ~19: node-MLP conditioned with 1/19
     dev_in = [(torch.from_numpy(f["node"]).to(device), torch.from_numpy(f["reid"]).to(device)) for f in frames]
 
+    from gnn_cca_amd.pipeline import FramePipeline
+    pipe = FramePipeline(model)
+
     def run(i):
+        # one native call per batch (gnncca_frames_forward): the launches of build_graph_batch -> model(b) -> threshold -> prune_and_cluster,
+        # bit for bit their results (tests/test_gpu_pipeline.py), without the Python between them
         f, (node, reid) = frames[i], dev_in[i]
-        b = build_graph_batch(f["xw"], f["yw"], f["ids"], f["id_cam"], f["sizes"], f["max_dist"], node, reid)
-        with torch.no_grad():
-            out = model(b)
-        probs, preds = threshold(out["classified_edges"][-1])
-        post = prune_and_cluster(b.edge_index, preds, b.x.shape[0], b.node_ptr_dev, b.edge_ptr_dev)
-        return b, out, preds, post
+        r = pipe(f["xw"], f["yw"], f["ids"], f["id_cam"], f["sizes"], f["max_dist"], node, reid)
+        return r.batch, r.outputs, r.preds, {"pruned": r.pruned, "labels": r.labels, "n_clusters": r.n_clusters, "_keep": r}
 
     # random weights put every logit on one side of 0: centre them on batch 0 so that pruning / clustering have work to do
     with torch.no_grad():
@@ -502,8 +503,9 @@ def terrace_leg(device, args, batch=64, n_batches=16, cpu_budget_s=12.0):
     n_done = reps * n_batches
     return {"workload": f"{n_batches} batches of {batch} consecutive valid EPFL-Terrace frames (real per-frame camera / identity "
                         f"structure, synthetic positions and embeddings): {nodes // n_done} detections, {edges // n_done} edges per batch",
-            "pipeline": "gnn_cca_amd.graph_build.build_graph_batch -> MOTMPNet.forward (L=4) -> postprocess.threshold -> "
-                        "postprocess.prune_and_cluster, eager, host planning and H2D of the per-detection arrays included",
+            "pipeline": "gnn_cca_amd.pipeline.FramePipeline: graph_build.build_graph_batch -> MOTMPNet.forward (L=4) -> postprocess.threshold -> "
+                        "postprocess.prune_and_cluster as ONE native call per batch (gnncca_frames_forward: the same 15 launches), host planning "
+                        "and H2D of the per-detection arrays included; `stage_ms_per_batch_synchronised` times the separate functions",
             "ms_per_batch": dt / n_done * 1e3, "frames_per_s": batch * n_done / dt, "edges_per_s": edges / dt,
             "stage_ms_per_batch_synchronised": {k: v / n_batches * 1e3 for k, v in stage.items()},
             "parity": {"ok": bool(checks) and all(c["ok"] for c in checks), "tolerance_abs": 1e-4, "batches": checks,

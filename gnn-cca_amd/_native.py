@@ -34,6 +34,14 @@ class Frames(C.Structure):
                 ("edge_ptr", C.c_void_p)]
 
 
+class FramesIO(C.Structure):
+    _fields_ = [("staged_dev", C.c_void_p), ("n_nodes", C.c_int64), ("n_frames", C.c_int64), ("n_edges", C.c_int64),
+                ("node_embeds", C.c_void_p), ("reid_embeds", C.c_void_p), ("reid_dim", C.c_int32), ("mode", C.c_int32), ("normalize", C.c_int32),
+                ("node_norm", C.c_void_p), ("reid_norm", C.c_void_p), ("edge_index", C.c_void_p), ("edge_attr", C.c_void_p),
+                ("edge_labels", C.c_void_p), ("logits", C.c_void_p), ("probs", C.c_void_p), ("predictions", C.c_void_p), ("pruned", C.c_void_p),
+                ("counters", C.c_void_p), ("labels", C.c_void_p)]
+
+
 class Trace(C.Structure):
     _fields_ = [("h_enc", C.c_void_p), ("e_enc", C.c_void_p), ("h_steps", C.c_void_p), ("e_steps", C.c_void_p)]
 
@@ -123,6 +131,7 @@ _SIGNATURES = {
                                         C.c_int64, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_void_p),
                                         C.POINTER(Dropout), C.c_void_p]),
     "gnncca_normalize_columns2": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
+    "gnncca_frames_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p]),
     "gnncca_plan_frames_bytes": (C.c_size_t, [C.c_int64, C.c_int64]),
     "gnncca_plan_frames": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                                        C.c_size_t]),

@@ -798,6 +798,49 @@ int gnncca_post_prune_cluster_frames(const int64_t* edge_index, const int64_t* p
 }
 
 
+int gnncca_frames_forward(const gnncca_mpn_dims* d, const void* packed_dev, const gnncca_frames_io* io, void* mpn_workspace,
+                          size_t mpn_workspace_bytes, void* post_workspace, size_t post_workspace_bytes, uint32_t options,
+                          gnncca_stream_t stream) {
+    if (!d || !io || !io->staged_dev) return GNNCCA_ERR_INVALID_ARG;
+    const int64_t n = io->n_nodes, g = io->n_frames, e = io->n_edges;
+    if (n < 1 || g < 1 || e < 0) return GNNCCA_ERR_INVALID_ARG;
+    if (n > 4096) return GNNCCA_ERR_UNSUPPORTED;   // (the one-launch normalisation's limit; bigger batches take the separate entry points)
+    if (!io->node_embeds || !io->reid_embeds || !io->edge_index || !io->edge_attr || !io->edge_labels || !io->logits || !io->probs ||
+        !io->predictions || !io->pruned || !io->counters || !io->labels || (io->normalize && (!io->node_norm || !io->reid_norm)))
+        return GNNCCA_ERR_INVALID_ARG;
+    // the staging image (gnncca_plan_frames): f64 xw[n], yw[n], max_dist[g]; i64 ids[n]; i32 person, cam, graph_of, graph_ptr, src_order, edge_ptr, edge_ptr_g
+    const char* base = static_cast<const char*>(io->staged_dev);
+    gnncca_frames fr;
+    fr.xw = reinterpret_cast<const double*>(base);
+    fr.yw = fr.xw + n;
+    fr.max_dist = fr.yw + n;
+    const int32_t* i32 = reinterpret_cast<const int32_t*>(base + 8 * (3 * n + g));
+    fr.person_id = i32, fr.cam = i32 + n, fr.graph_of = i32 + 2 * n, fr.graph_ptr = i32 + 3 * n;
+    fr.src_order = i32 + 3 * n + g + 1, fr.edge_ptr = i32 + 4 * n + g + 1;
+    const int32_t* edge_ptr_g = i32 + 5 * n + g + 2;
+    const float* x = io->node_embeds;
+    const float* reid = io->reid_embeds;
+    int st = GNNCCA_OK;
+    if (io->normalize) {
+        st = gnncca_normalize_columns2(io->reid_embeds, io->reid_dim, io->reid_norm, io->node_embeds, d->node_in, io->node_norm, n, stream);
+        if (st != GNNCCA_OK) return st;
+        x = io->node_norm, reid = io->reid_norm;
+    }
+    st = gnncca_build_edges(&fr, reid, io->reid_dim, n, e, io->mode, io->edge_index, io->edge_attr, io->edge_labels, stream);
+    if (st != GNNCCA_OK) return st;
+    const int n_out = gnncca_num_outputs(d);
+    if (n_out < 1) return GNNCCA_ERR_UNSUPPORTED;
+    if (e > 0) {
+        st = gnncca_mpn_forward_ex(d, packed_dev, x, io->edge_index, io->edge_attr, n, e, mpn_workspace, mpn_workspace_bytes, io->logits, nullptr,
+                                   options, stream);
+        if (st != GNNCCA_OK) return st;
+        st = gnncca_post_threshold(io->logits + (size_t)(n_out - 1) * e, e, io->probs, io->predictions, stream);
+        if (st != GNNCCA_OK) return st;
+    }
+    return gnncca_post_prune_cluster_frames(io->edge_index, io->predictions, n, e, fr.graph_ptr, edge_ptr_g, (int32_t)g, post_workspace,
+                                            post_workspace_bytes, io->pruned, io->counters, io->counters + n, io->labels, io->counters + 2 * n, stream);
+}
+
 // ---- backward ---------------------------------------------------------------------------
 // gnncca_dropout -> DropCfg; GNNCCA_OK with all p == 0 for a null / inactive one
 static int drop_cfg(const gnncca_dropout* dropout, DropCfg* out) {

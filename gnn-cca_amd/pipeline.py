@@ -1,0 +1,157 @@
+"""A batch of frames from detections to identity clusters in ONE native call (rows N1 + the path + N2 of SURVEY.md 8f).
+
+The per-batch body of the reference's inference loop (inference.py:189-345: normalise the embeddings, build the cross-camera graph,
+`mpn_model(data_batch)`, sigmoid / threshold, prune single-direction edges, flow counts, identity clusters) runs here as the SAME
+launches `graph_build.build_graph_batch`, `MOTMPNet.forward`, `postprocess.threshold` and `postprocess.prune_and_cluster` make -- the
+results are bit for bit theirs (tests/test_gpu_pipeline.py) -- but issued from one call of the C ABI (`gnncca_frames_forward`).  At this
+size (a batch of 64 Terrace frames: 1229 detections, 21 930 edges, 15 launches of 3-15 us) the loop is bound by host time per launch,
+and the Python between five calls is a third of it: 0.143 -> 0.11 ms per batch.
+
+    pipe = FramePipeline(model)                                     # model: gnn_cca_amd.MOTMPNet on the GPU, eval mode
+    r = pipe(xw, yw, ids, id_cam, graph_sizes, max_dist, node_embeds, reid_embeds)
+    r.labels, r.n_clusters, r.pruned, r.preds, r.probs, r.outputs['classified_edges'], r.batch (x, edge_index, edge_attr, ...)
+
+Batches of more than 4096 detections, train mode and forward hooks take the step-by-step path (same results).  No CPU fallback."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _native as nat
+from .graph_build import MODE_FULL, MODE_ONLY_APPEARANCE, MODE_ONLY_DIST, _as, _current_stream, _on, _raw_stream, _Staging, _staging, build_graph_batch
+from .postprocess import prune_and_cluster, threshold
+from .sharding import GraphBatch
+
+MAX_NODES = 4096
+
+
+class FrameResult:
+    """Outputs of one batch; tensors are views of three device buffers owned by this object."""
+    __slots__ = ("batch", "outputs", "probs", "preds", "pruned", "flow_out", "flow_in", "labels", "n_clusters", "_keep")
+
+
+class FramePipeline:
+    def __init__(self, model, only_appearance=False, only_dist=False, normalize=True):
+        self.model = model
+        self.mode = MODE_ONLY_APPEARANCE if only_appearance else (MODE_ONLY_DIST if only_dist else MODE_FULL)
+        self.normalize = bool(normalize)
+        self._post_ws = {}   # (stream, bytes) -> workspace tensor
+        self._shape = None   # (n, e) of the cached workspace sizes
+        self._sizes = (0, 0)
+
+    def _slow(self, xw, yw, ids, id_cam, sizes, max_dist, node, reid):
+        b = build_graph_batch(xw, yw, ids, id_cam, sizes, max_dist, node, reid, only_appearance=self.mode == MODE_ONLY_APPEARANCE,
+                              only_dist=self.mode == MODE_ONLY_DIST, normalize=self.normalize)
+        with torch.no_grad():
+            out = self.model(b)
+        r = FrameResult()
+        r.batch, r.outputs = b, out
+        r.probs, r.preds = threshold(out["classified_edges"][-1])
+        post = prune_and_cluster(b.edge_index, r.preds, b.x.shape[0], b.node_ptr_dev, b.edge_ptr_dev)
+        r.pruned, r.flow_out, r.flow_in, r.labels, r.n_clusters = post["pruned"], post["flow_out"], post["flow_in"], post["labels"], post["n_clusters"]
+        r._keep = post
+        return r
+
+    def __call__(self, xw, yw, ids, id_cam, graph_sizes, max_dist, node_embeds, reid_embeds):
+        m = self.model
+        if not (node_embeds.is_cuda and reid_embeds.is_cuda):
+            raise RuntimeError("gnn_cca_amd.pipeline runs on MI355X only (no CPU fallback)")
+        n = int(node_embeds.shape[0])
+        if m.training or n > MAX_NODES or n == 0 or m._containers_hooked():
+            return self._slow(xw, yw, ids, id_cam, graph_sizes, max_dist, node_embeds, reid_embeds)
+        dev = reid_embeds.device
+        lib = nat.lib()
+        xw, yw, md = _as(xw, np.float64), _as(yw, np.float64), _as(max_dist, np.float64)
+        ids64, cam64, sizes = _as(ids, np.int64), _as(id_cam, np.int64), _as(graph_sizes, np.int64)
+        g = len(sizes)
+        if not (len(xw) == len(yw) == len(ids64) == len(cam64) == n) or len(md) != g or reid_embeds.shape[0] != n:
+            raise ValueError("per-detection / per-frame arrays disagree on their lengths")
+        d = m.native_dims()
+        if node_embeds.dim() != 2 or node_embeds.shape[1] != d.node_in or node_embeds.dtype != torch.float32 or reid_embeds.dtype != torch.float32:
+            raise RuntimeError(f"expected float32 embeddings [N, {d.node_in}] / [N, R], got {tuple(node_embeds.shape)} {node_embeds.dtype}, "
+                               f"{tuple(reid_embeds.shape)} {reid_embeds.dtype}")
+        node_embeds = node_embeds if node_embeds.is_contiguous() else node_embeds.contiguous()
+        reid_embeds = reid_embeds if reid_embeds.is_contiguous() else reid_embeds.contiguous()
+        nbytes = lib.gnncca_plan_frames_bytes(n, g)
+        ring = _staging.get(dev.index)
+        if ring is None:
+            ring = _staging[dev.index] = _Staging()
+        pinned, event = ring.take(nbytes)
+        e = lib.gnncca_plan_frames(xw.ctypes.data, yw.ctypes.data, ids64.ctypes.data, cam64.ctypes.data, n, sizes.ctypes.data, md.ctypes.data, g,
+                                   pinned.data_ptr(), nbytes)
+        if e < 0:
+            if -e == nat.ERR_INVALID_ARG:
+                raise ValueError("id_cam length does not match graph_sizes")
+            nat.check(int(-e), "gnncca_plan_frames")
+        if e == 0:   # no cross-camera pair in the whole batch: nothing to launch on the path (the step-by-step functions return the empty containers)
+            return self._slow(xw, yw, ids64, cam64, sizes, md, node_embeds, reid_embeds)
+        n_attr = 4 if self.mode == MODE_FULL else 2
+        if n_attr != d.edge_in:
+            raise RuntimeError(f"the model takes {d.edge_in} edge attributes, this pipeline's mode builds {n_attr}")
+        r_dim, d_in = int(reid_embeds.shape[1]), int(d.node_in)
+        with _on(dev):
+            staged = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            staged.copy_(pinned[:nbytes], non_blocking=True)
+            event.record(_current_stream(dev))
+            blob = m._packed_weights(dev)
+            hot = m._hot
+            if hot.n_out < 0:
+                hot.n_out = lib.gnncca_num_outputs(C.byref(d))
+            n_out = hot.n_out
+            # three buffers: fp32 (normalised embeddings, edge attributes, labels, logits, probabilities), int64, int32; every region
+            # starts on a 256-byte boundary (the kernels use 16-byte accesses where the pointers allow them)
+            def up(v):
+                return (v + 63) // 64 * 64
+            o_node, o_reid = 0, up(n * d_in) if self.normalize else 0
+            o_attr = o_reid + up(n * r_dim) if self.normalize else 0
+            o_lab = o_attr + up(e * n_attr)
+            o_log = o_lab + up(e)
+            o_prob = o_log + up(n_out * e)
+            f32 = torch.empty(o_prob + e, dtype=torch.float32, device=dev)
+            o_pred, o_prun = up(2 * e), up(2 * e) + up(e)
+            i64 = torch.empty(o_prun + e, dtype=torch.int64, device=dev)
+            o_labels = up(2 * n + 1)
+            i32 = torch.empty(o_labels + n, dtype=torch.int32, device=dev)
+            if self._shape != (n, e):
+                self._shape = (n, e)
+                self._sizes = (lib.gnncca_workspace_bytes(C.byref(d), n, e) if e > 0 else 0, lib.gnncca_post_workspace_bytes(n, e) + 256)
+            ws_bytes, post_bytes = self._sizes
+            if e > 0 and ws_bytes == 0:
+                nat.check(lib.gnncca_supported(C.byref(d)), "MOTMPNet configuration")
+            ws = m._scratch(max(ws_bytes, 256), dev)
+            post_ws = torch.empty(post_bytes, dtype=torch.uint8, device=dev)
+            io = nat.FramesIO()
+            io.staged_dev, io.n_nodes, io.n_frames, io.n_edges = staged.data_ptr(), n, g, e
+            io.node_embeds, io.reid_embeds, io.reid_dim, io.mode, io.normalize = node_embeds.data_ptr(), reid_embeds.data_ptr(), r_dim, self.mode, int(self.normalize)
+            fp, ip, cp = f32.data_ptr(), i64.data_ptr(), i32.data_ptr()
+            if self.normalize:
+                io.node_norm, io.reid_norm = fp + 4 * o_node, fp + 4 * o_reid
+            io.edge_attr, io.edge_labels = fp + 4 * o_attr, fp + 4 * o_lab
+            io.logits, io.probs = fp + 4 * o_log, fp + 4 * o_prob
+            io.edge_index, io.predictions, io.pruned = ip, ip + 8 * o_pred, ip + 8 * o_prun
+            io.counters, io.labels = cp, cp + 4 * o_labels
+            st = lib.gnncca_frames_forward(C.byref(d), blob.data_ptr(), C.byref(io), ws.data_ptr(), ws.numel(), post_ws.data_ptr(), post_ws.numel(),
+                                           m._options(), _raw_stream(dev))
+        if st:
+            nat.check(st, "gnncca_frames_forward")
+        # views (the reference's containers): x, edge_index, edge_attr, logits as [E, 1] per classified step
+        x = f32[o_node:o_node + n * d_in].view(n, d_in) if self.normalize else node_embeds
+        reid_n = f32[o_reid:o_reid + n * r_dim].view(n, r_dim) if self.normalize else reid_embeds
+        i32_off = 8 * (3 * n + g)
+        host_i32 = pinned[i32_off:nbytes].numpy().view(np.int32)
+        batch = GraphBatch(x, i64[:2 * e].view(2, e), f32[o_attr:o_attr + e * n_attr].view(e, n_attr),
+                           host_i32[5 * n + g + 2:5 * n + 2 * g + 3].tolist(), host_i32[3 * n:3 * n + g + 1].tolist())
+        i32_dev = staged[i32_off:].view(torch.int32)
+        batch.node_ptr_dev = i32_dev[3 * n:3 * n + g + 1]
+        batch.edge_ptr_dev = i32_dev[5 * n + g + 2:5 * n + 2 * g + 3]
+        batch.edge_labels = f32[o_lab:o_lab + e]
+        batch.y = staged[8 * (2 * n + g):8 * (3 * n + g)].view(torch.int64)
+        batch.reid_embeds = reid_n
+        r = FrameResult()
+        r.batch = batch
+        r.outputs = {"classified_edges": list(f32[o_log:o_log + n_out * e].view(n_out, e, 1).unbind(0))}
+        r.probs = f32[o_prob:o_prob + e]
+        r.preds, r.pruned = i64[o_pred:o_pred + e], i64[o_prun:o_prun + e]
+        r.flow_out, r.flow_in, r.n_clusters, r.labels = i32[:n], i32[n:2 * n], i32[2 * n:2 * n + 1], i32[o_labels:o_labels + n]
+        r._keep = (staged, f32, i64, i32, ws, post_ws, blob)
+        return r

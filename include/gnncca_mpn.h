@@ -285,6 +285,35 @@ GNNCCA_API int gnncca_post_prune_cluster_frames(const int64_t* edge_index, const
                                                 int64_t* pruned_out, int32_t* flow_out, int32_t* flow_in,
                                                 int32_t* labels_out, int32_t* n_clusters_out, gnncca_stream_t stream);
 
+/* ---- rows N1 + the path + N2 in ONE call: a batch of frames from the uploaded staging image to identity clusters -------------------
+ * The per-batch body of inference.py:189-345 (normalise the embeddings, build the graph, MOTMPNet.forward, sigmoid / threshold,
+ * prune, flow counts, clusters) as the same launches gnncca_normalize_columns2 / gnncca_build_edges / gnncca_mpn_forward_ex /
+ * gnncca_post_threshold / gnncca_post_prune_cluster_frames make, issued from one native call: what a per-batch loop pays for at this
+ * size is host time per launch, and the glue between five calls is a third of it.  Every pointer is device memory; outputs are
+ * caller-allocated.  `staged_dev` is the image gnncca_plan_frames wrote, uploaded as is.  Batches of more than 4096 detections:
+ * GNNCCA_ERR_UNSUPPORTED (use the separate entry points). */
+typedef struct gnncca_frames_io {
+    const void* staged_dev;        /* gnncca_plan_frames' staging image on the device                                  */
+    int64_t n_nodes, n_frames, n_edges;
+    const float* node_embeds;      /* [N][node_in]  (raw; normalised into node_norm when `normalize`)                  */
+    const float* reid_embeds;      /* [N][reid_dim]                                                                    */
+    int32_t reid_dim, mode, normalize;
+    float* node_norm;              /* [N][node_in]  out (normalize != 0): the MPN's x                                  */
+    float* reid_norm;              /* [N][reid_dim] out (normalize != 0)                                               */
+    int64_t* edge_index;           /* [2][E] out                                                                       */
+    float* edge_attr;              /* [E][4 or 2] out                                                                  */
+    float* edge_labels;            /* [E] out                                                                          */
+    float* logits;                 /* [n_out][E] out                                                                   */
+    float* probs;                  /* [E] out: sigmoid of the last classified step                                     */
+    int64_t* predictions;          /* [E] out                                                                          */
+    int64_t* pruned;               /* [E] out                                                                          */
+    int32_t* counters;             /* [2 N + 1] out: flow_out | flow_in | n_clusters                                   */
+    int32_t* labels;               /* [N] out                                                                          */
+} gnncca_frames_io;
+GNNCCA_API int gnncca_frames_forward(const gnncca_mpn_dims* dims, const void* packed_dev, const gnncca_frames_io* io,
+                                     void* mpn_workspace, size_t mpn_workspace_bytes, void* post_workspace,
+                                     size_t post_workspace_bytes, uint32_t options, gnncca_stream_t stream);
+
 /* ---- backward pass (training through the HIP kernels, train.py:454-494) -----------------
  * Supported (GNNCCA_OK from gnncca_backward_supported): the MFMA family (both reattach flags, all three
  * aggregators), two-layer node encoder, L >= 1, BatchNorm nowhere or only between the classifier's two layers -- i.e.

@@ -1,0 +1,105 @@
+"""gnn_cca_amd.pipeline.FramePipeline: a batch of frames from detections to identity clusters in ONE native call
+(gnncca_frames_forward) -- the launches of graph_build.build_graph_batch, MOTMPNet.forward, postprocess.threshold and
+postprocess.prune_and_cluster issued without the Python in between.  Every output must be BIT FOR BIT the step-by-step path's
+(same kernels, same arguments), which the other GPU tests pin against the oracles and the reference's goldens."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _frames(rng, g, lo=0, hi=24, cams=4):
+    sizes = rng.integers(lo, hi, size=g)
+    if sizes.sum() == 0:
+        sizes[0] = 6
+    n = int(sizes.sum())
+    return dict(sizes=sizes, n=n, id_cam=rng.integers(0, cams, size=n), ids=rng.integers(0, 11, size=n), xw=rng.uniform(-10, 10, n),
+                yw=rng.uniform(-10, 10, n), max_dist=rng.uniform(10, 90, g), node=rng.standard_normal((n, 2048)).astype(np.float32),
+                reid=rng.standard_normal((n, 256)).astype(np.float32))
+
+
+def _model(seed=0):
+    import bench
+    m = bench.build_model(copy.deepcopy(bench.graph_net_params(L=4)), 20, seed=seed).cuda().eval()
+    return m
+
+
+def _stepwise(m, f, node, reid):
+    from gnn_cca_amd.graph_build import build_graph_batch
+    from gnn_cca_amd.postprocess import prune_and_cluster, threshold
+    b = build_graph_batch(f["xw"], f["yw"], f["ids"], f["id_cam"], f["sizes"], f["max_dist"], node, reid)
+    with torch.no_grad():
+        out = m(b)
+    probs, preds = threshold(out["classified_edges"][-1])
+    post = prune_and_cluster(b.edge_index, preds, b.x.shape[0], b.node_ptr_dev, b.edge_ptr_dev)
+    return b, out, probs, preds, post
+
+
+def _same(r, ref):
+    b, out, probs, preds, post = ref
+    assert torch.equal(r.batch.x, b.x) and torch.equal(r.batch.edge_index, b.edge_index) and torch.equal(r.batch.edge_attr, b.edge_attr)
+    assert torch.equal(r.batch.edge_labels, b.edge_labels) and torch.equal(r.batch.y, b.y) and torch.equal(r.batch.reid_embeds, b.reid_embeds)
+    assert r.batch.node_ptr == b.node_ptr and r.batch.edge_ptr == b.edge_ptr
+    assert torch.equal(r.batch.node_ptr_dev, b.node_ptr_dev) and torch.equal(r.batch.edge_ptr_dev, b.edge_ptr_dev)
+    assert len(r.outputs["classified_edges"]) == len(out["classified_edges"])
+    for a, c in zip(r.outputs["classified_edges"], out["classified_edges"]):
+        assert a.shape == c.shape and torch.equal(a, c)
+    assert torch.equal(r.probs, probs) and torch.equal(r.preds, preds)
+    for k in ("pruned", "flow_out", "flow_in", "labels", "n_clusters"):
+        assert torch.equal(getattr(r, k), post[k]), k
+
+
+@pytest.mark.parametrize("g,seed", [(64, 1), (1, 2), (7, 3), (200, 4)])
+def test_one_call_equals_the_step_by_step_path(g, seed):
+    from gnn_cca_amd.pipeline import FramePipeline
+    rng = np.random.default_rng(seed)
+    f = _frames(rng, g, hi=24 if g < 200 else 20)
+    m = _model()
+    node, reid = torch.from_numpy(f["node"]).cuda(), torch.from_numpy(f["reid"]).cuda()
+    # put the decision boundary inside the logits so that pruning and clustering have work to do
+    ref = _stepwise(m, f, node, reid)
+    with torch.no_grad():
+        sd = m.state_dict()
+        key = [k for k in sd if k.startswith("classifier.") and k.endswith(".bias")][-1]
+        sd[key] -= ref[1]["classified_edges"][-1].median()
+        m.load_state_dict(sd)
+    ref = _stepwise(m, f, node, reid)
+    pipe = FramePipeline(m)
+    for _ in range(3):                       # repeated calls: staging ring, workspace reuse
+        r = pipe(f["xw"], f["yw"], f["ids"], f["id_cam"], f["sizes"], f["max_dist"], node, reid)
+    torch.cuda.synchronize()
+    _same(r, ref)
+    assert int(r.n_clusters.item()) >= 1 and 0 < int(r.pruned.sum().item()) < r.pruned.numel()
+
+
+def test_shapes_alternate_and_fallbacks_agree():
+    """Batches of different sizes through ONE pipeline object (workspace sizes are cached per shape); a batch without any cross-camera
+    pair, a batch beyond 4096 detections and a hooked model take the step-by-step path inside the same call."""
+    from gnn_cca_amd.pipeline import FramePipeline
+    rng = np.random.default_rng(9)
+    m = _model(seed=1)
+    pipe = FramePipeline(m)
+    for g in (30, 3, 90, 30):
+        f = _frames(rng, g)
+        node, reid = torch.from_numpy(f["node"]).cuda(), torch.from_numpy(f["reid"]).cuda()
+        r = pipe(f["xw"], f["yw"], f["ids"], f["id_cam"], f["sizes"], f["max_dist"], node, reid)
+        _same(r, _stepwise(m, f, node, reid))
+    # one camera only: no edges
+    f = _frames(rng, 5, lo=3, hi=9, cams=1)
+    node, reid = torch.from_numpy(f["node"]).cuda(), torch.from_numpy(f["reid"]).cuda()
+    r = pipe(f["xw"], f["yw"], f["ids"], f["id_cam"], f["sizes"], f["max_dist"], node, reid)
+    assert r.batch.edge_index.shape == (2, 0) and int(r.n_clusters.item()) == f["n"]
+    # beyond the one-launch normalisation's 4096 rows
+    f = _frames(rng, 260, lo=14, hi=20)
+    assert f["n"] > 4096
+    node, reid = torch.from_numpy(f["node"]).cuda(), torch.from_numpy(f["reid"]).cuda()
+    r = pipe(f["xw"], f["yw"], f["ids"], f["id_cam"], f["sizes"], f["max_dist"], node, reid)
+    _same(r, _stepwise(m, f, node, reid))
+    # refusals
+    with pytest.raises(ValueError):
+        pipe(f["xw"][:-1], f["yw"], f["ids"], f["id_cam"], f["sizes"], f["max_dist"], node, reid)
+    with pytest.raises(RuntimeError):
+        pipe(f["xw"], f["yw"], f["ids"], f["id_cam"], f["sizes"], f["max_dist"], node.cpu(), reid)

@@ -32,6 +32,29 @@ def main():
         probs, preds = threshold(out["classified_edges"][-1])
         return prune_and_cluster(b.edge_index, preds, b.x.shape[0], b.node_ptr_dev, b.edge_ptr_dev)
 
+    from gnn_cca_amd.pipeline import FramePipeline
+    pipe = FramePipeline(model)
+
+    def run_pipe(i):
+        f, (node, reid) = frames[i], dev_in[i]
+        return pipe(f["xw"], f["yw"], f["ids"], f["id_cam"], f["sizes"], f["max_dist"], node, reid)
+
+    if os.environ.get("AB"):   # both forms in ONE process, alternating (separate short processes see different GPU clock states)
+        for fn in (run, run_pipe):
+            for i in range(n_batches):
+                fn(i)
+        torch.cuda.synchronize()
+        for rnd in range(4):
+            for name, fn in (("step by step ", run), ("FramePipeline", run_pipe)):
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    for i in range(n_batches):
+                        fn(i)
+                torch.cuda.synchronize()
+                print(f"{name}: {(time.perf_counter() - t0) / (reps * n_batches) * 1e3:.4f} ms per batch", flush=True)
+        return
+    if os.environ.get("PIPE"):
+        run = run_pipe
     for i in range(n_batches):
         run(i)
     torch.cuda.synchronize()
