@@ -23,8 +23,9 @@ reference's per-frame loop (inference.py:173-283) would use: K eager calls of MO
 gnn_cca_amd.inference.GraphedForward's one-forward HIP graph; ONE replay of GraphedForward.block -- the K forwards, every launch of
 each, nothing cached or skipped, captured back to back in one HIP graph; or the same K forwards as HIP graphs of four frames round
 robin on `--streams` streams (GraphedForward.block(chains=S): independent frames in flight).  `auto` times every form with the same
-block protocol, lists each in `config.ms_per_step_by_mode`, keeps the fastest as `value` and names it in `config.mode`
-(`config.frames_in_flight` says whether forwards overlapped; `pipelined` puts the one-at-a-time and the in-flight figure side by side).
+block protocol and lists each in `config.ms_per_step_by_mode`; `value` / `ms_per_step` / `config.gpu_over_cpu` are the fastest form that
+runs ONE forward at a time (eager, graph, graph_block: SURVEY 8d's E / t_forward, the definition of rounds 1-3), named in
+`config.mode`; the frames-in-flight figure lives in `pipelined` only (`--mode graphs` selects it by name for experiments).
 
 Prints ONE JSON line (rank 0) with the driver's contract plus `roofline` (dominant kernel mpn_step_kernel, per-launch
 algorithmic bytes / HIP-event duration) and `cpu_baseline` (the reference-shaped torch CPU
@@ -516,6 +517,173 @@ def terrace_leg(device, args, batch=64, n_batches=16, cpu_budget_s=12.0):
                                        f"MPN op for op, numpy / scipy post-processing)"}}
 
 
+def config_leg(nodes, L, edge_state, device, args, steps, cpu_budget_s=6.0, fused_cpu=False):
+    """One BASELINE.json config beside the headline: ONE dense `nodes`-node graph, `L` steps,
+    3 classified steps, `edge_state` storage of the edge latents (arithmetic fp32 either way).  ms per forward = the faster of the
+    one-forward-at-a-time forms (eager calls / one HIP graph of the block's K forwards), edges/s, the step kernel's roofline entry from
+    HIP events attached to its launches, max |logit - oracle.TorchOracle| on the same inputs, and that oracle's own time on the host."""
+    import copy
+
+    from gnn_cca_amd.inference import GraphedForward
+    from oracle.mpn_oracle import TorchOracle
+    params = graph_net_params(L=L)
+    model = build_model(copy.deepcopy(params), nodes).to(device)
+    model.edge_state_dtype = edge_state
+    data = make_data(nodes, 1, 1, device)
+    E, N = data.edge_index.shape[1], data.x.shape[0]
+    by_mode = {}
+    with torch.no_grad():
+        blocks, out = timed_blocks(lambda: model(data), steps, min(args.warmup, 10), None, device, args.backend, min_blocks=5, min_total_s=0.05)
+        by_mode["eager"] = blocks[len(blocks) // 2] / steps * 1e3
+        if steps * 4 * min(L, 3) * E <= (1 << 30):
+            try:
+                gf = GraphedForward(model, warmup=0)
+                blk = gf.block([data] * steps, adopt_inputs=True)
+                blk.replay()
+                blocks, _ = timed_blocks(None, steps, 0, None, device, args.backend, min_blocks=5, min_total_s=0.05, run_block=lambda: blk.replay()[-1])
+                by_mode["graph_block"] = blocks[len(blocks) // 2] / steps * 1e3
+                del blk, gf
+            except Exception as exc:  # noqa: BLE001
+                print(f"[bench] config leg dense{nodes}: block capture failed ({type(exc).__name__}: {exc})", file=sys.stderr)
+                torch.cuda.synchronize()
+        kms = {}
+        for _ in range(8):
+            for _q in range(2):
+                model(data)
+            _, times = model.forward_profiled(data)
+            for kind, ms in times:
+                kms.setdefault(kind, []).append(ms)
+        got = [o.detach().cpu() for o in model(data)["classified_edges"]]
+    ms = min(by_mode.values())
+    e_bytes = 12 if edge_state == "bf16" else 24
+    per_launch = step_algorithmic_bytes(E, L, 3, e_bytes=e_bytes)
+    alg = float(np.mean(per_launch)) if per_launch else 0.0
+    step_us = float(np.mean(kms["step"])) * 1e3 if "step" in kms else float("nan")
+    achieved = alg / (step_us * 1e-6) / 1e9 if step_us == step_us and step_us > 0 else 0.0
+    # parity + CPU baseline: the reference-shaped torch CPU path on the SAME graph
+    sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    orc = TorchOracle(copy.deepcopy(params), "resnet50", sd)
+    dc = make_data(nodes, 1, 1, "cpu")
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
+    ref = orc.forward(dc.x, dc.edge_index, dc.edge_attr)
+    times, t_end = [], time.perf_counter() + cpu_budget_s
+    while len(times) < 20 and (time.perf_counter() < t_end or len(times) < 2):
+        t0 = time.perf_counter()
+        orc.forward(dc.x, dc.edge_index, dc.edge_attr)
+        times.append(time.perf_counter() - t0)
+    cpu_med = float(np.median(times))
+    errs = [float((g - torch.as_tensor(r)).abs().max()) for g, r in zip(got, ref)]
+    scale = max(float(torch.as_tensor(r).abs().max()) for r in ref)
+    res = {"workload": f"1 x dense{nodes} (N={N}, E={E}), feat 2048, L={L}, 3 classified steps, fp32 arithmetic, {edge_state} edge state, eval",
+           "ms_per_step": ms, "ms_per_step_by_mode": by_mode, "value": E / (ms * 1e-3), "unit": "edges/s", "steps": steps,
+           "edge_state_storage": "bf16" if edge_state == "bf16" else "f32",
+           "roofline": {"bound": "latency" if E * 2 * e_bytes < 32e6 else "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                        "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "avg_launch_us": step_us, "algorithmic_bytes_per_launch": alg,
+                        "kernel": ("mpn_step_fast_kernel" if N <= 512 else "mpn_step_pipe_kernel") + ", mean over the L-1 message steps (HIP events per launch)"},
+           "kernels_us": {k: float(np.mean(v)) * 1e3 for k, v in kms.items()},
+           "parity": {"max_abs_err": errs, "max_rel_err": max(errs) / max(scale, 1e-30), "max_abs_logit": scale, "tolerance_abs": 1e-4,
+                      "ok": bool(max(errs) <= 1e-4), "against": "oracle.TorchOracle (fp32, CPU) on the same graph"},
+           "cpu_baseline": {"value": E / cpu_med, "unit": "edges/s", "cores": min(os.cpu_count() or 1, 16), "kind": "port",
+                            "sample": f"{len(times)} forwards of the same graph, median {cpu_med * 1e3:.2f} ms; oracle.TorchOracle, fp32"}}
+    res["gpu_over_cpu"] = res["value"] / res["cpu_baseline"]["value"]
+    return res
+
+
+def train_leg(device, args, frames=64, cams=4, per=5, cpu_reps=3):
+    """`train_step`: one training iteration of the reference (train.py:454-494: forward, BCE loss over the classified steps, backward,
+    SGD step) on a batch of 64 Terrace-shaped frames (4 cameras x 5 detections, cross-camera edges only; config_training.yaml's model:
+    no BatchNorm) through the fused engine -- eager and as gnn_cca_amd.training.GraphedTrainStep's whole-iteration HIP graph --, the
+    loss and one gradient against oracle.TorchTrainOracle (the reference's ops under torch autograd on the CPU), and that oracle's time."""
+    import copy
+
+    from gnn_cca_amd.training import GraphedTrainStep
+    from oracle.mpn_oracle import TorchTrainOracle
+    params = graph_net_params(cls_bn=False)
+    n_g = cams * per
+    cam = np.repeat(np.arange(cams), per)
+    li, lj = np.nonzero(cam[:, None] != cam[None, :])
+    ei = np.concatenate([np.stack([li, lj]) + f * n_g for f in range(frames)], axis=1).astype(np.int64)
+    N, E = frames * n_g, ei.shape[1]
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((N, 2048)).astype(np.float32)
+    x /= np.linalg.norm(x, axis=0, keepdims=True)
+    ea = rng.random((E, 4)).astype(np.float32)
+    lab = (rng.random(E) < 0.2).astype(np.float32)
+    model = build_model(copy.deepcopy(params), n_g).to(device)
+    model.train()
+    sd0 = {k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()}
+    d = Data()
+    d.x, d.edge_index, d.edge_attr = torch.from_numpy(x).to(device), torch.from_numpy(ei).to(device), torch.from_numpy(ea).to(device)
+    labels = torch.from_numpy(lab).to(device)
+    crit = torch.nn.BCEWithLogitsLoss()
+
+    def loss_fn(outputs, lbl):
+        return sum(crit(t.view(-1), lbl) for t in outputs["classified_edges"])
+
+    # parity first, from the initial weights: loss and d loss / d (edge-model weight) against the autograd oracle
+    model.zero_grad(set_to_none=True)
+    loss0 = loss_fn(model(d), labels)
+    loss0.backward()
+    gname = "MPNet.edge_model.edge_mlp.fc_layers.0.weight"
+    g_gpu = dict(model.named_parameters())[gname].grad.detach().cpu()
+    engine = getattr(model, "_train_path", None)
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
+    orc = TorchTrainOracle(copy.deepcopy(params), "resnet50", sd0)
+    r_loss, _, r_grads = orc.loss_and_grads(x, ei, ea, lab)
+    g_ref = torch.as_tensor(r_grads[gname])
+    t0 = time.perf_counter()
+    for _ in range(cpu_reps):
+        orc.loss_and_grads(x, ei, ea, lab)
+    cpu_ms = (time.perf_counter() - t0) / cpu_reps * 1e3
+    gscale = max(float(g_ref.abs().max()), 1e-30)
+    parity = {"loss_gpu": float(loss0), "loss_oracle": float(r_loss), "loss_abs_err": abs(float(loss0) - float(r_loss)),
+              "grad": gname, "grad_max_abs_err": float((g_gpu - g_ref).abs().max()), "grad_max_abs": gscale,
+              "against": "oracle.TorchTrainOracle (torch CPU autograd over the reference's ops) from the same initial weights"}
+    parity["ok"] = bool(parity["loss_abs_err"] <= 1e-5 * max(1.0, abs(float(r_loss))) and parity["grad_max_abs_err"] <= 1e-4 * max(gscale, 1e-6) + 1e-7)
+    opt = torch.optim.SGD(model.parameters(), lr=1e-3)
+
+    def eager_step():
+        opt.zero_grad(set_to_none=True)
+        loss = loss_fn(model(d), labels)
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(3):
+        eager_step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    reps = 20
+    for _ in range(reps):
+        eager_step()
+    torch.cuda.synchronize()
+    eager_ms = (time.perf_counter() - t0) / reps * 1e3
+    graph_ms = None
+    try:
+        gstep = GraphedTrainStep(model, opt, loss_fn, warmup=2)
+        for _ in range(5):
+            gstep(d, labels)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(50):
+            gl = gstep(d, labels)
+        torch.cuda.synchronize()
+        graph_ms = (time.perf_counter() - t0) / 50 * 1e3
+        graph_finite = bool(torch.isfinite(gl).item())
+    except Exception as exc:  # noqa: BLE001
+        print(f"[bench] train leg: whole-iteration capture failed ({type(exc).__name__}: {exc})", file=sys.stderr)
+        torch.cuda.synchronize()
+        graph_finite = None
+    best = min(v for v in (eager_ms, graph_ms) if v is not None)
+    return {"workload": f"{frames} frames of {cams} cameras x {per} detections as one batch (N={N}, E={E}), feat 2048, L=4, 3 classified steps, "
+                        f"config_training.yaml's model (no BatchNorm), BCE loss over the classified steps, SGD",
+            "engine": engine, "ms_per_iteration": best, "ms_per_iteration_eager": eager_ms, "ms_per_iteration_graphed": graph_ms,
+            "graphed_loss_finite": graph_finite, "iterations_per_s": 1e3 / best, "edges_per_s": E * 1e3 / best, "parity": parity,
+            "cpu_baseline": {"ms_per_iteration": cpu_ms, "cores": min(os.cpu_count() or 1, 16), "kind": "port",
+                             "sample": f"{cpu_reps} forward + loss + backward passes of the same batch through oracle.TorchTrainOracle (no optimizer step)"},
+            "gpu_over_cpu": cpu_ms / best}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -542,6 +710,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-terrace", action="store_true", help="skip the EPFL-Terrace frame-distribution pipeline leg (N = 1)")
     ap.add_argument("--no-config4", action="store_true", help="skip the sharded 512 x dense128 leg (BASELINE config 4)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the legs of BASELINE configs 2, 3 (bf16 state) and 5 (N = 1)")
+    ap.add_argument("--no-train", action="store_true", help="skip the training-iteration leg (N = 1)")
     ap.add_argument("--config4-graphs", type=int, default=512)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--single-device", action="store_true",
@@ -610,8 +780,9 @@ def main():
         #                (`static_inputs`: the producer writes each frame there), so a replay copies nothing
         #   graph_block  ONE replay of GraphedForward.block([frame] * K, adopt_inputs=True): the K forwards -- every launch of each,
         #                each with its own outputs -- captured back to back in one HIP graph
-        # `auto` times all three with the same block protocol, reports each in config.ms_per_step_by_mode and keeps the fastest as
-        # `value`.  `pipelined` (extra object) is GraphedForward(streams=S).submit: S forwards in flight; never `value`.
+        # `auto` times all three with the same block protocol, reports each in config.ms_per_step_by_mode and keeps the fastest of
+        # these ONE-FORWARD-AT-A-TIME forms as `value` (edges/s = E / t_forward -- the definition of rounds 1-3).  The
+        # frames-in-flight form (graph_block_chains, below) is timed too and reported under `pipelined`; it is never `value`.
         forms = {"eager": (eager_run, None)}
         gf = GraphedForward(model, warmup=0)
         if args.mode in ("graph", "graphk", "graphs", "auto"):
@@ -659,17 +830,19 @@ def main():
         if not timed:   # the requested graph form could not be captured
             timed["eager"] = timed_blocks(eager_run, args.steps, args.warmup, dist, device, args.backend, min_blocks=args.min_blocks)
         by_mode = {k: v[0][len(v[0]) // 2] / args.steps * 1e3 for k, v in timed.items()}
-        best = min(by_mode, key=by_mode.get)
+        # `value` = one forward at a time; frames in flight only when that form was asked for by name (--mode graphs)
+        one_at_a_time = {k: v for k, v in by_mode.items() if k != "graph_block_chains"} or by_mode
+        best = min(one_at_a_time, key=one_at_a_time.get)
         blocks, out = timed[best]
         api = {"eager": "gnn_cca_amd.MOTMPNet.forward, one call per step (eager)",
                "graph": "gnn_cca_amd.inference.GraphedForward.__call__, one HIP-graph replay per step (static inputs, no copies)",
                "graph_block": f"gnn_cca_amd.inference.GraphedForward.block, one HIP graph of {args.steps} forwards per block",
                "graph_block_chains": f"gnn_cca_amd.inference.GraphedForward.block(chains={args.streams}), the {args.steps} forwards of a block "
                                      f"as small HIP graphs (1-4 frames each) round robin on {args.streams} streams ({args.streams} frames in flight)"}
-        mode_used = api[best] + (" (auto: fastest of " + ", ".join(sorted(by_mode)) + ")" if args.mode == "auto" else "")
+        mode_used = api[best] + (" (auto: fastest one-forward-at-a-time form of " + ", ".join(sorted(one_at_a_time)) + ")" if args.mode == "auto" else "")
         run = forms[best][0] or eager_run
         t = blocks[len(blocks) // 2]      # median block of K steps (max over ranks inside every block)
-        # one frame at a time vs frames in flight, side by side (both are in ms_per_step_by_mode; `value` is the faster)
+        # one frame at a time vs frames in flight, side by side (both are in ms_per_step_by_mode; `value` is the one-at-a-time form)
         pipelined = None
         if "graph_block_chains" in by_mode and "graph_block" in by_mode:
             same = all(torch.equal(a_, b_) for a_, b_ in zip(timed["graph_block_chains"][1]["classified_edges"],
@@ -850,6 +1023,21 @@ def main():
                 res["terrace_pipeline"] = terrace_leg(device, args)
             except Exception as exc:  # noqa: BLE001
                 res["terrace_pipeline"] = {"error": f"{type(exc).__name__}: {exc}"}
+        if world == 1 and not args.no_configs:
+            # BASELINE.json configs 2, 3 as named (bf16 storage) and 5 (fp32 and bf16 storage), each one forward at a time
+            res["configs"] = {}
+            for key, (nn_, l_, es_) in {"config2_dense64_L4_fp32": (64, 4, "fp32"), "config3_dense256_L4_bf16_state": (256, 4, "bf16"),
+                                        "config5_dense1024_L8_fp32": (1024, 8, "fp32"), "config5_dense1024_L8_bf16_state": (1024, 8, "bf16")}.items():
+                try:
+                    res["configs"][key] = config_leg(nn_, l_, es_, device, args, steps=max(1, min(args.steps, 50 if nn_ >= 1024 else 200)))
+                except Exception as exc:  # noqa: BLE001
+                    res["configs"][key] = {"error": f"{type(exc).__name__}: {exc}"}
+                    torch.cuda.synchronize()
+        if world == 1 and not args.no_train:
+            try:
+                res["train_step"] = train_leg(device, args)
+            except Exception as exc:  # noqa: BLE001
+                res["train_step"] = {"error": f"{type(exc).__name__}: {exc}"}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(params, model, args.nodes, args.graphs)
             res["parity"] = res["cpu_baseline"].pop("parity", None)

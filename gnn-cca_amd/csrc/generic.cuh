@@ -375,8 +375,8 @@ static int forward_generic(const gnncca_mpn_dims* d, const void* packed_dev, con
     if (L == 0) return classify_edges(e0, EF);
     // ---- the fused form: one launch per step (generic_fused.cuh) when every width fits its per-thread LDS budget -----------------------
     if (use_fused) {
-        const int parts = std::max(1, fT / std::max(H, 1));
-        const size_t lds = ((size_t)2 * fW * (fT + 1) + gp.w_floats + (gp.tab_ld + 3) / 4 * 4 + gp.hin_w + (size_t)parts * H) * sizeof(float);
+        const size_t lds = gen_fused_lds_bytes(fW, fT, gp.w_floats, gp.tab_ld, gp.hin_w, H);
+        if (lds > kGenFusedLdsMax) return GNNCCA_ERR_UNSUPPORTED;   // (gen_fused_ok admits by the same formula: unreachable)
         {   // (once per device and size: the call costs tens of microseconds of host time)
             static thread_local int attr_dev = -1;
             static thread_local size_t attr_lds = 0;

@@ -275,7 +275,6 @@ __global__ __launch_bounds__(256) void gen_step_fused_kernel(const GenStepParams
     }
     const float* tab = s_tab;   // this node's P_src | . | Q, staged below (read once per output pass: from HBM / L2 that was a dependent
                                 // round trip per pass -- sixteen per tile at node latent 64)
-    const int ein_w = p.e_a_w + p.e_b_w;
     // aggregation roles: thread (channel c, part pt) for c < H; parts split the T edges of a tile evenly
     const int parts = max(1, T / max(p.H, 1));
     const int chunk = (T + parts - 1) / parts;
@@ -417,6 +416,13 @@ __global__ __launch_bounds__(256) void gen_step_fused_kernel(const GenStepParams
     if (p.tab_out) gen_project_node(p, s_hin, node);
 }
 
+// dynamic LDS of one gen_step_fused_kernel workgroup (floats -> bytes): the one formula gen_fused_ok admits by and the launch sizes by
+constexpr size_t kGenFusedLdsMax = 160 * 1024;
+static inline size_t gen_fused_lds_bytes(int wmax_padded, int T, int w_floats, int tab_ld, int hin_w, int H) {
+    const int parts = std::max(1, T / std::max(H, 1));
+    return ((size_t)2 * wmax_padded * (T + 1) + (size_t)w_floats + (size_t)((tab_ld + 3) / 4 * 4) + (size_t)hin_w + (size_t)parts * H) * sizeof(float);
+}
+
 // can the fused step run this configuration?  (every width it keeps per thread in LDS within the budget; at least one layer in
 // the two message-passing MLPs; H <= T so that every channel has a reducer thread)
 static bool gen_fused_ok(const gnncca_mpn_dims* d, int64_t n_nodes, int* T_out, int* wmax_out) {
@@ -438,11 +444,10 @@ static bool gen_fused_ok(const gnncca_mpn_dims* d, int64_t n_nodes, int* T_out, 
     // edges per tile = threads per workgroup.  A single frame-sized graph has one workgroup per CU at most: everything is exposed
     // latency there and the widest tile (one pass over a dense-256 node's 255 edges) is the fastest -- 132 KB of LDS at width 64;
     // batches want two workgroups per CU instead (66 KB)
-    const int T = (wmax <= 32 || (wmax <= 64 && n_nodes <= 1024)) ? 256 : 128;
-    if (d->node_dim > T) return false;
+    int T = (wmax <= 32 || (wmax <= 64 && n_nodes <= 1024)) ? 256 : 128;
+    size_t wf = 0;
     {   // the weights every edge uses must fit their LDS stage (40 KB) next to the activations
         const int ef_in = (d->reattach_edges ? 2 : 1) * d->edge_dim;
-        size_t wf = 0;
         auto add = [&](const gnncca_mlp& m, int kn_first) {
             for (int l = 0; l < m.n_layers; ++l)
                 wf += (size_t)((l == 0 && kn_first >= 0 ? kn_first : m.layers[l].in_dim) + 1) * (size_t)((m.layers[l].out_dim + 7) / 8 * 8);
@@ -450,8 +455,18 @@ static bool gen_fused_ok(const gnncca_mpn_dims* d, int64_t n_nodes, int* T_out, 
         add(d->edge_mlp, ef_in), add(d->node_mlp, d->edge_dim), add(d->cls_edge, -1), add(d->enc_edge, -1);
         if (wf > 10240) return false;
     }
+    const int wpad = (wmax + 3) / 4 * 4;   // keeps the LDS regions behind the activation buffers 16-byte aligned
+    // The WHOLE LDS footprint of gen_step_fused_kernel, as the launch code sizes it (gen_fused_lds_bytes below is that formula): two
+    // k-major activation buffers, the weight stage, the node's table row, its hin vector and the reduction parts.  It must fit the 160 KB
+    // a CU has: the widest tile first, then the 128-edge tile, else the op-by-op path (a launch that asks for more would fail outright).
+    const int tab_ld = 2 * d->edge_mlp.layers[0].out_dim + d->node_mlp.layers[0].out_dim;
+    const int hin_w = (d->reattach_nodes ? 2 : 1) * d->node_dim;
+    for (;; T = 128) {
+        if (d->node_dim <= T && gen_fused_lds_bytes(wpad, T, (int)((wf + 3) / 4 * 4), tab_ld, hin_w, d->node_dim) <= kGenFusedLdsMax) break;
+        if (T == 128) return false;
+    }
     *T_out = T;
-    *wmax_out = (wmax + 3) / 4 * 4;   // keeps the LDS regions behind the activation buffers 16-byte aligned
+    *wmax_out = wpad;
     return true;
 }
 

@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MSG ? (NPW 
         const i32x4 r = reinterpret_cast<const i32x4*>(p.rng)[nclamp];
         rbk = seg_s + r[1], rA = r[0] - seg_s, rB = r[2] - seg_s;
     }
-    const int half = lane >> 5, ch = lane & 31;
+    const int ch = lane & 31;
     const float* __restrict__ psq = p.psq_in + (size_t)nclamp * kPsQStride;
     float psrc[kEF];
 #pragma unroll

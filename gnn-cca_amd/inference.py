@@ -150,8 +150,13 @@ class GraphedForward:
 
     def _drop_stale(self, stamp):
         stale = [k for k, v in self._graphs.items() if v[3] != stamp]
+        dropped = {id(self._graphs[k][0]) for k in stale}
         for k in stale:
             del self._graphs[k]
+        # a slot must not keep replaying a dropped graph: it addresses the workspace and the packed blob that went with it
+        for slot in [s for s, (g, _st) in self._slot_last.items() if id(g) in dropped]:
+            del self._slot_last[slot]
+            self._slot_out.pop(slot, None)
         for k in [k for k, b in self._blocks.items() if b._stamp != stamp]:
             del self._blocks[k]
 
@@ -313,7 +318,11 @@ class GraphedForward:
         """The lean form of `submit` for a producer that keeps every slot's static inputs filled (`slot_inputs`) and orders itself:
         replay slot `slot`'s graph of the shape last handed out / submitted on it, on the slot's stream -- no checks, no copies, no
         fork, no event (one graph launch of host work).  Order the results with `join()`."""
-        graph, st = self._slot_last[slot]
+        last = self._slot_last.get(slot)
+        if last is None:
+            raise RuntimeError(f"replay_slot({slot}): no live graph on this slot (never submitted, or dropped when the weights / options "
+                               f"changed): hand the frame to submit() / slot_inputs() again")
+        graph, st = last
         with torch.cuda.stream(st):
             graph.replay()
 

@@ -58,6 +58,33 @@ def test_generic_family_wide_and_narrow_vs_oracle(latent):
         assert np.abs(o.cpu().numpy() - r).max() <= 2e-5 * max(1.0, float(np.abs(r).max()))
 
 
+
+@pytest.mark.parametrize("edge_fc,node_fc", [([64, 48, 6], [64, 64]), ([128, 6], [128, 64])])
+def test_generic_family_lds_budget_picks_a_tile_that_fits(edge_fc, node_fc):
+    """node latent 64 with multi-layer MPN MLPs on a graph of <= 1024 nodes.  The widest tile (T = 256) of the fused generic
+    step needs 2 * 64 * 257 * 4 B = 131.6 KB of activations plus ~36 KB of staged weights there -- more than a CU's 160 KB; a 128-wide
+    layer needs 132 KB + weights at T = 128 too.  `gen_fused_ok` now sizes the WHOLE footprint and steps down to the 128-edge tile or to
+    the op-by-op path instead of letting the launch fail (GNNCCA_ERR_HIP)."""
+    params, arch, sd, _ = load_case(os.path.join(GOLDEN_DIR, "dense64.npz"))
+    params = copy.deepcopy(params)
+    params["encoder_feats_dict"]["nodes"][arch]["node_out_dim"] = 64
+    params["edge_model_feats_dict"]["fc_dims"] = list(edge_fc)
+    params["node_model_feats_dict"]["fc_dims"] = list(node_fc)
+    n = 40
+    m, sd = _random_model(params, arch, n)
+    rng = np.random.default_rng(5)
+    ei = np.concatenate([_dense_graph(n), _dense_graph(17, n)[:, ::3]], axis=1)
+    nn = n + 17
+    x = rng.standard_normal((nn, 2048)).astype(np.float32) / 45.0
+    ea = rng.random((ei.shape[1], 4)).astype(np.float32)
+    ref = NumpyOracle(params, arch, sd, np.float32).forward(x, ei, ea)
+    with torch.no_grad():
+        out = m(Data(torch.from_numpy(x).cuda(), torch.from_numpy(ei).cuda(), torch.from_numpy(ea).cuda()))["classified_edges"]
+    for o, r in zip(out, ref):
+        assert np.isfinite(o.cpu().numpy()).all()
+        assert np.abs(o.cpu().numpy() - r).max() <= 2e-5 * max(1.0, float(np.abs(r).max()))
+
+
 CHILD = r"""
 import json, os, sys, copy
 sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))

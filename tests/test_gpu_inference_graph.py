@@ -192,6 +192,23 @@ def test_forwards_in_flight_on_several_streams():
         assert _eq(gf.slot_outputs(i)["classified_edges"], want[3 + i]), i
     with pytest.raises(RuntimeError):
         GraphedForward(m).submit(frames[0])
+    # a change of the module's options (or of the blob's address) drops every graph captured under the old ones, and a slot
+    # whose graph went with them must refuse to replay it (it addressed the dropped workspace and blob) instead of reading freed memory
+    m.edge_state_dtype = "bf16"
+    try:
+        gf.submit(frames[0]).result()
+        torch.cuda.synchronize()
+        refused = 0
+        for i in range(3):
+            try:
+                gf.replay_slot(i)
+            except RuntimeError:
+                refused += 1
+        gf.join()
+        torch.cuda.synchronize()
+        assert refused == 2      # the slot that took the new frame replays its NEW graph; the other two have nothing live
+    finally:
+        m.edge_state_dtype = "fp32"
 
 
 def test_refusals():

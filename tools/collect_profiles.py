@@ -40,7 +40,7 @@ def run(tag, sub, extra, bench_args):
 def main():
     tag = sys.argv[1]
     trace_only = "--trace-only" in sys.argv[2:sys.argv.index("--")]   # kernel-trace + stats only (e.g. the HIP-graph block form of the headline)
-    bench_args = sys.argv[sys.argv.index("--") + 1:] + ["--no-cpu-baseline", "--no-scale-probe", "--no-config4", "--no-terrace", "--streams", "0", "--profile-reps", "0"]
+    bench_args = sys.argv[sys.argv.index("--") + 1:] + ["--no-cpu-baseline", "--no-scale-probe", "--no-config4", "--no-terrace", "--no-configs", "--no-train", "--streams", "0", "--profile-reps", "0"]
     summary = {"command": "python3 bench.py " + " ".join(bench_args), "kernels": {}}
     d = run(tag, "trace", ["--kernel-trace", "--stats"], bench_args)
     stats = glob.glob(os.path.join(d, "*", "*kernel_stats.csv"))

@@ -16,9 +16,33 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+MAX_PER_BLOCK = 4   # TCP_* / TA_* counters one pass can hold on gfx950: a pass that asks for more (eight were tried in round 4:
+                    # profiles/r04_logs/pmc_r04_tcp.log) makes rocprofv3 abort inside the profiled GPU process and hang in finalisation
+
+
+def split_groups(groups):
+    """A group with more than MAX_PER_BLOCK counters of one of those blocks is never handed to rocprofv3: it is cut into passes that fit."""
+    out = []
+    for grp in groups:
+        cur, per_block = [], {}
+        for c in grp:
+            block = c.split("_", 1)[0] if c.startswith(("TCP_", "TA_")) else None
+            if block and per_block.get(block, 0) >= MAX_PER_BLOCK:
+                out.append(cur)
+                cur, per_block = [], {}
+            cur.append(c)
+            if block:
+                per_block[block] = per_block.get(block, 0) + 1
+        if cur:
+            out.append(cur)
+    if out != groups:
+        print(f"pmc_kernel: counter groups re-cut to at most {MAX_PER_BLOCK} TCP_* / TA_* counters per pass: {out}", flush=True)
+    return out
+
+
 def main():
-    kern, groups = sys.argv[1], [g.split(",") for g in sys.argv[2].split(";")]
-    bench_args = sys.argv[sys.argv.index("--") + 1:] + ["--no-cpu-baseline", "--no-scale-probe", "--no-config4", "--no-terrace", "--streams", "0", "--profile-reps", "0", "--mode", "eager",
+    kern, groups = sys.argv[1], split_groups([g.split(",") for g in sys.argv[2].split(";")])
+    bench_args = sys.argv[sys.argv.index("--") + 1:] + ["--no-cpu-baseline", "--no-scale-probe", "--no-config4", "--no-terrace", "--no-configs", "--no-train", "--streams", "0", "--profile-reps", "0", "--mode", "eager",
                                                          "--steps", "30", "--warmup", "5"]
     res = {}
     for gi, grp in enumerate(groups):
