@@ -625,7 +625,10 @@ def train_leg(device, args, frames=64, cams=4, per=5, cpu_reps=3):
     loss0 = loss_fn(model(d), labels)
     loss0.backward()
     gname = "MPNet.edge_model.edge_mlp.fc_layers.0.weight"
-    g_gpu = dict(model.named_parameters())[gname].grad.detach().cpu()
+    g_gpu = dict(model.named_parameters())[gname].grad.detach().cpu().clone()
+    loss0 = float(loss0)       # (no tensor of this iteration's autograd graph may outlive it: the whole-iteration capture below would find
+    model.zero_grad(set_to_none=True)   # AccumulateGrad nodes of another stream alive and synchronise inside the capture)
+    torch.cuda.synchronize()
     engine = getattr(model, "_train_path", None)
     torch.set_num_threads(min(os.cpu_count() or 1, 16))
     orc = TorchTrainOracle(copy.deepcopy(params), "resnet50", sd0)
@@ -636,32 +639,32 @@ def train_leg(device, args, frames=64, cams=4, per=5, cpu_reps=3):
         orc.loss_and_grads(x, ei, ea, lab)
     cpu_ms = (time.perf_counter() - t0) / cpu_reps * 1e3
     gscale = max(float(g_ref.abs().max()), 1e-30)
-    parity = {"loss_gpu": float(loss0), "loss_oracle": float(r_loss), "loss_abs_err": abs(float(loss0) - float(r_loss)),
+    parity = {"loss_gpu": loss0, "loss_oracle": float(r_loss), "loss_abs_err": abs(loss0 - float(r_loss)),
               "grad": gname, "grad_max_abs_err": float((g_gpu - g_ref).abs().max()), "grad_max_abs": gscale,
               "against": "oracle.TorchTrainOracle (torch CPU autograd over the reference's ops) from the same initial weights"}
     parity["ok"] = bool(parity["loss_abs_err"] <= 1e-5 * max(1.0, abs(float(r_loss))) and parity["grad_max_abs_err"] <= 1e-4 * max(gscale, 1e-6) + 1e-7)
     opt = torch.optim.SGD(model.parameters(), lr=1e-3)
 
-    def eager_step():
-        opt.zero_grad(set_to_none=True)
-        loss = loss_fn(model(d), labels)
-        loss.backward()
-        opt.step()
-        return loss
-
-    for _ in range(3):
-        eager_step()
+    gstep = GraphedTrainStep(model, opt, loss_fn, warmup=3)    # its first three calls ARE the eager iteration (GraphedTrainStep._eager)
     torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        gstep(d, labels)
+    torch.cuda.synchronize()
+    t_first = (time.perf_counter() - t0) / 3 * 1e3
+
+    def eager_step():
+        gstep._eager(d, labels)
+
     t0 = time.perf_counter()
     reps = 20
     for _ in range(reps):
         eager_step()
     torch.cuda.synchronize()
     eager_ms = (time.perf_counter() - t0) / reps * 1e3
-    graph_ms = None
+    graph_ms, graph_finite = None, None
     try:
-        gstep = GraphedTrainStep(model, opt, loss_fn, warmup=2)
-        for _ in range(5):
+        for _ in range(3):      # the capture (fourth call through the object) and two replays
             gstep(d, labels)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -673,7 +676,7 @@ def train_leg(device, args, frames=64, cams=4, per=5, cpu_reps=3):
     except Exception as exc:  # noqa: BLE001
         print(f"[bench] train leg: whole-iteration capture failed ({type(exc).__name__}: {exc})", file=sys.stderr)
         torch.cuda.synchronize()
-        graph_finite = None
+    del t_first
     best = min(v for v in (eager_ms, graph_ms) if v is not None)
     return {"workload": f"{frames} frames of {cams} cameras x {per} detections as one batch (N={N}, E={E}), feat 2048, L=4, 3 classified steps, "
                         f"config_training.yaml's model (no BatchNorm), BCE loss over the classified steps, SGD",
@@ -712,6 +715,7 @@ def main():
     ap.add_argument("--no-config4", action="store_true", help="skip the sharded 512 x dense128 leg (BASELINE config 4)")
     ap.add_argument("--no-configs", action="store_true", help="skip the legs of BASELINE configs 2, 3 (bf16 state) and 5 (N = 1)")
     ap.add_argument("--no-train", action="store_true", help="skip the training-iteration leg (N = 1)")
+    ap.add_argument("--train-leg-only", action="store_true", help="(internal) run the training-iteration leg alone and print its JSON object")
     ap.add_argument("--config4-graphs", type=int, default=512)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--single-device", action="store_true",
@@ -721,6 +725,14 @@ def main():
     ap.add_argument("--launch-timeout", type=float, default=900.0, help="launcher: seconds before the rank processes are stopped")
     args = ap.parse_args()
 
+    if args.train_leg_only:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: the HIP path is the only implementation (no CPU fallback)")
+        torch.cuda.set_device(0)
+        out = train_leg(torch.device("cuda", 0), args)
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
+        return
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         launch_ranks(args)   # does not return
         return
@@ -1034,8 +1046,15 @@ def main():
                     res["configs"][key] = {"error": f"{type(exc).__name__}: {exc}"}
                     torch.cuda.synchronize()
         if world == 1 and not args.no_train:
+            # in a child process of its own: the leg captures torch's autograd + optimizer into a HIP graph, and a crash inside that
+            # machinery must cost this leg, not the line (the parent waits; one process on the GPU at a time computes)
+            import subprocess
             try:
-                res["train_step"] = train_leg(device, args)
+                torch.cuda.synchronize()
+                cp = subprocess.run([sys.executable, os.path.abspath(__file__), "--train-leg-only"], capture_output=True, text=True, timeout=600)
+                line = [ln for ln in cp.stdout.splitlines() if ln.startswith("{")]
+                res["train_step"] = json.loads(line[-1]) if cp.returncode == 0 and line else {
+                    "error": f"child exit code {cp.returncode}: {cp.stderr.strip().splitlines()[-1] if cp.stderr.strip() else 'no output'}"}
             except Exception as exc:  # noqa: BLE001
                 res["train_step"] = {"error": f"{type(exc).__name__}: {exc}"}
         if world == 1 and not args.no_cpu_baseline:
