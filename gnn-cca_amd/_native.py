@@ -64,6 +64,8 @@ OPT_ENC_SPLIT3 = 2
 OPT_ENC_UNSPLIT = 4
 OPT_COLUMN_RANGES = 8
 BWD_GRADS_ZEROED = 1
+POST_ROUNDING, POST_PRUNING, POST_SPLITTING = 1, 2, 4        # gnncca_post_finalize_frame_host switches (config_inference.yaml:6-8)
+POST_TRIGGER_ROUNDING, POST_TRIGGER_SPLITTING = 1, 2         # trigger bits of gnncca_post_prune_cluster_frames_ex
 
 
 _SIGNATURES = {
@@ -97,6 +99,11 @@ _SIGNATURES = {
     "gnncca_post_prune_cluster_frames": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32,
                                                    C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                    C.c_void_p, C.c_void_p]),
+    "gnncca_post_prune_cluster_frames_ex": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32,
+                                                      C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gnncca_post_finalize_frame_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32,
+                                                  C.c_void_p, C.c_void_p, C.c_void_p]),
     "gnncca_backward_supported": (C.c_int, [C.POINTER(MpnDims)]),
     "gnncca_backward_workspace_bytes": (C.c_size_t, [C.POINTER(MpnDims), C.c_int64, C.c_int64]),
     "gnncca_mpn_backward": (C.c_int, [C.POINTER(MpnDims), C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -10,8 +10,8 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libgnncca_mpn.so")
-SOURCES = ["pack.cpp", "mpn_forward.hip", "graph_build.hip"]
-HEADERS = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".cuh"))] + [os.path.join(ROOT, "include", "gnncca_mpn.h")]
+SOURCES = ["pack.cpp", "post_host.cpp", "mpn_forward.hip", "graph_build.hip"]
+HEADERS = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".cuh", ".inc"))] + [os.path.join(ROOT, "include", "gnncca_mpn.h")]
 
 
 def _hipcc():
@@ -32,6 +32,12 @@ def needs_build():
 def build_stamps(verbose=False):
     """Diagnostic twin (tools/stamps.py): same sources with -DGNNCCA_STAMPS -> lib/libgnncca_mpn_stamps.so."""
     return build(force=True, verbose=verbose, out=os.path.join(LIB_DIR, "libgnncca_mpn_stamps.so"), defs=["-DGNNCCA_STAMPS"])
+
+
+def build_f16_ablations(verbose=False):
+    """Diagnostic twin (tools/ab_f16_ablations.sh): the fp16-split encoder GEMM's ablation kernels compiled in -> lib/libgnncca_mpn_f16abl.so
+    (select with GNNCCA_DIAG=1 GNNCCA_LIB=... GNNCCA_GEMM_F16_DIAG=n)."""
+    return build(force=True, verbose=verbose, out=os.path.join(LIB_DIR, "libgnncca_mpn_f16abl.so"), defs=["-DGNNCCA_F16_ABLATIONS"])
 
 
 def build(force=False, verbose=False, out=None, defs=()):
@@ -58,5 +64,7 @@ def build(force=False, verbose=False, out=None, defs=()):
 if __name__ == "__main__":
     if "--stamps" in sys.argv:
         print(build_stamps(verbose=True))
+    elif "--f16-ablations" in sys.argv:
+        print(build_f16_ablations(verbose=True))
     else:
         print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,385 @@
+#pragma once
+// Part of the single translation unit mpn_forward.hip.
+namespace gnncca {
+
+// ------------------------------------------------------------------------------------------------------------
+// First encoder layer on big batches, round 5: the "fp16-split" GEMM  out = x . W^T  (N >= 6144 nodes, K = in, O = 128).
+// Replaces the first nn.Linear of encoder.node_mlp (models/mpn.py:131 <- models/mlp.py:13) and, un-split (FUSE), the rest of the encoder.
+//
+// ARITHMETIC.  x = x0 + x1 / 2048 and w = w0 + w1 / 2048 with fp16 pieces: x0 = fp16(x), x1 = fp16((x - x0) * 2048) -- the residual is exact
+// in fp32 and, scaled by 2^11, sits in x0's exponent range, so the pair carries 22 significant bits of x (error <= 2^-22 |x|, or 2^-36
+// absolute below fp16's normal range).  x . w ~= x0 w0 + (x0 w1 + x1 w0) / 2048: THREE piece products on v_mfma_f32_32x32x16_f16 (every
+// product of two fp16 values is exact in fp32, accumulation is fp32) in two accumulators (the unscaled and the 2^-11 one), against the six
+// bf16 products of round 2's form -- half the matrix work for the same class of accuracy (measured against an fp64 evaluation the result
+// is closer than an fp32 GEMM's: tools/time_encoder.py --check, tests/test_gpu_parity.py).  fp16 has a narrow exponent: a workgroup whose x
+// holds a finite magnitude >= 65520 (it would round to infinity), or any workgroup when a WEIGHT does (flag words written by the packers),
+// recomputes its tile on the bf16 six-product arm inside the same launch (`bf16_arm`: range of fp32, round 2's arithmetic) -- no input
+// makes this kernel wrong, unusual ones make it slower.
+//
+// DATA MOVEMENT.  256 rows x 128 columns per workgroup, 8 waves; wave w owns rows [32 w, 32 w + 32) and ALL 128 columns, so the x operand
+// is wave-private: every wave streams its own 32 rows by LDS-DMA (buffer_load_dwordx4 ... lds: 8 rows x 128 B per instruction, full
+// lines, no VGPR staging, no ds_write) into its own three-slot ring of raw fp32, two chunks ahead, and needs NO barrier for it -- only its
+// own counted vmcnt.  The A fragments are read back as fp32 (lane (r, h): 32 B of row r per 16-deep k-step, granules XOR-swizzled on the
+// SOURCE address so that ds_read_b128 is conflict-free) and split into the two fp16 pieces in registers: each element is converted once.
+// W (pre-split at pack time, BlobHeader::enc_w2h: the LDS image chunk by chunk) goes through a shared three-slot ring the same way, ONE
+// workgroup barrier per 32-deep chunk.  LDS traffic per chunk and CU: 48 KB written by DMA + 160 KB of fragment reads, against 72 KB of
+// ds_write + 192 KB of reads in the 256-row bf16 kernel (encoder.cuh), and no conversion-store pass.
+// Workgroup b walks its k chunks from chunk (37 b) mod nk on (see enc_gemm_split_lds_kernel: 5.0 -> 6.2 TB/s for this access shape).
+// LDS: x rings 8 x 3 x 4 KB + W ring 3 x 16 KB = 144 KB (= kLdsGemmBytes); the fused epilogue reuses it.
+// ------------------------------------------------------------------------------------------------------------
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) void* lds_dma_ptr;
+
+constexpr int kF16Stages = 3;
+constexpr int kF16XSlot = 32 * 128;                                   // bytes per wave and stage: 32 rows x 32 floats
+constexpr int kF16WSlot = 2 * 128 * 64;                               // bytes per stage: 2 pieces x 128 columns x 32 halfs
+constexpr int kF16XBytes = 8 * kF16Stages * kF16XSlot;                // 98 304
+constexpr size_t kF16LdsBytes = (size_t)kF16XBytes + (size_t)kF16Stages * kF16WSlot;   // 147 456
+
+// The rest of encoder.node_mlp on a 256 x 128 tile h1 that sits in LDS as H1[256][132] (bias and ReLU applied): wave w finishes rows
+// [32 w, 32 w + 32) -- layer 2 (four partial 32x32x2 f32 MFMA tiles over k quarters, summed ((d0 + d1) + d2) + d3), h0, the step-1
+// projections.  The arithmetic of enc_gemm_split_lds_kernel's fused epilogue (encoder.cuh), statement for statement.
+__device__ __forceinline__ void enc_finish_tile_rows(float* H1, int wave, int l32, int h, int row0, int M, const EncFuseParams& fp) {
+    constexpr int LD1 = 132, LD0 = 36;
+    float* hblk = H1 + (size_t)wave * 32 * LD1;
+    f32x16 d;
+    {
+        f32x16 dq[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float* hrow = hblk + l32 * LD1 + 32 * q + 16 * h;
+            const float* w2row = fp.W2 + (size_t)l32 * 128 + 32 * q + 16 * h;
+            float av[16], bv[16];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 a4 = *reinterpret_cast<const f32x4*>(hrow + 4 * j);
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(w2row + 4 * j);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) av[4 * j + t] = a4[t], bv[4 * j + t] = b4[t];
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) dq[q][i] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) dq[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[s], dq[q], 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) d[i] = ((dq[0][i] + dq[1][i]) + dq[2][i]) + dq[3][i];
+    }
+    const float bias2 = fp.b2[l32];
+    float* H0 = hblk;   // [32][36], over this wave's own (consumed) rows of H1
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int rl = (i & 3) + 8 * (i >> 2) + 4 * h;
+        const float v = fmaxf(d[i] + bias2, 0.f);
+        H0[rl * LD0 + l32] = v;
+        const int row = row0 + wave * 32 + rl;
+        if (row < M) {
+            fp.h0[(size_t)row * kH + l32] = v;
+            if (fp.trace_h) fp.trace_h[(size_t)row * kH + l32] = v;
+        }
+    }
+    float a2[16];
+    {
+        const float* hr = H0 + l32 * LD0 + 16 * h;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 a4 = *reinterpret_cast<const f32x4*>(hr + 4 * j);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a2[4 * j + q] = a4[q];
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int slot = 32 * t + l32;
+        const bool on = slot < kProjOut;
+        float b2v[16];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) b2v[s] = on ? fp.projwT[(16 * h + s) * kProjOut + slot] : 0.f;
+        f32x16 pacc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) pacc[i] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[s], b2v[s], pacc, 0, 0, 0);
+        const float pb = on ? fp.projb[slot] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = row0 + wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+            if (row < M && on) {
+                const float v = pacc[i] + pb;
+                if (slot < kPdStride)
+                    fp.pd_out[(size_t)row * kPdStride + slot] = v;
+                else
+                    fp.psq_out[(size_t)row * kPsQStride + slot - kPdStride] = v;
+            }
+        }
+    }
+}
+
+// The bf16 six-product arm for a tile the fp16 pieces cannot carry: round 2's arithmetic (encoder.cuh: enc_gemm_split_direct_kernel's
+// loop -- x straight from global memory into three bf16 fragments, the chunk's W pieces through two LDS stages, one barrier per chunk) in
+// this kernel's tiling (wave = 32 rows x 128 columns).  Rare by construction; written for correctness, not speed.
+__device__ __forceinline__ void enc_f16_bf16_arm(f32x16 (&acc)[4], const float* __restrict__ x, const unsigned short* __restrict__ w3, int M, int K,
+                                                 int row0w, int kbeg, int nk, unsigned char* lds_raw) {
+    constexpr int BN = 128, BK = 32, LDK = 40;
+    typedef __bf16 (*wsm_t)[3][BN][LDK];
+    wsm_t wsm = reinterpret_cast<wsm_t>(lds_raw);   // [2][3][128][40] bf16 = 61 440 B
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
+    const size_t plane = (size_t)BN * BK;
+    const float* __restrict__ xrow = x + (size_t)min(row0w + (lane & 31), M - 1) * K + kbeg + 8 * h;
+    int wp[3], wcol[3], wk[3];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        const int idx = tid + 512 * u;
+        wp[u] = idx >> 9, wcol[u] = (idx & 511) >> 2, wk[u] = (idx & 3) * 8;
+    }
+    f32x4 xreg[4];
+    bf16x8 wreg[3], afrag[2][3];
+    auto load_next = [&](int kt) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            xreg[2 * ks] = *reinterpret_cast<const f32x4*>(xrow + kt * BK + ks * 16);
+            xreg[2 * ks + 1] = *reinterpret_cast<const f32x4*>(xrow + kt * BK + ks * 16 + 4);
+        }
+#pragma unroll
+        for (int u = 0; u < 3; ++u)
+            wreg[u] = *reinterpret_cast<const bf16x8*>(w3 + ((size_t)(kbeg / BK + kt) * 3 + wp[u]) * plane + wcol[u] * BK + wk[u]);
+    };
+    auto convert_x = [&]() {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float v = xreg[2 * ks + (q >> 2)][q & 3];
+                const __bf16 h0 = (__bf16)v;
+                const float r1 = v - (float)h0;
+                const __bf16 h1 = (__bf16)r1;
+                const float r2 = r1 - (float)h1;
+                afrag[ks][0][q] = h0, afrag[ks][1][q] = h1, afrag[ks][2][q] = (__bf16)r2;
+            }
+    };
+    auto store_w = [&](int stage) {
+#pragma unroll
+        for (int u = 0; u < 3; ++u) *reinterpret_cast<bf16x8*>(&wsm[stage][wp[u]][wcol[u]][wk[u]]) = wreg[u];
+    };
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[c][i] = 0.f;
+    load_next(0);
+    store_w(0);
+    convert_x();
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int stage = kt & 1;
+        if (kt + 1 < nk) load_next(kt + 1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                bf16x8 b[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) b[p] = *reinterpret_cast<const bf16x8*>(&wsm[stage][p][c * 32 + (lane & 31)][ks * 16 + 8 * h]);
+                acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[ks][2], b[0], acc[c], 0, 0, 0);   // smallest terms first
+                acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[ks][1], b[1], acc[c], 0, 0, 0);
+                acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[ks][0], b[2], acc[c], 0, 0, 0);
+                acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[ks][1], b[0], acc[c], 0, 0, 0);
+                acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[ks][0], b[1], acc[c], 0, 0, 0);
+                acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[ks][0], b[0], acc[c], 0, 0, 0);
+            }
+        if (kt + 1 < nk) {
+            store_w(stage ^ 1);
+            convert_x();
+        }
+        __syncthreads();
+    }
+}
+
+struct EncF16Params {
+    const float* x;
+    const unsigned short* w2h;     // BlobHeader::enc_w2h
+    const unsigned* w_bad;         // BlobHeader::enc_w2h_bad: kW2hBadWords words
+    const unsigned short* w3;      // BlobHeader::enc_w3 (the bf16 arm's pieces)
+    float* out;                    // split-K slabs [ks][M][128] (not FUSE)
+    int M, K, kslice;
+    int k_rotate;
+    int force_arm;                 // diagnostics / tests: 1 = every tile takes the bf16 arm
+};
+
+// DIAG (GNNCCA_DIAG builds of the ablation matrix, timing only -- the results are garbage): bit 0 = no MFMAs (the fragments stay used), bit 1 = every
+// workgroup streams the FIRST 256 rows of x (x from L2), bit 2 = no fp16 split (the raw bits of x feed the MFMAs)
+template <bool FUSE, int DIAG = 0>
+__device__ __forceinline__ void enc_gemm_f16_body(const EncF16Params p, const EncFuseParams fp) {
+    constexpr int BK = 32;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, l32 = lane & 31;
+    const int M = p.M, K = p.K;
+    if (FUSE && blockIdx.x == gridDim.x - 1) {   // the plan workgroup (its first four waves: plan_finish is written for 256 threads)
+        if (tid < 256)
+            plan_finish(fp.ei, fp.E, M, fp.seg_ptr, fp.col32, fp.perm, fp.cursor, fp.flags, fp.blockflags, reinterpret_cast<unsigned*>(lds_raw));
+        return;
+    }
+    const int row0 = blockIdx.x * 256;
+    const int kbeg = blockIdx.y * p.kslice;
+    const int nk = min(p.kslice, K - kbeg) / BK;
+    const int rot = p.k_rotate ? (int)((blockIdx.x * 37u + blockIdx.y * 11u) % (unsigned)nk) : 0;
+    auto kchunk = [&](int kt) {
+        const int kr = kt + rot;
+        return kr >= nk ? kr - nk : kr;
+    };
+    // ---- LDS-DMA sources: this workgroup's rows of x behind a descriptor of their own (rows beyond M read as zero: out of range),
+    //      the whole fp16 W image behind another ---------------------------------------------------------------------------------------
+    const int rows_here = min(256, M - row0);
+    const rsrc_t rx = make_rsrc(p.x + ((DIAG & 2) ? (size_t)0 : (size_t)row0 * K), (unsigned long long)rows_here * K * 4);
+    const rsrc_t rw = make_rsrc(p.w2h, (unsigned long long)(K / BK) * kF16WSlot);
+    unsigned xoff[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int rl = 8 * j + (lane >> 3);                           // row inside the wave's 32
+        const int gs = (lane & 7) ^ ((4 * j + (lane >> 4)) & 7);      // source granule that lands in LDS granule slot (lane & 7) of that row
+        xoff[j] = (unsigned)((size_t)(wave * 32 + rl) * K * 4 + gs * 16);
+    }
+    const unsigned woff = (unsigned)(wave * 2048 + lane * 16);
+    unsigned char* xring = lds_raw + (size_t)wave * kF16Stages * kF16XSlot;
+    unsigned char* wring = lds_raw + kF16XBytes;
+    auto issue = [&](int kt) {   // six LDS-DMA instructions: the wave's 32 rows x 128 B of x, and its eighth of the chunk's W image
+        const int kc = kchunk(kt);
+        const int st = kt % kF16Stages;
+        const unsigned xs = (unsigned)(kbeg + kc * BK) * 4u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_dma_ptr)(xring + st * kF16XSlot + j * 1024), 16, xoff[j], xs, 0, 0);
+        const unsigned ws = (unsigned)(kbeg / BK + kc) * (unsigned)kF16WSlot;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_dma_ptr)(wring + st * kF16WSlot + wave * 2048 + j * 1024), 16, woff + j * 1024, ws, 0, 0);
+    };
+    // weights beyond fp16: one word per lane of wave 0, folded with the x check below
+    unsigned wbad = (wave == 0 && lane < kW2hBadWords) ? p.w_bad[lane] : 0u;
+    issue(0);
+    if (nk > 1) issue(1);
+    f32x16 accA[4], accB[4];   // unscaled products x0 w0; products carrying one residual (x0 w1 + x1 w0), scaled by 2^11
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) accA[c][i] = 0.f, accB[c][i] = 0.f;
+    float amax = 0.f;
+    // fragment addresses: A from the wave's fp32 ring (row l32, granules 4 s + 2 h and + 1, XOR (l32 >> 1) & 7), B from the W ring
+    // (column 32 c + l32, granule 2 s + h, XOR (column >> 2) & 3 -- the image pack.cpp: w2h_index writes)
+    const int aswz = (l32 >> 1) & 7;
+    const unsigned char* abase = xring + l32 * 128;
+    int boffs[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) boffs[c] = (c * 32 + l32) * 64;
+    const int bswz = (l32 >> 2) & 3;   // ((32 c + l32) >> 2) & 3
+    for (int kt = 0; kt < nk; ++kt) {
+        // my own DMA of chunk kt has landed (issued two iterations ago; the six of chunk kt + 1 may still fly) ...
+        if (kt + 1 < nk)
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // ... and so has every other wave's share of W(kt); every wave is also past its reads of stage (kt - 1) % 3, which the DMA below refills
+        __builtin_amdgcn_s_barrier();
+        if (kt + 2 < nk) issue(kt + 2);
+        const int st = kt % kF16Stages;
+        const unsigned char* a = abase + st * kF16XSlot;
+        const unsigned char* b = wring + st * kF16WSlot;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(a + (((4 * s + 2 * h) ^ aswz) << 4));
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(a + (((4 * s + 2 * h + 1) ^ aswz) << 4));
+            f16x8 b0[4], b1[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                b0[c] = *reinterpret_cast<const f16x8*>(b + boffs[c] + (((2 * s + h) ^ bswz) << 4));
+                b1[c] = *reinterpret_cast<const f16x8*>(b + 128 * 64 + boffs[c] + (((2 * s + h) ^ bswz) << 4));
+            }
+            f16x8 a0, a1;
+            if (DIAG & 4) {
+                a0 = __builtin_bit_cast(f16x8, v0), a1 = __builtin_bit_cast(f16x8, v1);
+            } else
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x2 v = q < 2 ? f32x2{v0[2 * q], v0[2 * q + 1]} : f32x2{v1[2 * q - 4], v1[2 * q - 3]};
+                const f16x2 p0 = __builtin_convertvector(v, f16x2);                       // v_cvt_pk_f16_f32: round to nearest even
+                const f32x2 r = (v - f32x2{(float)p0[0], (float)p0[1]}) * 2048.0f;       // exact
+                const f16x2 p1 = __builtin_convertvector(r, f16x2);
+                a0[2 * q] = p0[0], a0[2 * q + 1] = p0[1];
+                a1[2 * q] = p1[0], a1[2 * q + 1] = p1[1];
+                amax = fmaxf(fmaxf(amax, fabsf(v[0])), fabsf(v[1]));
+            }
+            if (DIAG & 1) {
+                asm volatile("" ::"v"(a0), "v"(a1), "v"(b0[0]), "v"(b0[1]), "v"(b0[2]), "v"(b0[3]), "v"(b1[0]), "v"(b1[1]), "v"(b1[2]), "v"(b1[3]));
+            } else
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                accA[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0[c], accA[c], 0, 0, 0);
+                accB[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1[c], accB[c], 0, 0, 0);
+                accB[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0[c], accB[c], 0, 0, 0);
+            }
+        }
+    }
+    f32x16 acc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[c][i] = fmaf(accB[c][i], 1.0f / 2048.0f, accA[c][i]);
+    // ---- does this tile need the bf16 arm?  (workgroup-uniform: the arm has barriers) -------------------------------------------------
+    __syncthreads();   // every wave is done with the rings
+    unsigned* s_flag = reinterpret_cast<unsigned*>(lds_raw);
+    if (tid == 0) *s_flag = 0u;
+    __syncthreads();
+    if (!(amax < kF16Limit) || wbad != 0u || p.force_arm) atomicOr(s_flag, 1u);   // (a NaN in x: the arm's business too)
+    __syncthreads();
+    const bool arm = *s_flag != 0u;
+    __syncthreads();
+    if (arm) enc_f16_bf16_arm(acc, p.x, p.w3, M, K, row0 + wave * 32, kbeg, nk, lds_raw);
+    if (!FUSE) {
+        float* __restrict__ dst = p.out + (size_t)blockIdx.y * M * 128;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int col = c * 32 + l32;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = row0 + wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                if (row < M) dst[(size_t)row * 128 + col] = acc[c][i];
+            }
+        }
+        return;
+    }
+    // ---- fused epilogue: h1 = [ReLU](acc + b1) -> LDS -> the rest of the encoder (enc_finish_tile_rows) -------------------------------
+    constexpr int LD1 = 132;
+    float* H1 = reinterpret_cast<float*>(lds_raw);   // [256][132] = 135 KB over the (dead) rings
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int col = c * 32 + l32;
+        const float bias = fp.b1[col];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int rl = wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+            const float v = acc[c][i] + bias;
+            H1[rl * LD1 + col] = fp.relu_prev ? fmaxf(v, 0.f) : v;
+        }
+    }
+    __syncthreads();
+    enc_finish_tile_rows(H1, wave, l32, h, row0, M, fp);
+}
+
+// (concrete kernels around the body: with this toolchain a __global__ TEMPLATE that issues the LDS-DMA builtin from a lambda was not emitted)
+__global__ __launch_bounds__(512) void enc_gemm_f16_fused_kernel(const EncF16Params p, const EncFuseParams fp) { enc_gemm_f16_body<true>(p, fp); }
+__global__ __launch_bounds__(512) void enc_gemm_f16_split_kernel(const EncF16Params p, const EncFuseParams fp) { enc_gemm_f16_body<false>(p, fp); }
+#ifdef GNNCCA_F16_ABLATIONS   // diagnostic twin build only (tools/ab_f16_ablations.sh)
+#define GNNCCA_F16_DIAG_KERNEL(D) \
+    __global__ __launch_bounds__(512) void enc_gemm_f16_fused_diag##D##_kernel(const EncF16Params p, const EncFuseParams fp) { enc_gemm_f16_body<true, D>(p, fp); }
+GNNCCA_F16_DIAG_KERNEL(1)
+GNNCCA_F16_DIAG_KERNEL(2)
+GNNCCA_F16_DIAG_KERNEL(3)
+GNNCCA_F16_DIAG_KERNEL(4)
+GNNCCA_F16_DIAG_KERNEL(5)
+GNNCCA_F16_DIAG_KERNEL(6)
+GNNCCA_F16_DIAG_KERNEL(7)
+#endif
+
+}  // namespace gnncca

@@ -277,6 +277,7 @@ struct EncFuseParams {
     unsigned* flags;
     const unsigned* blockflags;
     int E;
+    int k_rotate;      // 1: workgroup b walks its k chunks from chunk (37 b) mod nk on, wrapping (the sum is order-free; see the kernel)
     int diag_x_rows;   // GNNCCA_DIAG experiment (0 in production): > 0 = every workgroup streams rows [0, diag_x_rows) of x instead of its
                        // own -- the same loads, conversions and MFMAs with x served from L2 (timing only: the results are garbage)
 };
@@ -315,6 +316,17 @@ __global__ __launch_bounds__(512) void enc_gemm_split_lds_kernel(const float* __
     const int row0 = blockIdx.x * RA;
     const int kbeg = blockIdx.y * kslice;
     const int nk = min(kslice, K - kbeg) / BK;
+    // k ROTATION (round 5).  Every workgroup of a round reads 128 B from each of its 256 rows (8 KB apart) per chunk, and all of them walk
+    // the same k at about the same time: the chip's 256 request streams then agree in the address bits BELOW the row stride chunk after
+    // chunk, i.e. they crowd the same memory channels (tools/ubench_xring.hip: this walk streams at 5.0 TB/s, the same walk with every
+    // workgroup STARTING at another chunk at 6.2 -- the linear-sweep rate).  A dot product does not care where its sum starts, so
+    // workgroup b takes its chunks in the order rot, rot + 1, ..., nk - 1, 0, ..., rot - 1 with rot = 37 b mod nk.  The summation ORDER
+    // then depends on the row block, which is why GNNCCA_OPT_ENC_UNSPLIT (bitwise batch independence) runs with k_rotate = 0.
+    const int rot = fp.k_rotate ? (int)((blockIdx.x * 37u + blockIdx.y * 11u) % (unsigned)nk) : 0;
+    auto kchunk = [&](int kt) {
+        const int kr = kt + rot;
+        return kr >= nk ? kr - nk : kr;
+    };
     // loader roles: x chunk = 256 rows x 8 float4 -> 4 per thread; W chunk = 1536 16-B granules -> 3 per thread
     const float* xsrc[4];
     int xdst[4];
@@ -335,13 +347,15 @@ __global__ __launch_bounds__(512) void enc_gemm_split_lds_kernel(const float* __
     f32x4 xr[4];
     bf16x8 wreg[3];
     auto load_x = [&](int kt) {
+        const int kc = kchunk(kt);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) xr[u] = *reinterpret_cast<const f32x4*>(xsrc[u] + kt * BK);
+        for (int u = 0; u < 4; ++u) xr[u] = *reinterpret_cast<const f32x4*>(xsrc[u] + kc * BK);
     };
     auto load_w = [&](int kt) {
+        const int kc = kchunk(kt);
 #pragma unroll
         for (int u = 0; u < 3; ++u)
-            wreg[u] = *reinterpret_cast<const bf16x8*>(w3 + (size_t)(kbeg / BK + kt) * wchunk + (size_t)(tid + 512 * u) * 8);
+            wreg[u] = *reinterpret_cast<const bf16x8*>(w3 + (size_t)(kbeg / BK + kc) * wchunk + (size_t)(tid + 512 * u) * 8);
     };
     auto store_stage = [&](int stage) {
         __bf16* a = sa + (size_t)stage * 3 * RA * BK;
@@ -462,8 +476,9 @@ __global__ __launch_bounds__(512) void enc_gemm_split_lds_kernel(const float* __
         // x in two register sets (chunk k in set k & 1), W in one (its source is L2-resident)
         f32x4 xs[1][4];
         auto load_x2 = [&](int kt, f32x4 (&dst)[4]) {
+            const int kc = kchunk(kt);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) dst[u] = *reinterpret_cast<const f32x4*>(xsrc[u] + kt * BK);
+            for (int u = 0; u < 4; ++u) dst[u] = *reinterpret_cast<const f32x4*>(xsrc[u] + kc * BK);
         };
         auto store_stage2 = [&](int stage, const f32x4 (&src)[4], const bf16x8 (&wsrc)[3]) {
             __bf16* a = sa + (size_t)stage * 3 * RA * BK;

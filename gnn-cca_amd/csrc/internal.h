@@ -16,7 +16,7 @@ extern thread_local int g_last_hip_error;  // hipError_t of the last failed HIP 
 const char* diag_env(const char* name);
 int diag_env_int(const char* name, int fallback, int lo, int hi);
 
-constexpr uint32_t kBlobMagic = 0x4D504E35u;  // "MPN5": bumped with every change of the blob layout (a blob is only
+constexpr uint32_t kBlobMagic = 0x4D504E36u;  // "MPN6": bumped with every change of the blob layout (a blob is only
                                               // valid for the library build that packed it; load_packed_blob checks)
 constexpr int kH = 32;        // node latent width the MFMA step kernel is built for (node_out_dim)
 constexpr int kEF = 6;        // edge latent width (edge_out_dim): 3 k-steps of v_mfma_f32_32x32x2_f32
@@ -51,8 +51,14 @@ struct BlobHeader {
     int32_t fast_consts;                    // [kFastConsts] contiguous copy of the per-step scalars (see below), or 0
     int32_t enc_w3;                         // first encoder weight as 3 bf16 pieces, [in/32][3][out][32], or 0
     int32_t wne_bf16;                       // [9][64] dwords: W_ne as packed bf16 piece pairs, the B operands of msg_bf16.cuh
-    int32_t pad[5];
+    int32_t enc_w2h;                        // first encoder weight as 2 fp16 pieces (w = w0 + w1 / 2048), the LDS image of enc_f16.cuh:
+                                            // [in/32][2 pieces][out = 128][32] halfs, 16-B granule kc of column c stored at kc ^ ((c >> 2) & 3); or 0
+    int32_t enc_w2h_bad;                    // [kW2hBadWords] words: non-zero where a weight does not fit fp16 (|w| >= 65520): the fp16 GEMM then
+                                            // hands every tile to its bf16 arm
+    int32_t pad[3];
 };
+constexpr int kW2hBadWords = 64;            // one per pack block (pack_device_kernel's grid is 64 wide): no atomics, nothing to reset
+constexpr float kF16Limit = 65520.0f;       // the smallest magnitude that fp16 round-to-nearest-even turns into infinity
 
 // Layout of the `fast_consts` block (floats): the per-step scalars mpn_step_fast_kernel reads into SGPRs.
 // Present when edge_in == 4, no reattach flags and the classifier is Linear(6,4)+ReLU+Linear(4,1).
@@ -74,7 +80,9 @@ bool fast_consts_ok(const gnncca_mpn_dims* d);
 // folding / splitting as gnncca_pack_weights, bit for bit, without the parameters ever visiting the host.
 struct PackSeg {
     int32_t kind;               // 0: weight element, 1: bias element, 2: weight element split into 3 bf16 planes,
-                                // 3: W_ne element (row = channel, column = k < 6) as bf16 pieces in the MsgB lane layout
+                                // 3: W_ne element (row = channel, column = k < 6) as bf16 pieces in the MsgB lane layout,
+                                // 4: weight element split into 2 fp16 pieces in the swizzled chunk image of BlobHeader::enc_w2h
+                                //    (dst = enc_w2h, unit0 unused, plane = float offset of the kW2hBadWords flag words)
     int32_t dst;                // float offset in the blob (kind 2: offset of plane 0)
     int32_t param;              // index of the Linear's weight (kind 0, 2) or bias (kind 1) in the parameter list
     int32_t bn;                 // index of the BatchNorm weight (gamma; beta, mean, var follow), or -1

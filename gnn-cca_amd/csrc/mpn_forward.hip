@@ -27,6 +27,7 @@
 #include "step_general.cuh"
 #include "step_fast.cuh"
 #include "step_pipe.cuh"
+#include "enc_f16.cuh"
 #include "generic_fused.cuh"
 #include "generic.cuh"
 #include "postprocess.cuh"
@@ -201,6 +202,8 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
             std::memset(&fp, 0, sizeof(fp));
             static const int gemm_x_l2 = diag_env_int("GNNCCA_GEMM_X_L2_ROWS", 0, 1, 256);   // diagnostics: x served from L2 (timing only)
             fp.diag_x_rows = gemm_x_l2;
+            static const bool no_rot = diag_env("GNNCCA_GEMM_NO_KROT") != nullptr;   // diagnostics: A/B the k rotation of the 256-row GEMM
+            fp.k_rotate = ((options & GNNCCA_OPT_ENC_UNSPLIT) == 0 && !no_rot) ? 1 : 0;
             if (fused_tail) {
                 fp.b1 = blob + hdr.enc_node_b[0];
                 fp.W2 = blob + hdr.enc_node_w[1];
@@ -231,10 +234,19 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
                 }
                 plan_launched = true;
             }
+            // The fp16-split form (enc_f16.cuh) is the default of the 256-row regime; the bf16 form stays for GNNCCA_OPT_ENC_UNSPLIT (whose
+            // bitwise batch independence is stated on the bf16 arithmetic of all three un-split kernels), for GNNCCA_OPT_ENC_SPLIT3 (an option
+            // of that form) and as the A/B reference (GNNCCA_GEMM_BF16).  K / ks_split is a multiple of 32 on this path.
+            static const bool gemm_bf16 = diag_env("GNNCCA_GEMM_BF16") != nullptr;
+            static const int f16_force_arm = diag_env_int("GNNCCA_GEMM_F16_ARM", 0, 0, 1);   // diagnostics / tests: every tile on the bf16 arm
+            const bool use_f16 = use_lds && !use_r32 && hdr.enc_w2h != 0 && !split3 && (options & GNNCCA_OPT_ENC_UNSPLIT) == 0 && !gemm_bf16 &&
+                                 gemm_x_l2 == 0 && K % 32 == 0 && (K / ks_split) % 32 == 0;
             static thread_local int attr_dev = -1;  // once per device and thread: the attribute is per device
             int dev = 0;
             HIP_TRY(hipGetDevice(&dev));
             if (attr_dev != dev) {
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(enc_gemm_f16_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kF16LdsBytes));
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(enc_gemm_f16_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kF16LdsBytes));
                 const void* fns[8] = {reinterpret_cast<const void*>(enc_gemm_split_lds_kernel<false, false>),
                                       reinterpret_cast<const void*>(enc_gemm_split_lds_kernel<true, false>),
                                       reinterpret_cast<const void*>(enc_gemm_split_lds_kernel<false, true>),
@@ -262,6 +274,33 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
                     GNNCCA_LAUNCH((enc_gemm_rows32_fused_kernel<true, 4>), rgrid, dim3(256), 0, st, cur_in, w3, N, K, fp);
                 else
                     GNNCCA_LAUNCH((enc_gemm_rows32_fused_kernel<false, 4>), rgrid, dim3(256), 0, st, cur_in, w3, N, K, fp);
+            } else if (use_lds && use_f16) {
+                // round 5: the fp16-split GEMM (enc_f16.cuh) -- three piece products, x and W by LDS-DMA rings; same grids, same epilogues
+                EncF16Params q;
+                std::memset(&q, 0, sizeof(q));
+                q.x = cur_in;
+                q.w2h = reinterpret_cast<const unsigned short*>(blob + hdr.enc_w2h);
+                q.w_bad = reinterpret_cast<const unsigned*>(blob + hdr.enc_w2h_bad);
+                q.w3 = w3;
+                q.out = part;
+                q.M = N, q.K = K, q.kslice = K / ks_split;
+                q.k_rotate = fp.k_rotate;
+                q.force_arm = f16_force_arm;
+                const dim3 fgrid((N + 255) / 256 + 1, 1), sgrid((N + 255) / 256, ks_split);
+#ifdef GNNCCA_F16_ABLATIONS
+                static const int f16_diag = diag_env_int("GNNCCA_GEMM_F16_DIAG", 0, 0, 7);
+                if (fused_tail && f16_diag) {
+                    typedef void (*kfn)(const EncF16Params, const EncFuseParams);
+                    static const kfn fns[8] = {nullptr, enc_gemm_f16_fused_diag1_kernel, enc_gemm_f16_fused_diag2_kernel, enc_gemm_f16_fused_diag3_kernel,
+                                               enc_gemm_f16_fused_diag4_kernel, enc_gemm_f16_fused_diag5_kernel, enc_gemm_f16_fused_diag6_kernel, enc_gemm_f16_fused_diag7_kernel};
+                    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fns[f16_diag]), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kF16LdsBytes));
+                    GNNCCA_LAUNCH(fns[f16_diag], fgrid, dim3(512), kF16LdsBytes, st, q, fp);
+                } else
+#endif
+                if (fused_tail)
+                    GNNCCA_LAUNCH(enc_gemm_f16_fused_kernel, fgrid, dim3(512), kF16LdsBytes, st, q, fp);
+                else
+                    GNNCCA_LAUNCH(enc_gemm_f16_split_kernel, sgrid, dim3(512), kF16LdsBytes, st, q, fp);
             } else if (use_lds) {
                 // 256-row workgroups, both operands through LDS (144 KB: one workgroup per CU, 8 waves); split-K by whole
                 // rounds of 256 workgroups (internal.h: enc_lds_ksplit)
@@ -733,17 +772,52 @@ int gnncca_post_prune_cluster_frames(const int64_t* edge_index, const int64_t* p
                                      void* workspace, size_t workspace_bytes, int64_t* pruned_out, int32_t* flow_out,
                                      int32_t* flow_in, int32_t* labels_out, int32_t* n_clusters_out,
                                      gnncca_stream_t stream) {
+    return gnncca_post_prune_cluster_frames_ex(edge_index, predictions, n_nodes, n_edges, node_ptr_dev, edge_ptr_dev, n_frames, workspace,
+                                               workspace_bytes, pruned_out, flow_out, flow_in, labels_out, n_clusters_out, nullptr, nullptr, stream);
+}
+
+// `plan` (internal; null from the public entry points): the graph plan the MPN forward of the same batch left in ITS workspace (seg_ptr,
+// col32, perm, flags) -- gnncca_frames_forward hands it over, so the pruning needs no plan launches of its own
+struct PostPlan {
+    const int* seg_ptr;
+    const int* col32;
+    const int* perm;
+    const unsigned* flags;
+};
+static int post_prune_cluster_impl(const int64_t* edge_index, const int64_t* predictions, int64_t n_nodes, int64_t n_edges,
+                                   const int32_t* node_ptr_dev, const int32_t* edge_ptr_dev, int32_t n_frames, void* workspace,
+                                   size_t workspace_bytes, int64_t* pruned_out, int32_t* flow_out, int32_t* flow_in, int32_t* labels_out,
+                                   int32_t* n_clusters_out, int32_t* sizes_scratch, int32_t* triggers_out, const PostPlan* plan,
+                                   gnncca_stream_t stream);
+
+int gnncca_post_prune_cluster_frames_ex(const int64_t* edge_index, const int64_t* predictions, int64_t n_nodes, int64_t n_edges,
+                                        const int32_t* node_ptr_dev, const int32_t* edge_ptr_dev, int32_t n_frames, void* workspace,
+                                        size_t workspace_bytes, int64_t* pruned_out, int32_t* flow_out, int32_t* flow_in,
+                                        int32_t* labels_out, int32_t* n_clusters_out, int32_t* sizes_scratch, int32_t* triggers_out,
+                                        gnncca_stream_t stream) {
+    return post_prune_cluster_impl(edge_index, predictions, n_nodes, n_edges, node_ptr_dev, edge_ptr_dev, n_frames, workspace, workspace_bytes,
+                                   pruned_out, flow_out, flow_in, labels_out, n_clusters_out, sizes_scratch, triggers_out, nullptr, stream);
+}
+
+static int post_prune_cluster_impl(const int64_t* edge_index, const int64_t* predictions, int64_t n_nodes, int64_t n_edges,
+                                   const int32_t* node_ptr_dev, const int32_t* edge_ptr_dev, int32_t n_frames, void* workspace,
+                                   size_t workspace_bytes, int64_t* pruned_out, int32_t* flow_out, int32_t* flow_in, int32_t* labels_out,
+                                   int32_t* n_clusters_out, int32_t* sizes_scratch, int32_t* triggers_out, const PostPlan* plan,
+                                   gnncca_stream_t stream) {
     if (n_nodes < 0 || n_edges < 0 || n_frames < 0) return GNNCCA_ERR_INVALID_ARG;
+    if ((sizes_scratch == nullptr) != (triggers_out == nullptr)) return GNNCCA_ERR_INVALID_ARG;
     if ((node_ptr_dev == nullptr) != (edge_ptr_dev == nullptr) || (node_ptr_dev != nullptr && n_frames == 0))
         return GNNCCA_ERR_INVALID_ARG;
     if (n_nodes >= (1ll << 31) - 64 || n_edges >= (1ll << 31) - 64) return GNNCCA_ERR_UNSUPPORTED;
+    const size_t n_trig = (size_t)(node_ptr_dev ? n_frames : 1);
     if (n_nodes == 0) {
         if (n_clusters_out) HIP_TRY(hipMemsetAsync(n_clusters_out, 0, sizeof(int32_t), static_cast<hipStream_t>(stream)));
+        if (triggers_out) HIP_TRY(hipMemsetAsync(triggers_out, 0, n_trig * sizeof(int32_t), static_cast<hipStream_t>(stream)));
         return GNNCCA_OK;
     }
     if (!workspace || !flow_out || !flow_in || !labels_out || !n_clusters_out) return GNNCCA_ERR_INVALID_ARG;
     if (n_edges > 0 && (!edge_index || !predictions || !pruned_out)) return GNNCCA_ERR_INVALID_ARG;
-    if (workspace_bytes < gnncca_post_workspace_bytes(n_nodes, n_edges)) return GNNCCA_ERR_WORKSPACE;
+    if (!plan && workspace_bytes < gnncca_post_workspace_bytes(n_nodes, n_edges)) return GNNCCA_ERR_WORKSPACE;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int N = (int)n_nodes, E = (int)n_edges;
     auto up = [](size_t v) { return (v + 255) / 256 * 256; };
@@ -759,19 +833,30 @@ int gnncca_post_prune_cluster_frames(const int64_t* edge_index, const int64_t* p
     int* perm = reinterpret_cast<int*>(base + off);
     off += up((size_t)E * 4);
     int* cursor = reinterpret_cast<int*>(base + off);
+    if (plan) {   // the MPN forward's plan of the same edge_index: nothing to build here
+        seg_ptr = const_cast<int*>(plan->seg_ptr), col32 = const_cast<int*>(plan->col32), perm = const_cast<int*>(plan->perm);
+        flags = const_cast<unsigned*>(plan->flags);
+    }
     const long long* ei = reinterpret_cast<const long long*>(edge_index);
     const long long* pred = reinterpret_cast<const long long*>(predictions);
     long long* pruned = reinterpret_cast<long long*>(pruned_out);
     // zero the counters: one memset when the caller laid flow_out | flow_in | n_clusters out back to back (gnn_cca_amd.postprocess does)
     const bool one_block = flow_in == flow_out + N && n_clusters_out == flow_in + N;
-    if (one_block) {
+    const bool trig_block = one_block && triggers_out && sizes_scratch == n_clusters_out + 1 && triggers_out == sizes_scratch + N;
+    if (trig_block) {
+        HIP_TRY(hipMemsetAsync(flow_out, 0, ((size_t)3 * N + 1 + n_trig) * 4, st));
+    } else if (one_block) {
         HIP_TRY(hipMemsetAsync(flow_out, 0, ((size_t)2 * N + 1) * 4, st));
     } else {
         HIP_TRY(hipMemsetAsync(flow_out, 0, (size_t)N * 4, st));
         HIP_TRY(hipMemsetAsync(flow_in, 0, (size_t)N * 4, st));
         HIP_TRY(hipMemsetAsync(n_clusters_out, 0, sizeof(int32_t), st));
     }
-    if (E > 0) {
+    if (triggers_out && !trig_block) {
+        HIP_TRY(hipMemsetAsync(sizes_scratch, 0, (size_t)N * 4, st));
+        HIP_TRY(hipMemsetAsync(triggers_out, 0, n_trig * 4, st));
+    }
+    if (E > 0 && !plan) {
         EncPlanParams ep;
         std::memset(&ep, 0, sizeof(ep));
         ep.ei = ei;
@@ -783,16 +868,19 @@ int gnncca_post_prune_cluster_frames(const int64_t* edge_index, const int64_t* p
         hipLaunchKernelGGL(plan_only_kernel, dim3(plan_num_blocks(E)), dim3(256), 0, st, ep);
         HIP_TRY(hipGetLastError());
     }
-    hipLaunchKernelGGL(gen_plan_finish_kernel, dim3(1), dim3(256), 0, st, ei, E, N, seg_ptr, col32, perm, cursor, flags,
-                       (const unsigned*)blockflags);
-    HIP_TRY(hipGetLastError());
+    if (!plan) {
+        hipLaunchKernelGGL(gen_plan_finish_kernel, dim3(1), dim3(256), 0, st, ei, E, N, seg_ptr, col32, perm, cursor, flags,
+                           (const unsigned*)blockflags);
+        HIP_TRY(hipGetLastError());
+    }
     if (E > 0) {
         hipLaunchKernelGGL(post_prune_kernel, grid1((size_t)E, 256), dim3(256), 0, st, ei, pred, (long long)E, (const int*)seg_ptr,
                            (const int*)col32, (const int*)perm, (const unsigned*)flags, pruned, flow_out, flow_in);
         HIP_TRY(hipGetLastError());
     }
     hipLaunchKernelGGL(post_cc_kernel, dim3(node_ptr_dev ? (unsigned)n_frames : 1u), dim3(1024), 0, st, ei,
-                       (const long long*)pruned, (long long)E, N, node_ptr_dev, edge_ptr_dev, labels_out, n_clusters_out);
+                       (const long long*)pruned, (long long)E, N, node_ptr_dev, edge_ptr_dev, labels_out, n_clusters_out,
+                       (const int*)flow_out, (const int*)flow_in, sizes_scratch, triggers_out);
     HIP_TRY(hipGetLastError());
     return GNNCCA_OK;
 }
@@ -837,8 +925,26 @@ int gnncca_frames_forward(const gnncca_mpn_dims* d, const void* packed_dev, cons
         st = gnncca_post_threshold(io->logits + (size_t)(n_out - 1) * e, e, io->probs, io->predictions, stream);
         if (st != GNNCCA_OK) return st;
     }
-    return gnncca_post_prune_cluster_frames(io->edge_index, io->predictions, n, e, fr.graph_ptr, edge_ptr_g, (int32_t)g, post_workspace,
-                                            post_workspace_bytes, io->pruned, io->counters, io->counters + n, io->labels, io->counters + 2 * n, stream);
+    // the pruning searches reverse edges in the CSR plan of edge_index -- the one the forward above left in ITS workspace (seg_ptr / col32 /
+    // perm / flag word: same plan_block + plan_finish, same stream): handed over instead of being built a second time (two launches less)
+    PostPlan plan;
+    const PostPlan* have_plan = nullptr;
+    if (e > 0 && mpn_workspace) {
+        char* wb = static_cast<char*>(mpn_workspace);
+        if (classify(d) == kFamilyMfma32x6) {
+            const Workspace ws = carve(d, n, e);
+            plan = PostPlan{reinterpret_cast<const int*>(wb + ws.seg_ptr), reinterpret_cast<const int*>(wb + ws.col32),
+                            reinterpret_cast<const int*>(wb + ws.perm), reinterpret_cast<const unsigned*>(wb + ws.flags)};
+        } else {
+            const GenWorkspace ws = carve_generic(d, n, e);
+            plan = PostPlan{reinterpret_cast<const int*>(wb + ws.seg_ptr), reinterpret_cast<const int*>(wb + ws.col32),
+                            reinterpret_cast<const int*>(wb + ws.perm), reinterpret_cast<const unsigned*>(wb + ws.flags)};
+        }
+        have_plan = &plan;
+    }
+    int32_t* c = io->counters;   // flow_out | flow_in | n_clusters | sizes (scratch) | triggers [G]
+    return post_prune_cluster_impl(io->edge_index, io->predictions, n, e, fr.graph_ptr, edge_ptr_g, (int32_t)g, post_workspace, post_workspace_bytes,
+                                   io->pruned, c, c + n, io->labels, c + 2 * n, c + 2 * n + 1, c + 3 * n + 1, have_plan, stream);
 }
 
 // ---- backward ---------------------------------------------------------------------------

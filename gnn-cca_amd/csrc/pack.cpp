@@ -176,6 +176,49 @@ static inline float bf16_to_float(uint16_t h) {
     return f;
 }
 
+// fp32 -> fp16, round to nearest even, subnormals kept, |f| >= 65520 -> infinity: bit for bit v_cvt_f16_f32 in the default float mode
+// (what `(_Float16)v` compiles to in pack_device_kernel)
+static inline uint16_t f16_rne(float f) {
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    const uint16_t sign = (uint16_t)((u >> 16) & 0x8000u);
+    const uint32_t a = u & 0x7FFFFFFFu;
+    if (a >= 0x7F800000u) return (uint16_t)(sign | 0x7C00u | ((a > 0x7F800000u) ? 0x0200u : 0u));   // inf / NaN
+    if (a >= 0x477FF000u) return (uint16_t)(sign | 0x7C00u);                                          // >= 65520: rounds to infinity
+    if (a >= 0x38800000u) {                                                                            // normal fp16 range: 2^-14 ...
+        const uint32_t m = a - 0x38000000u;                                                            // rebias 127 -> 15
+        return (uint16_t)(sign | (uint16_t)((m + 0xFFFu + ((m >> 13) & 1u)) >> 13));                  // (a carry into the exponent is the right answer)
+    }
+    if (a < 0x33000000u) return sign;                                                                  // < 2^-25: rounds to zero (2^-25 itself ties to even = 0)
+    // subnormal fp16: value = mant * 2^-24 with mant = round(|f| * 2^24)
+    const int e = (int)(a >> 23);                                                                      // 102 ... 112
+    const uint32_t mant = (a & 0x7FFFFFu) | 0x800000u;                                                // 24-bit significand, |f| = mant * 2^(e - 150)
+    const int sh = 126 - e;                                                                            // mant >> sh = |f| * 2^24
+    const uint32_t q = mant >> sh, rem = mant & ((1u << sh) - 1u), half = 1u << (sh - 1);
+    return (uint16_t)(sign | (uint16_t)(q + ((rem > half || (rem == half && (q & 1u))) ? 1u : 0u)));
+}
+static inline float f16_to_float(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 0x1Fu, m = h & 0x3FFu;
+    uint32_t u;
+    if (e == 0x1Fu) u = sign | 0x7F800000u | (m << 13);
+    else if (e != 0) u = sign | ((e + 112u) << 23) | (m << 13);
+    else if (m == 0) u = sign;
+    else {
+        int s = 0;
+        uint32_t mm = m;
+        while (!(mm & 0x400u)) mm <<= 1, ++s;
+        u = sign | ((uint32_t)(113 - s) << 23) | ((mm & 0x3FFu) << 13);
+    }
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+}
+// position (in halfs) of piece 0 of weight element (output column o, input i) in the enc_w2h image; piece 1 sits 128 * 32 halfs further
+static inline size_t w2h_index(int o, int i) {
+    const int kc = (i % 32) / 8;
+    return (size_t)(i / 32) * (2 * 128 * 32) + (size_t)o * 32 + (size_t)(((kc ^ ((o >> 2) & 3)) << 3) + (i % 8));
+}
+
 // ---------------------------------------------------------------------------------------------
 struct BlobPlan {
     BlobHeader h;
@@ -220,6 +263,10 @@ static BlobPlan plan_blob(const gnncca_mpn_dims* d) {
     }
     p.h.fast_consts = fast_consts_ok(d) ? take(kFastConsts) : 0;
     p.h.enc_w3 = enc_split_ok(d) ? take((size_t)3 * d->enc_node.layers[0].in_dim * d->enc_node.layers[0].out_dim / 2) : 0;
+    if (p.h.enc_w3) {   // (enc_split_ok: out = 128) the same weight as two fp16 pieces for enc_f16.cuh, plus its overflow words
+        p.h.enc_w2h = take((size_t)d->enc_node.layers[0].in_dim * d->enc_node.layers[0].out_dim);   // 2 pieces x 2 B = 4 B per element
+        p.h.enc_w2h_bad = take(kW2hBadWords);
+    }
     p.total_floats = off;
     p.h.total_floats = (uint32_t)off;
     return p;
@@ -312,6 +359,12 @@ bool pack_program(const gnncca_mpn_dims* d, PackProgram* out) {
             PackSeg& g = out->segs[n++];
             g.kind = 2, g.dst = p.h.enc_w3, g.param = L.w, g.bn = L.bn, g.rows = L.out, g.cols = L.in, g.drs = 0, g.dcs = 0;
             g.srs = L.in, g.scs = 1, g.plane = L.out * 32;  // [in/32][3 pieces][out][32]: see gnncca_pack_weights
+        }
+        if (i == 0 && p.h.enc_w2h) {
+            if (n >= kMaxPackSegs) return false;
+            PackSeg& g = out->segs[n++];
+            g.kind = 4, g.dst = p.h.enc_w2h, g.param = L.w, g.bn = L.bn, g.rows = L.out, g.cols = L.in, g.drs = 0, g.dcs = 0;
+            g.srs = L.in, g.scs = 1, g.plane = p.h.enc_w2h_bad;
         }
         if (i == d->enc_node.n_layers - 1) weight(L, p.h.enc_last_wT, 0, kH, L.in, 0, 1, kH, L.in, 1);
     }
@@ -451,6 +504,23 @@ int gnncca_pack_weights(const gnncca_mpn_dims* d, const float* const* params, in
                     w3[k] = h0;
                     w3[plane + k] = h1;
                     w3[2 * plane + k] = bf16_rne(r2);
+                }
+        }
+        if (i == 0 && p.h.enc_w2h) {
+            // w = w0 + w1 / 2048 with fp16 pieces (w1 = the residual scaled into w0's exponent range; 22 significant bits in all): the
+            // fp16-split GEMM of enc_f16.cuh needs THREE piece products where the bf16 form needs six.  A weight beyond fp16's range sets
+            // the flag word of the pack block that owns the element (device packer: element t belongs to block (t / 256) % 64).
+            uint16_t* w2 = reinterpret_cast<uint16_t*>(blob + p.h.enc_w2h);
+            uint32_t* bad = reinterpret_cast<uint32_t*>(blob + p.h.enc_w2h_bad);
+            for (int o = 0; o < f.out; ++o)
+                for (int i = 0; i < f.in; ++i) {
+                    const float v = f.w[(size_t)o * f.in + i];
+                    const uint16_t h0 = f16_rne(v);
+                    const float r = (v - f16_to_float(h0)) * 2048.0f;
+                    const size_t k = w2h_index(o, i);
+                    w2[k] = h0;
+                    w2[k + 128 * 32] = f16_rne(r);
+                    if (!(std::fabs(v) < kF16Limit)) bad[(((size_t)o * f.in + i) / 256) % kW2hBadWords] = 1u;
                 }
         }
         if (i == d->enc_node.n_layers - 1)
@@ -620,7 +690,7 @@ static const char* const kDiagSwitches[] = {
     "GNNCCA_DIAG", "GNNCCA_LIB", "GNNCCA_STAMPS", "GNNCCA_STEP_R2", "GNNCCA_STEP_NOMEM", "GNNCCA_STEP_NOEPI", "GNNCCA_STEP_NOHOOK", "GNNCCA_STEP_EARLYBAR",
     "GNNCCA_STEP_NORANGE", "GNNCCA_RANGE_MAX_E", "GNNCCA_PD_LDS_MIN", "GNNCCA_PD_LDS_MAX", "GNNCCA_TAIL_NPW", "GNNCCA_WPS", "GNNCCA_NO_NT", "GNNCCA_NO_PAD",
     "GNNCCA_GEMM_DIRECT", "GNNCCA_GEMM_SPLIT_MIN", "GNNCCA_GEMM_LDS_MIN", "GNNCCA_GEMM_NOPIPE", "GNNCCA_NO_FUSE", "GNNCCA_NO_MFMA_TAIL",
-    "GNNCCA_TAIL_MFMA_MIN", "GNNCCA_NO_RIDE", "GNNCCA_GEMM_DIRECT_WG", "GNNCCA_GEMM_R32_NST", "GNNCCA_GEN_UNFUSED", "GNNCCA_NPW", "GNNCCA_NPW_MIN_N", "GNNCCA_NPW_MIN_N_FIRST", "GNNCCA_DEFER_CLS", "GNNCCA_GEMM_X_L2_ROWS", "GNNCCA_NPW_MAX_CHUNKS"};
+    "GNNCCA_TAIL_MFMA_MIN", "GNNCCA_NO_RIDE", "GNNCCA_GEMM_DIRECT_WG", "GNNCCA_GEMM_R32_NST", "GNNCCA_GEN_UNFUSED", "GNNCCA_NPW", "GNNCCA_NPW_MIN_N", "GNNCCA_NPW_MIN_N_FIRST", "GNNCCA_DEFER_CLS", "GNNCCA_GEMM_X_L2_ROWS", "GNNCCA_NPW_MAX_CHUNKS", "GNNCCA_GEMM_NO_KROT", "GNNCCA_GEMM_BF16", "GNNCCA_GEMM_F16_ARM", "GNNCCA_GEMM_F16_DIAG"};
 
 extern "C" char** environ;
 

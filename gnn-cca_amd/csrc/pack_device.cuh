@@ -31,6 +31,7 @@ __global__ __launch_bounds__(256) void pack_device_kernel(const PackProgram* __r
     const float *gamma = nullptr, *beta = nullptr, *mean = nullptr, *var = nullptr;
     if (g.bn >= 0) gamma = ptrs.p[g.bn], beta = ptrs.p[g.bn + 1], mean = ptrs.p[g.bn + 2], var = ptrs.p[g.bn + 3];
     const long long total = (long long)g.rows * g.cols;
+    int f16_bad = 0;   // kind 4: an element of this block does not fit fp16
     for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
         const int r = (int)(t / g.cols), c = (int)(t - (long long)r * g.cols);
         float v = src[(size_t)g.src_off + (size_t)r * g.srs + (size_t)c * g.scs];
@@ -56,6 +57,15 @@ __global__ __launch_bounds__(256) void pack_device_kernel(const PackProgram* __r
             wb[384 + j2 + 2 * r] = wb[384 + j2 + 2 * (r + 32)] = h1;
             wb[768 + j2 + 2 * r] = h2;
             wb[768 + j2 + 2 * (r + 32)] = h0;
+        } else if (g.kind == 4) {   // two fp16 pieces in the swizzled chunk image of enc_f16.cuh (pack.cpp: w2h_index); `(_Float16)` is
+            // v_cvt_f16_f32: round to nearest even, subnormals kept -- pack.cpp's f16_rne bit for bit
+            _Float16* w2 = reinterpret_cast<_Float16*>(blob + g.dst);
+            const _Float16 h0 = (_Float16)v;
+            const float rr = (v - (float)h0) * 2048.0f;
+            const size_t kk = (size_t)(c / 32) * (2 * 128 * 32) + (size_t)r * 32 + (size_t)(((((c % 32) / 8) ^ ((r >> 2) & 3)) << 3) + (c % 8));
+            w2[kk] = h0;
+            w2[kk + 128 * 32] = (_Float16)rr;
+            if (!(fabsf(v) < kF16Limit)) f16_bad = 1;
         } else if (g.kind == 2) {
             unsigned short* w3 = reinterpret_cast<unsigned short*>(blob + g.dst);
             const unsigned short h0 = pack_bf16_rne(v);
@@ -68,6 +78,10 @@ __global__ __launch_bounds__(256) void pack_device_kernel(const PackProgram* __r
         } else {
             blob[(size_t)g.dst + k] = v;
         }
+    }
+    if (g.kind == 4) {   // (block-uniform) this block's overflow word: written every time, so a repack needs no reset and no atomics
+        const int any = __syncthreads_or(f16_bad);
+        if (threadIdx.x == 0 && blockIdx.x < kW2hBadWords) reinterpret_cast<unsigned*>(blob + g.plane)[blockIdx.x] = any ? 1u : 0u;
     }
 }
 

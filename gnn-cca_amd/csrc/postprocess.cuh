@@ -55,9 +55,14 @@ __global__ __launch_bounds__(256) void post_prune_kernel(const long long* __rest
 // edge_ptr of a disjoint union of frame graphs, edges of a frame contiguous: Batch.from_data_list's layout) every frame
 // gets its own workgroup -- components never cross frames -- and the batch is processed frames-wide in parallel.
 // *n_clusters must be zero on entry.
+// `triggers` (optional; zero on entry, with `sizes` [N_all]): this workgroup's frame sets bit 0 of its word when one of its nodes has
+// flow_out or flow_in > 3 (libs/utils.py:58-62: compute_rounding has work to do) and bit 1 when one of its clusters has more than four
+// members (libs/utils.py:321-322: disjoint_big_clusters has) -- the two conditions under which the host heuristics change the frame.
 __global__ __launch_bounds__(1024) void post_cc_kernel(const long long* __restrict__ ei, const long long* __restrict__ pred,
                                                        long long E_all, int N_all, const int* __restrict__ node_ptr,
-                                                       const int* __restrict__ edge_ptr, int* labels, int* n_clusters) {
+                                                       const int* __restrict__ edge_ptr, int* labels, int* n_clusters,
+                                                       const int* __restrict__ flow_out, const int* __restrict__ flow_in, int* sizes,
+                                                       int* triggers) {
     __shared__ int s_changed;
     const int tid = threadIdx.x;
     const int v0 = node_ptr ? node_ptr[blockIdx.x] : 0, v1 = node_ptr ? node_ptr[blockIdx.x + 1] : N_all;
@@ -95,6 +100,17 @@ __global__ __launch_bounds__(1024) void post_cc_kernel(const long long* __restri
     int mine = 0;
     for (int v = v0 + tid; v < v1; v += 1024) mine += ld(v) == v;
     if (mine) atomicAdd(n_clusters, mine);
+    if (triggers) {
+        int trig = 0;
+        for (int v = v0 + tid; v < v1; v += 1024) {
+            if (flow_out[v] > 3 || flow_in[v] > 3) trig |= 1;      // (final: the prune kernel is a launch of its own, before this one)
+            atomicAdd(&sizes[ld(v)], 1);
+        }
+        __syncthreads();   // (the adds above are counted in vmcnt, which the barrier waits for: they are performed)
+        for (int v = v0 + tid; v < v1; v += 1024)
+            if (ld(v) == v && __hip_atomic_load(&sizes[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 4) trig |= 2;
+        if (trig) atomicOr(&triggers[blockIdx.x], trig);
+    }
 }
 
 // ---- frame padding for the one-graph-fits-all-frames replay (gnn_cca_amd.inference.GraphedForward(pad_to=...)) ---------------------------

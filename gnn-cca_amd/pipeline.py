@@ -10,6 +10,13 @@ and the Python between five calls is a third of it: 0.143 -> 0.11 ms per batch.
     pipe = FramePipeline(model)                                     # model: gnn_cca_amd.MOTMPNet on the GPU, eval mode
     r = pipe(xw, yw, ids, id_cam, graph_sizes, max_dist, node_embeds, reid_embeds)
     r.labels, r.n_clusters, r.pruned, r.preds, r.probs, r.outputs['classified_edges'], r.batch (x, edge_index, edge_attr, ...)
+    r.triggers                                                      # [G] int32 on the device: frames the host heuristics can change
+    f = r.final()                                                   # the reference's FINAL predictions / ID_pred partition under
+    f['predictions'], f['labels'], f['n_clusters']                  # ROUNDING / PRUNING / SPLITTING (config_inference.yaml:6-8)
+
+`r.final()` (= `postprocess.finalize`) synchronises once to read the trigger words; frames that raised none keep the device chain's result
+(it is final for them), the others go through the reference's rounding / splitting heuristics on the host (csrc/post_host.cpp), frame by
+frame as the reference's batch-size-1 validation loop does.  The constructor's `rounding` / `pruning` / `splitting` mirror CONFIG's keys.
 
 Batches of more than 4096 detections, train mode and forward hooks take the step-by-step path (same results).  No CPU fallback."""
 import ctypes as C
@@ -19,7 +26,7 @@ import torch
 
 from . import _native as nat
 from .graph_build import MODE_FULL, MODE_ONLY_APPEARANCE, MODE_ONLY_DIST, _as, _current_stream, _on, _raw_stream, _Staging, _staging, build_graph_batch
-from .postprocess import prune_and_cluster, threshold
+from .postprocess import finalize, prune_and_cluster, threshold
 from .sharding import GraphBatch
 
 MAX_NODES = 4096
@@ -27,12 +34,25 @@ MAX_NODES = 4096
 
 class FrameResult:
     """Outputs of one batch; tensors are views of three device buffers owned by this object."""
-    __slots__ = ("batch", "outputs", "probs", "preds", "pruned", "flow_out", "flow_in", "labels", "n_clusters", "_keep")
+    __slots__ = ("batch", "outputs", "probs", "preds", "pruned", "flow_out", "flow_in", "labels", "n_clusters", "triggers", "_switches", "_final", "_keep")
+
+    def final(self):
+        """The reference's final predictions and identity clusters for this batch (inference.py:306-345 under the pipeline's ROUNDING /
+        PRUNING / SPLITTING switches): `postprocess.finalize` on this result, computed once.  Synchronises."""
+        if self._final is None:
+            b = self.batch
+            r, p, s = self._switches
+            self._final = finalize(b.edge_index, self.probs, self.pruned, self.labels, self.n_clusters, self.triggers, b.node_ptr, b.edge_ptr,
+                                   rounding=r, pruning=p, splitting=s)
+        return self._final
 
 
 class FramePipeline:
-    def __init__(self, model, only_appearance=False, only_dist=False, normalize=True):
+    def __init__(self, model, only_appearance=False, only_dist=False, normalize=True, rounding=True, pruning=True, splitting=True):
         self.model = model
+        if not pruning:
+            raise ValueError("FramePipeline prunes on the device (PRUNING = True, as config_inference.yaml:7 ships it)")
+        self.switches = (bool(rounding), bool(pruning), bool(splitting))
         self.mode = MODE_ONLY_APPEARANCE if only_appearance else (MODE_ONLY_DIST if only_dist else MODE_FULL)
         self.normalize = bool(normalize)
         self._post_ws = {}   # (stream, bytes) -> workspace tensor
@@ -49,6 +69,7 @@ class FramePipeline:
         r.probs, r.preds = threshold(out["classified_edges"][-1])
         post = prune_and_cluster(b.edge_index, r.preds, b.x.shape[0], b.node_ptr_dev, b.edge_ptr_dev)
         r.pruned, r.flow_out, r.flow_in, r.labels, r.n_clusters = post["pruned"], post["flow_out"], post["flow_in"], post["labels"], post["n_clusters"]
+        r.triggers, r._switches, r._final = post["triggers"], self.switches, None
         r._keep = post
         return r
 
@@ -110,7 +131,7 @@ class FramePipeline:
             f32 = torch.empty(o_prob + e, dtype=torch.float32, device=dev)
             o_pred, o_prun = up(2 * e), up(2 * e) + up(e)
             i64 = torch.empty(o_prun + e, dtype=torch.int64, device=dev)
-            o_labels = up(2 * n + 1)
+            o_labels = up(3 * n + 1 + g)      # flow_out | flow_in | n_clusters | cluster sizes (scratch) | triggers [G]
             i32 = torch.empty(o_labels + n, dtype=torch.int32, device=dev)
             if self._shape != (n, e):
                 self._shape = (n, e)
@@ -153,5 +174,6 @@ class FramePipeline:
         r.probs = f32[o_prob:o_prob + e]
         r.preds, r.pruned = i64[o_pred:o_pred + e], i64[o_prun:o_prun + e]
         r.flow_out, r.flow_in, r.n_clusters, r.labels = i32[:n], i32[n:2 * n], i32[2 * n:2 * n + 1], i32[o_labels:o_labels + n]
+        r.triggers, r._switches, r._final = i32[3 * n + 1:3 * n + 1 + g], self.switches, None
         r._keep = (staged, f32, i64, i32, ws, post_ws, blob)
         return r

@@ -3,8 +3,16 @@
 `threshold` = inference.py:286-291 (sigmoid, >= 0.5); `prune_and_cluster` = utils.remove_edges_single_direction
 (libs/utils.py:387-404) + the flow counts of utils.compute_rounding (libs/utils.py:54-59) + the clusters
 utils.compute_SCC_and_Clusters (libs/utils.py:295-317) returns for the pruned edge set -- without the networkx /
-Python-list round trips through the host.  The bridge-based rounding and splitting heuristics are not reproduced here.
+Python-list round trips through the host -- and, per frame, the two TRIGGER bits of the reference's bridge-based heuristics
+(a node with flow > 3: utils.compute_rounding has work to do, libs/utils.py:58-62; a cluster with more than four members:
+utils.disjoint_big_clusters has, libs/utils.py:321-322).  `finalize` runs those heuristics, in the order of the shipped
+configuration (config_inference.yaml:6-8 ROUNDING / PRUNING / SPLITTING = True; inference.py:306-345), for the frames that
+raised a bit: native host code (csrc/post_host.cpp; SURVEY.md 8f keeps the bridge searches on the CPU), one frame at a time
+as the reference does.  A frame with no bit set already has its final partition.
 """
+import ctypes as C
+
+import numpy as np
 import torch
 
 from . import _native as nat
@@ -46,13 +54,16 @@ def prune_and_cluster(edge_index, predictions, n_nodes, node_ptr=None, edge_ptr=
     e = ei.shape[1]
     lib = nat.lib()
     ws = torch.empty(lib.gnncca_post_workspace_bytes(n_nodes, e) + 256, dtype=torch.uint8, device=dev)
-    counters = torch.empty(2 * n_nodes + 1, dtype=torch.int32, device=dev)   # flow_out | flow_in | n_clusters: zeroed by ONE memset
+    if (node_ptr is None) != (edge_ptr is None):
+        raise ValueError("node_ptr and edge_ptr go together")
+    n_trig = (len(node_ptr) if not torch.is_tensor(node_ptr) else node_ptr.numel()) - 1 if node_ptr is not None else 1
+    # flow_out | flow_in | n_clusters | cluster sizes (scratch) | triggers: zeroed by ONE memset
+    counters = torch.empty(3 * n_nodes + 1 + max(n_trig, 1), dtype=torch.int32, device=dev)
     out = {"pruned": torch.empty(e, dtype=torch.int64, device=dev),
            "flow_out": counters[:n_nodes], "flow_in": counters[n_nodes:2 * n_nodes],
            "labels": torch.empty(n_nodes, dtype=torch.int32, device=dev),
-           "n_clusters": counters[2 * n_nodes:]}
-    if (node_ptr is None) != (edge_ptr is None):
-        raise ValueError("node_ptr and edge_ptr go together")
+           "n_clusters": counters[2 * n_nodes:2 * n_nodes + 1],
+           "triggers": counters[3 * n_nodes + 1:3 * n_nodes + 1 + max(n_trig, 1)]}
     n_frames, np_dev, ep_dev = 0, None, None
     if node_ptr is not None:
         def as_dev(v):
@@ -66,13 +77,61 @@ def prune_and_cluster(edge_index, predictions, n_nodes, node_ptr=None, edge_ptr=
         if ep_dev.numel() != n_frames + 1 or n_frames < 1:
             raise ValueError("node_ptr / edge_ptr must both have G + 1 entries")
     with _on(dev):
-        st = lib.gnncca_post_prune_cluster_frames(ei.data_ptr(), pred.data_ptr(), n_nodes, e,
-                                                  np_dev.data_ptr() if np_dev is not None else None,
-                                                  ep_dev.data_ptr() if ep_dev is not None else None, n_frames,
-                                                  ws.data_ptr(), ws.numel(), out["pruned"].data_ptr(),
-                                                  out["flow_out"].data_ptr(), out["flow_in"].data_ptr(),
-                                                  out["labels"].data_ptr(), out["n_clusters"].data_ptr(), _stream(dev))
+        cp = counters.data_ptr()
+        st = lib.gnncca_post_prune_cluster_frames_ex(ei.data_ptr(), pred.data_ptr(), n_nodes, e,
+                                                     np_dev.data_ptr() if np_dev is not None else None,
+                                                     ep_dev.data_ptr() if ep_dev is not None else None, n_frames,
+                                                     ws.data_ptr(), ws.numel(), out["pruned"].data_ptr(),
+                                                     cp, cp + 4 * n_nodes, out["labels"].data_ptr(), cp + 8 * n_nodes,
+                                                     cp + 8 * n_nodes + 4, cp + 12 * n_nodes + 4, _stream(dev))
     if st:
         nat.check(st, "gnncca_post_prune_cluster")
     out["_workspace"] = (ws, np_dev, ep_dev)
     return out
+
+
+def finalize(edge_index, probs, pruned, labels, n_clusters, triggers, node_ptr=None, edge_ptr=None, rounding=True, pruning=True,
+             splitting=True):
+    """The reference's FINAL predictions and identity clusters under the three switches of config_inference.yaml:6-8 (inference.py:306-345:
+    PRUNING -> ROUNDING -> PRUNING -> SPLITTING), from what `threshold` + `prune_and_cluster` left on the device.
+
+    `triggers` [G] (prune_and_cluster's) says which frames the heuristics can change; this call SYNCHRONISES to read it.  Frames with no
+    bit set keep the device chain's result -- it is final for them.  For the others the frame's edges, probabilities and pruned predictions
+    are copied to the host, `gnncca_post_finalize_frame_host` (csrc/post_host.cpp: utils.compute_rounding, remove_edges_single_direction,
+    disjoint_big_clusters, compute_SCC_and_Clusters with the reference's artefacts) runs frame by frame, and the patched tensors go back.
+    `node_ptr` / `edge_ptr`: HOST sequences of G + 1 ints (GraphBatch.node_ptr / .edge_ptr); None = the whole graph is one frame.
+
+    -> dict(predictions int64 [E], labels int32 [N], n_clusters int32 [1] on the device, frames_finalized: list of frame ids,
+            triggers: host int32 [G]).  `pruning=False` is refused: the device chain has already pruned."""
+    if not pruning:
+        raise ValueError("finalize works on the pruned predictions of prune_and_cluster (PRUNING = True, as shipped)")
+    trig = triggers.cpu().numpy()          # the one synchronisation of this stage
+    want = (nat.POST_TRIGGER_ROUNDING if rounding else 0) | (nat.POST_TRIGGER_SPLITTING if splitting else 0)
+    todo = np.nonzero(trig & want)[0].tolist()
+    if not todo:
+        return {"predictions": pruned, "labels": labels, "n_clusters": n_clusters, "frames_finalized": [], "triggers": trig}
+    n, e = labels.shape[0], pruned.shape[0]
+    if node_ptr is None:
+        node_ptr, edge_ptr = [0, n], [0, e]
+    node_ptr, edge_ptr = [int(v) for v in node_ptr], [int(v) for v in edge_ptr]
+    ei = edge_index.cpu().numpy()
+    pr = np.ascontiguousarray(probs.reshape(-1).cpu().numpy(), dtype=np.float32)
+    pred = pruned.cpu().numpy().copy()
+    lab = labels.cpu().numpy().copy()
+    src, dst = np.ascontiguousarray(ei[0]), np.ascontiguousarray(ei[1])
+    total = int(n_clusters.cpu().numpy()[0])
+    switches = (nat.POST_ROUNDING if rounding else 0) | nat.POST_PRUNING | (nat.POST_SPLITTING if splitting else 0)
+    lib = nat.lib()
+    k_new = C.c_int32(0)
+    for g in todo:
+        v0, v1, k0, k1 = node_ptr[g], node_ptr[g + 1], edge_ptr[g], edge_ptr[g + 1]
+        before = int((lab[v0:v1] == np.arange(v0, v1)).sum())
+        st = lib.gnncca_post_finalize_frame_host(src.ctypes.data + 8 * k0, dst.ctypes.data + 8 * k0, v0, v1 - v0, k1 - k0,
+                                                 pr.ctypes.data + 4 * k0, pred.ctypes.data + 8 * k0, switches,
+                                                 lab.ctypes.data + 4 * v0, C.byref(k_new), None)
+        if st:
+            nat.check(st, "gnncca_post_finalize_frame_host")
+        total += int(k_new.value) - before
+    dev = pruned.device
+    return {"predictions": torch.from_numpy(pred).to(dev), "labels": torch.from_numpy(lab).to(dev),
+            "n_clusters": torch.tensor([total], dtype=torch.int32, device=dev), "frames_finalized": todo, "triggers": trig}

@@ -285,6 +285,38 @@ GNNCCA_API int gnncca_post_prune_cluster_frames(const int64_t* edge_index, const
                                                 int64_t* pruned_out, int32_t* flow_out, int32_t* flow_in,
                                                 int32_t* labels_out, int32_t* n_clusters_out, gnncca_stream_t stream);
 
+/* The same with the two TRIGGER bits of the host heuristics per frame (or for the whole graph when no frame ranges are given):
+ * triggers_out[g] bit 0 (GNNCCA_POST_TRIGGER_ROUNDING) = a node of frame g has flow_out or flow_in > 3 after the pruning -- the condition
+ * under which utils.compute_rounding changes anything (libs/utils.py:58-62); bit 1 (GNNCCA_POST_TRIGGER_SPLITTING) = a cluster of frame g
+ * has more than four members -- utils.disjoint_big_clusters' (libs/utils.py:321-322).  A frame with no bit set already has its final
+ * ID_pred under ROUNDING / PRUNING / SPLITTING = True: rounding returns [], the second pruning is idempotent, splitting returns at once.
+ * `sizes_scratch` [N] int32 and `triggers_out` [max(n_frames, 1)] int32 are zeroed by the call (one memset with the counters when they
+ * follow n_clusters_out in memory: flow_out | flow_in | n_clusters | sizes | triggers).  Both null: the call above. */
+#define GNNCCA_POST_TRIGGER_ROUNDING 1
+#define GNNCCA_POST_TRIGGER_SPLITTING 2
+GNNCCA_API int gnncca_post_prune_cluster_frames_ex(const int64_t* edge_index, const int64_t* predictions, int64_t n_nodes,
+                                                   int64_t n_edges, const int32_t* node_ptr_dev, const int32_t* edge_ptr_dev,
+                                                   int32_t n_frames, void* workspace, size_t workspace_bytes,
+                                                   int64_t* pruned_out, int32_t* flow_out, int32_t* flow_in,
+                                                   int32_t* labels_out, int32_t* n_clusters_out, int32_t* sizes_scratch,
+                                                   int32_t* triggers_out, gnncca_stream_t stream);
+
+/* Row N2, second half, for ONE frame on the HOST ("bridges-based heuristics stay on CPU"): the reference's call sequence
+ * inference.py:306-345 after the threshold -- by the three switches of config_inference.yaml:6-8 (all True as shipped):
+ * utils.remove_edges_single_direction (libs/utils.py:387-404) -> utils.compute_rounding (25-173) -> remove_edges_single_direction ->
+ * utils.disjoint_big_clusters (319-386) -> utils.compute_SCC_and_Clusters (295-317).  Plain host arrays: `src` / `dst` [E] the frame's
+ * edges in the reference's edge order with node ids in [node_base, node_base + n_nodes), `probs` [E] the sigmoid values, `predictions`
+ * [E] in: the thresholded (or already pruned) 0 / 1 predictions, out: the final ones.  labels_out [n_nodes] (optional) = smallest
+ * batch-global node id of the node's final cluster, *n_clusters_out (optional) = number of final clusters, id_pred_out [n_nodes]
+ * (optional) = the reference's ID_pred, its label NUMBERING included (networkx's generation order: see csrc/post_host.cpp).
+ * Frames are processed one at a time as the reference does (validation batch size 1, main.py:368). */
+#define GNNCCA_POST_ROUNDING 1
+#define GNNCCA_POST_PRUNING 2
+#define GNNCCA_POST_SPLITTING 4
+GNNCCA_API int gnncca_post_finalize_frame_host(const int64_t* src, const int64_t* dst, int64_t node_base, int64_t n_nodes,
+                                               int64_t n_edges, const float* probs, int64_t* predictions, int32_t switches,
+                                               int32_t* labels_out, int32_t* n_clusters_out, int64_t* id_pred_out);
+
 /* ---- rows N1 + the path + N2 in ONE call: a batch of frames from the uploaded staging image to identity clusters -------------------
  * The per-batch body of inference.py:189-345 (normalise the embeddings, build the graph, MOTMPNet.forward, sigmoid / threshold,
  * prune, flow counts, clusters) as the same launches gnncca_normalize_columns2 / gnncca_build_edges / gnncca_mpn_forward_ex /
@@ -307,7 +339,7 @@ typedef struct gnncca_frames_io {
     float* probs;                  /* [E] out: sigmoid of the last classified step                                     */
     int64_t* predictions;          /* [E] out                                                                          */
     int64_t* pruned;               /* [E] out                                                                          */
-    int32_t* counters;             /* [2 N + 1] out: flow_out | flow_in | n_clusters                                   */
+    int32_t* counters;             /* [3 N + 1 + G] out: flow_out | flow_in | n_clusters | cluster sizes (scratch) | triggers [G] */
     int32_t* labels;               /* [N] out                                                                          */
 } gnncca_frames_io;
 GNNCCA_API int gnncca_frames_forward(const gnncca_mpn_dims* dims, const void* packed_dev, const gnncca_frames_io* io,

@@ -22,7 +22,7 @@ def pytest_configure(config):
 
 def golden_cases():
     names = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
-    return [n for n in names if not n.startswith(("weights_", "graph_", "ckpt_", "post_", "bwd_", "drop_", "lw_", "rng_", "terrace_"))]
+    return [n for n in names if not n.startswith(("weights_", "graph_", "ckpt_", "post_", "post2_", "bwd_", "drop_", "lw_", "rng_", "terrace_"))]
 
 
 @pytest.fixture(scope="session")

@@ -169,16 +169,33 @@ class BlobHeader(C.Structure):  # mirror of csrc/internal.h: BlobHeader
                 ("enc_edge_b", C.c_int32), ("wee", C.c_int32), ("wne_b", C.c_int32), ("proj_wT", C.c_int32),
                 ("proj_b", C.c_int32), ("cls_layers", C.c_int32), ("cls_hidden", C.c_int32), ("cls_w1", C.c_int32),
                 ("cls_b1", C.c_int32), ("cls_w2", C.c_int32), ("cls_b2", C.c_int32), ("fast_consts", C.c_int32),
-                ("enc_w3", C.c_int32), ("wne_bf16", C.c_int32), ("pad", C.c_int32 * 5)]
+                ("enc_w3", C.c_int32), ("wne_bf16", C.c_int32), ("enc_w2h", C.c_int32), ("enc_w2h_bad", C.c_int32),
+                ("pad", C.c_int32 * 3)]
 
 
 def blob_forward(blob_u8, params, arch, x, edge_index, edge_attr):
     raw = blob_u8.numpy().tobytes()
     h = BlobHeader.from_buffer_copy(raw[:C.sizeof(BlobHeader)])
     f = np.frombuffer(raw, dtype=np.float32)
-    assert h.magic == 0x4D504E35 and h.total_floats * 4 == len(raw)
+    assert h.magic == 0x4D504E36 and h.total_floats * 4 == len(raw)   # "MPN6"
     enc = params["encoder_feats_dict"]["nodes"][arch]
     dims = [enc["node_in_dim"]] + list(enc["node_fc_dims"]) + [enc["node_out_dim"]]
+    if h.enc_w2h:   # the fp16 piece image of the first encoder weight (csrc/enc_f16.cuh): w0 = fp16(w), w1 = fp16((w - w0) * 2048), bit for bit
+        # numpy's round-to-nearest-even conversions, at [in / 32][piece][out][32] with the 16-B granule kc of column c stored at kc ^ ((c >> 2) & 3)
+        K, O = dims[0], dims[1]
+        assert O == 128 and K % 32 == 0
+        W = f[h.enc_node_w[0]:h.enc_node_w[0] + K * O].reshape(O, K)
+        img = np.frombuffer(raw, dtype=np.float16)[2 * h.enc_w2h:2 * h.enc_w2h + 2 * K * O].reshape(K // 32, 2, O, 4, 8)
+        o = np.arange(O)[:, None]
+        kc = np.arange(4)[None, :]
+        nat = img[:, :, o, kc ^ ((o >> 2) & 3), :]                      # [chunk][piece][out][kc][8] in natural k order
+        w0 = nat[:, 0].transpose(1, 0, 2, 3).reshape(O, K)
+        w1 = nat[:, 1].transpose(1, 0, 2, 3).reshape(O, K)
+        want0 = W.astype(np.float16)
+        want1 = ((W - want0.astype(np.float32)) * np.float32(2048)).astype(np.float16)
+        assert np.array_equal(w0.view(np.uint16), want0.view(np.uint16)) and np.array_equal(w1.view(np.uint16), want1.view(np.uint16))
+        bad = np.frombuffer(raw, dtype=np.uint32)[h.enc_w2h_bad:h.enc_w2h_bad + 64]
+        assert bad.any() == bool((np.abs(W) >= 65520).any())
     nf = 2 if params["reattach_initial_nodes"] else 1
     ef = 2 if params["reattach_initial_edges"] else 1
     edge_in = params["encoder_feats_dict"]["edges"]["edge_in_dim"]
@@ -300,6 +317,13 @@ def run_pack_program(prog, params, nbytes):
             u16[j2 + 2 * r], u16[j2 + 2 * (r + 32)] = h0, h0
             u16[384 + j2 + 2 * r], u16[384 + j2 + 2 * (r + 32)] = h1, h1
             u16[768 + j2 + 2 * r], u16[768 + j2 + 2 * (r + 32)] = h2, h0
+        elif g.kind == 4:   # two fp16 pieces in the swizzled chunk image of csrc/enc_f16.cuh + this element's pack-block flag word
+            h0 = v.astype(np.float16)
+            h1 = ((v - h0.astype(np.float32)) * np.float32(2048)).astype(np.float16)
+            kk = 2 * g.dst + (c // 32) * (2 * 128 * 32) + r * 32 + (((((c % 32) // 8) ^ ((r >> 2) & 3)) << 3) + (c % 8))
+            u16[kk], u16[kk + 128 * 32] = h0.view(np.uint16), h1.view(np.uint16)
+            t = r * g.cols + c
+            np.bitwise_or.at(blob.view(np.uint32), g.plane + (t // 256) % 64, (~(np.abs(v) < 65520.0)).astype(np.uint32))
         elif g.kind == 2:
             k = (c // 32) * 3 * g.plane + r * 32 + (c % 32)   # [in/32][3 pieces][out][32]
             h0 = _bf16_rne(v)

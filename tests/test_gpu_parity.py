@@ -251,6 +251,55 @@ def test_lds_staged_split_gemm_vs_fp64_oracle(n_nodes):
         assert np.abs(o.cpu().numpy() - r).max() <= TOL_TIGHT * 2
 
 
+@pytest.mark.parametrize("n_nodes", [6144 + 9, 51200 + 33])
+@pytest.mark.parametrize("what", ["x_beyond_fp16", "w_beyond_fp16", "x_tiny"])
+def test_fp16_split_gemm_range_guard(n_nodes, what):
+    """The fp16-split GEMM (csrc/enc_f16.cuh, round 5) carries x and W as two fp16 pieces each.  fp16's exponent is narrow: a workgroup
+    that meets a finite |x| >= 65520, or any workgroup when a weight is that large (flag words written by the packers), must recompute
+    its tile on the bf16 six-product arm; magnitudes below fp16's normal range (6.1e-5) degrade gracefully (absolute error <= 2^-36 per
+    element).  Encoder output against an fp64 evaluation -- RELATIVE to each row's magnitude where huge values are planted -- and logits
+    against the fp32 oracle; split-K (6153 nodes) and fused un-split (51 233 nodes) launches."""
+    params, arch, sd = _default_model(1.0)
+    sd = {k: np.array(v, copy=True) for k, v in sd.items()}
+    rng = np.random.default_rng(n_nodes)
+    x = rng.standard_normal((n_nodes, 2048)).astype(np.float32)
+    x /= np.linalg.norm(x, axis=0, keepdims=True)
+    hot = [5, 300, n_nodes - 2]
+    if what == "x_beyond_fp16":
+        x[hot[0], 7] = 7.0e4           # just beyond fp16 (65504)
+        x[hot[1], 2040] = -3.0e9
+        x[hot[2], 1000] = 65519.0      # still rounds to 65504: no arm needed for this one, and it must be right either way
+    elif what == "w_beyond_fp16":
+        sd["encoder.node_mlp.fc_layers.0.weight"][17, 33] = 1.0e5
+    else:
+        x[hot[0]] *= 1e-4              # a whole row far below fp16's normal range
+        x[hot[1], ::2] = 0.0
+    src = np.repeat(np.arange(n_nodes), 2)
+    dst = (src + np.tile([1, 5], n_nodes)) % n_nodes
+    ei = np.stack([src, dst]).astype(np.int64)
+    ea = rng.random((ei.shape[1], 4)).astype(np.float32)
+    orc = NumpyOracle(params, arch, sd, np.float32)
+    tr = {}
+    ref = orc.forward(x, ei, ea, tr)
+    m = build(params, arch, sd)
+    d = Data(torch.from_numpy(x).cuda(), torch.from_numpy(ei).cuda(), torch.from_numpy(ea).cuda())
+    trace = {}
+    with torch.no_grad():
+        out = [t.clone() for t in m(d)["classified_edges"]]
+        m(d, trace=trace)
+    h64 = NumpyOracle(params, arch, sd, np.float64)._mlp("encoder.node_mlp", x.astype(np.float64))
+    got = trace["h_enc"].cpu().numpy().astype(np.float64)
+    assert np.isfinite(got).all()
+    scale = np.maximum(np.abs(h64).max(axis=1, keepdims=True), 1.0)          # per row: planted values make a row's outputs huge
+    err_gpu = (np.abs(got - h64) / scale).max()
+    err_ref = (np.abs(tr["h_enc"] - h64) / scale).max()
+    assert err_gpu <= max(4 * err_ref, 2e-7), (err_gpu, err_ref)
+    for o, r in zip(out, ref):
+        o = o.cpu().numpy()
+        assert np.isfinite(o).all()
+        assert (np.abs(o - r) / np.maximum(np.abs(r), 1.0)).max() <= TOL_TIGHT * 2
+
+
 @pytest.mark.parametrize("n_nodes,products", [(4096 + 3, 6), (8192, 6), (8192 + 5, 6), (16384 + 77, 6), (30000, 6), (8192 + 5, 3)])
 def test_unsplit_32_row_encoder_vs_fp64_oracle(n_nodes, products):
     """`model.encoder_unsplit = True`: mid-size batches take the un-split 32-row split-bf16 GEMM with the fused epilogue

@@ -48,7 +48,7 @@ def _same(r, ref):
     for a, c in zip(r.outputs["classified_edges"], out["classified_edges"]):
         assert a.shape == c.shape and torch.equal(a, c)
     assert torch.equal(r.probs, probs) and torch.equal(r.preds, preds)
-    for k in ("pruned", "flow_out", "flow_in", "labels", "n_clusters"):
+    for k in ("pruned", "flow_out", "flow_in", "labels", "n_clusters", "triggers"):
         assert torch.equal(getattr(r, k), post[k]), k
 
 
@@ -73,6 +73,28 @@ def test_one_call_equals_the_step_by_step_path(g, seed):
     torch.cuda.synchronize()
     _same(r, ref)
     assert int(r.n_clusters.item()) >= 1 and 0 < int(r.pruned.sum().item()) < r.pruned.numel()
+    # the reference's FINAL result (ROUNDING / PRUNING / SPLITTING = True, inference.py:306-345): every frame through the oracle's restatement
+    # of the heuristics (pinned by the reference's goldens in tests/test_post_heuristics.py) on the GPU's own probabilities
+    from oracle import post_oracle as po
+    fin = r.final()
+    assert fin is r.final()
+    ei, probs = r.batch.edge_index.cpu().numpy(), r.probs.cpu().numpy()
+    got_pred, got_lab = fin["predictions"].cpu().numpy(), fin["labels"].cpu().numpy()
+    trig = r.triggers.cpu().numpy()
+    total, flagged = 0, 0
+    for q in range(len(r.batch.node_ptr) - 1):
+        v0, v1, k0, k1 = r.batch.node_ptr[q], r.batch.node_ptr[q + 1], r.batch.edge_ptr[q], r.batch.edge_ptr[q + 1]
+        _, want, ids, k = po.finalize(ei[:, k0:k1] - v0, None, v1 - v0, probs=probs[k0:k1])
+        assert np.array_equal(got_pred[k0:k1], want), q
+        assert po.same_partition(got_lab[v0:v1], ids), q
+        total += k
+        changed = not np.array_equal(want, r.pruned.cpu().numpy()[k0:k1])
+        assert not (changed and trig[q] == 0), q          # a frame the heuristics change always raises a trigger
+        flagged += int(trig[q] != 0)
+    assert int(fin["n_clusters"].item()) == total
+    assert fin["frames_finalized"] == [q for q in range(len(trig)) if trig[q]]
+    if g >= 64:
+        assert flagged >= 1
 
 
 def test_shapes_alternate_and_fallbacks_agree():
