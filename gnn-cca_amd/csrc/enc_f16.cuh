@@ -204,6 +204,7 @@ struct EncF16Params {
     int M, K, kslice;
     int k_rotate;
     int force_arm;                 // diagnostics / tests: 1 = every tile takes the bf16 arm
+    int prio_late_half;            // 1: waves 4-7 run the main loop at s_setprio 1
 };
 
 // DIAG (GNNCCA_DIAG builds of the ablation matrix, timing only -- the results are garbage): bit 0 = no MFMAs (the fragments stay used), bit 1 = every
@@ -221,6 +222,7 @@ __device__ __forceinline__ void enc_gemm_f16_body(const EncF16Params p, const En
             plan_finish(fp.ei, fp.E, M, fp.seg_ptr, fp.col32, fp.perm, fp.cursor, fp.flags, fp.blockflags, reinterpret_cast<unsigned*>(lds_raw));
         return;
     }
+    PHASE_T_DECL;
     const int row0 = blockIdx.x * 256;
     const int kbeg = blockIdx.y * p.kslice;
     const int nk = min(p.kslice, K - kbeg) / BK;
@@ -244,22 +246,26 @@ __device__ __forceinline__ void enc_gemm_f16_body(const EncF16Params p, const En
     const unsigned woff = (unsigned)(wave * 2048 + lane * 16);
     unsigned char* xring = lds_raw + (size_t)wave * kF16Stages * kF16XSlot;
     unsigned char* wring = lds_raw + kF16XBytes;
-    auto issue = [&](int kt) {   // six LDS-DMA instructions: the wave's 32 rows x 128 B of x, and its eighth of the chunk's W image
-        const int kc = kchunk(kt);
+    // six LDS-DMA instructions per wave and chunk: the wave's 32 rows x 128 B of x (j = 0 ... 3), and its eighth of the chunk's W image (4, 5)
+    // (kt beyond the last chunk: a clamped duplicate into a stage nobody reads any more -- the loop stays branch-free and every iteration
+    // leaves exactly six instructions in flight, which is what its one counted wait assumes)
+    auto issue_one = [&](int kt, int j) {
+        const int kc = kchunk(min(kt, nk - 1));
         const int st = kt % kF16Stages;
-        const unsigned xs = (unsigned)(kbeg + kc * BK) * 4u;
+        if (j < 4)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_dma_ptr)(xring + st * kF16XSlot + j * 1024), 16, xoff[j & 3], (unsigned)(kbeg + kc * BK) * 4u, 0, 0);
+        else
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_dma_ptr)(wring + st * kF16WSlot + wave * 2048 + (j - 4) * 1024), 16, woff + (j - 4) * 1024,
+                                                     (unsigned)(kbeg / BK + kc) * (unsigned)kF16WSlot, 0, 0);
+    };
+    auto issue = [&](int kt) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_dma_ptr)(xring + st * kF16XSlot + j * 1024), 16, xoff[j], xs, 0, 0);
-        const unsigned ws = (unsigned)(kbeg / BK + kc) * (unsigned)kF16WSlot;
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_dma_ptr)(wring + st * kF16WSlot + wave * 2048 + j * 1024), 16, woff + j * 1024, ws, 0, 0);
+        for (int j = 0; j < 6; ++j) issue_one(kt, j);
     };
     // weights beyond fp16: one word per lane of wave 0, folded with the x check below
     unsigned wbad = (wave == 0 && lane < kW2hBadWords) ? p.w_bad[lane] : 0u;
     issue(0);
-    if (nk > 1) issue(1);
+    issue(1);
     f32x16 accA[4], accB[4];   // unscaled products x0 w0; products carrying one residual (x0 w1 + x1 w0), scaled by 2^11
 #pragma unroll
     for (int c = 0; c < 4; ++c)
@@ -274,15 +280,22 @@ __device__ __forceinline__ void enc_gemm_f16_body(const EncF16Params p, const En
 #pragma unroll
     for (int c = 0; c < 4; ++c) boffs[c] = (c * 32 + l32) * 64;
     const int bswz = (l32 >> 2) & 3;   // ((32 c + l32) >> 2) & 3
+    // two waves share every SIMD; the later-dispatched half loses every arbitration at equal priority (stamps: its compute phase took
+    // 2650 cycles per chunk against 1900, and the first half then waited for it at the barrier): one static priority for that half
+    if (p.prio_late_half && wave >= 4) __builtin_amdgcn_s_setprio(1);
+    PHASE_T(4);   // prologue
     for (int kt = 0; kt < nk; ++kt) {
+        PHASE_T(3);
         // my own DMA of chunk kt has landed (issued two iterations ago; the six of chunk kt + 1 may still fly) ...
-        if (kt + 1 < nk)
-            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        PHASE_T(0);
         // ... and so has every other wave's share of W(kt); every wave is also past its reads of stage (kt - 1) % 3, which the DMA below refills
         __builtin_amdgcn_s_barrier();
-        if (kt + 2 < nk) issue(kt + 2);
+        PHASE_T(1);
+        // The six DMA instructions of chunk kt + 2 are NOT issued here in one burst: the CU takes in an LDS-DMA instruction every ~36 cycles
+        // (stamps: 48 of them after the barrier stalled waves 4-7 for 1700 cycles per chunk while their MFMAs waited behind them in program
+        // order), so they go out one at a time between the MFMA groups below, where a full queue costs nothing
+        PHASE_T(2);
         const int st = kt % kF16Stages;
         const unsigned char* a = abase + st * kF16XSlot;
         const unsigned char* b = wring + st * kF16WSlot;
@@ -318,9 +331,18 @@ __device__ __forceinline__ void enc_gemm_f16_body(const EncF16Params p, const En
                 accA[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0[c], accA[c], 0, 0, 0);
                 accB[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1[c], accB[c], 0, 0, 0);
                 accB[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0[c], accB[c], 0, 0, 0);
+                const int slot = 4 * s + c;               // 0 ... 7: DMA j = slot - 1 behind the MFMAs of groups 1 ... 6
+                if (slot >= 1 && slot <= 6) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    issue_one(kt + 2, slot - 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
         }
     }
+    PHASE_T(3);
+    if (p.prio_late_half && wave >= 4) __builtin_amdgcn_s_setprio(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped duplicates of the last two iterations must land before the rings are reused
     f32x16 acc[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c)
@@ -336,6 +358,7 @@ __device__ __forceinline__ void enc_gemm_f16_body(const EncF16Params p, const En
     const bool arm = *s_flag != 0u;
     __syncthreads();
     if (arm) enc_f16_bf16_arm(acc, p.x, p.w3, M, K, row0 + wave * 32, kbeg, nk, lds_raw);
+    PHASE_T(5);   // drain, combine, arm decision
     if (!FUSE) {
         float* __restrict__ dst = p.out + (size_t)blockIdx.y * M * 128;
 #pragma unroll
@@ -347,6 +370,8 @@ __device__ __forceinline__ void enc_gemm_f16_body(const EncF16Params p, const En
                 if (row < M) dst[(size_t)row * 128 + col] = acc[c][i];
             }
         }
+        PHASE_T(6);
+        PHASE_T_FLUSH(7);
         return;
     }
     // ---- fused epilogue: h1 = [ReLU](acc + b1) -> LDS -> the rest of the encoder (enc_finish_tile_rows) -------------------------------
@@ -365,6 +390,8 @@ __device__ __forceinline__ void enc_gemm_f16_body(const EncF16Params p, const En
     }
     __syncthreads();
     enc_finish_tile_rows(H1, wave, l32, h, row0, M, fp);
+    PHASE_T(6);   // epilogue
+    PHASE_T_FLUSH(7);
 }
 
 // (concrete kernels around the body: with this toolchain a __global__ TEMPLATE that issues the LDS-DMA builtin from a lambda was not emitted)

@@ -286,6 +286,8 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
                 q.M = N, q.K = K, q.kslice = K / ks_split;
                 q.k_rotate = fp.k_rotate;
                 q.force_arm = f16_force_arm;
+                static const int f16_prio = diag_env_int("GNNCCA_GEMM_F16_PRIO", 0, 0, 1);   // diagnostics: static priority of waves 4-7 (measured: 122.9 vs 121 us at N = 65 536 -- off)
+                q.prio_late_half = f16_prio;
                 const dim3 fgrid((N + 255) / 256 + 1, 1), sgrid((N + 255) / 256, ks_split);
 #ifdef GNNCCA_F16_ABLATIONS
                 static const int f16_diag = diag_env_int("GNNCCA_GEMM_F16_DIAG", 0, 0, 7);

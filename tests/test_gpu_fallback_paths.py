@@ -139,3 +139,44 @@ def test_generic_op_by_op_path_agrees_with_the_fused_step():
     unfused = _child("generic", {"GNNCCA_DIAG": "1", "GNNCCA_GEN_UNFUSED": "1"})
     assert fused["golden_err"] <= 5e-6 and unfused["golden_err"] <= 5e-6
     assert np.abs(np.asarray(fused["generic_dims"]) - np.asarray(unfused["generic_dims"])).max() <= 5e-6
+
+
+def test_union_beyond_the_buffer_addressed_step_kernel():
+    """`csrc/mpn_forward.hip` switches the node message to the f32 form (`StepParams::msg_f32`) when `step_pipe_fits`
+    fails -- a union whose edge state no longer sits below the 2^31-byte reach of the buffer-addressed step kernel (6 planes x e_stride x 4 B
+    > 2^31: beyond ~ 89 M edge slots).  5 600 x dense128 = 91.0 M edges crosses it.  Inputs are generated on the device (13 GB in all; the
+    host sees a sample only).  Checked: every logit finite; the first, a middle and the last graphs of the union within 2e-6 of the SAME
+    graphs run as a small batch (which takes the split-bf16 message form and other encoder / step regimes) -- the bound
+    tests/test_gpu_sharded.py states for a graph's logits across dispatch regimes -- and that small batch against the fp32 oracle."""
+    import bench
+    from test_gpu_parity import _default_model
+    n, g = 128, 5600
+    params, arch, sd = _default_model(1.0 / (n - 1))
+    m = build(params, arch, sd)
+    dev = torch.device("cuda", 0)
+    ei1 = bench.dense_union(n, 1, dev)
+    e1 = ei1.shape[1]
+    assert 6 * g * e1 * 4 > 2 ** 31            # the condition step_pipe_fits refuses
+    gen = torch.Generator(device=dev).manual_seed(5)
+    x = torch.randn(g * n, 2048, generator=gen, device=dev) * (1.0 / (g * n) ** 0.5)     # column norms ~ 1, as after F.normalize(dim=0)
+    ea = torch.rand(g * e1, 4, generator=gen, device=dev)
+    ei = bench.dense_union(n, g, dev)
+    with torch.no_grad():
+        out = m(Data(x, ei, ea))["classified_edges"]
+    torch.cuda.synchronize()
+    assert len(out) == 3 and all(o.shape == (g * e1, 1) for o in out)
+    assert all(bool(torch.isfinite(o).all().item()) for o in out)
+    assert m.graph_flags() & 3 == 0
+    pick = [0, 1, g // 2, g - 2, g - 1]
+    small = Data(torch.cat([x[q * n:(q + 1) * n] for q in pick]), bench.dense_union(n, len(pick), dev),
+                 torch.cat([ea[q * e1:(q + 1) * e1] for q in pick]))
+    big = [torch.cat([o[q * e1:(q + 1) * e1] for q in pick]).clone() for o in out]
+    del out, ei, ea, x
+    torch.cuda.empty_cache()
+    with torch.no_grad():
+        got = m(small)["classified_edges"]
+    for a, b in zip(big, got):
+        assert float((a - b).abs().max()) <= 2e-6
+    ref = NumpyOracle(params, arch, sd, np.float32).forward(small.x.cpu().numpy(), small.edge_index.cpu().numpy(), small.edge_attr.cpu().numpy())
+    for a, r in zip(got, ref):
+        assert np.abs(a.cpu().numpy() - r).max() <= 5e-6

@@ -294,10 +294,14 @@ def test_fp16_split_gemm_range_guard(n_nodes, what):
     err_gpu = (np.abs(got - h64) / scale).max()
     err_ref = (np.abs(tr["h_enc"] - h64) / scale).max()
     assert err_gpu <= max(4 * err_ref, 2e-7), (err_gpu, err_ref)
-    for o, r in zip(out, ref):
-        o = o.cpu().numpy()
+    # logits: a planted magnitude of 1e4 ... 1e9 runs through sums whose terms cancel, so "close to the fp32 oracle" is the wrong yardstick
+    # there (two fp32 evaluations differ by the rounding of the big intermediates): both are judged against an fp64 evaluation
+    ref64 = NumpyOracle(params, arch, sd, np.float64).forward(x.astype(np.float64), ei, ea.astype(np.float64))
+    for o, r, r64 in zip(out, ref, ref64):
+        o = o.cpu().numpy().astype(np.float64)
         assert np.isfinite(o).all()
-        assert (np.abs(o - r) / np.maximum(np.abs(r), 1.0)).max() <= TOL_TIGHT * 2
+        s = np.maximum(np.abs(r64), 1.0)
+        assert (np.abs(o - r64) / s).max() <= max(4 * (np.abs(r - r64) / s).max(), TOL_TIGHT * 2)
 
 
 @pytest.mark.parametrize("n_nodes,products", [(4096 + 3, 6), (8192, 6), (8192 + 5, 6), (16384 + 77, 6), (30000, 6), (8192 + 5, 3)])
