@@ -119,12 +119,13 @@ __device__ __forceinline__ void enc_finish_tile_rows(float* H1, int wave, int l3
 // The bf16 six-product arm for a tile the fp16 pieces cannot carry: round 2's arithmetic (encoder.cuh: enc_gemm_split_direct_kernel's
 // loop -- x straight from global memory into three bf16 fragments, the chunk's W pieces through two LDS stages, one barrier per chunk) in
 // this kernel's tiling (wave = 32 rows x 128 columns).  Rare by construction; written for correctness, not speed.
+// `active`: false for waves beyond the eight that compute (the 32-row kernel's loader waves): they only keep the barriers company.
 __device__ __forceinline__ void enc_f16_bf16_arm(f32x16 (&acc)[4], const float* __restrict__ x, const unsigned short* __restrict__ w3, int M, int K,
-                                                 int row0w, int kbeg, int nk, unsigned char* lds_raw) {
+                                                 int row0w, int kbeg, int nk, unsigned char* lds_raw, bool active = true) {
     constexpr int BN = 128, BK = 32, LDK = 40;
     typedef __bf16 (*wsm_t)[3][BN][LDK];
     wsm_t wsm = reinterpret_cast<wsm_t>(lds_raw);   // [2][3][128][40] bf16 = 61 440 B
-    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
+    const int tid = active ? threadIdx.x : 0, lane = tid & 63, h = lane >> 5;
     const size_t plane = (size_t)BN * BK;
     const float* __restrict__ xrow = x + (size_t)min(row0w + (lane & 31), M - 1) * K + kbeg + 8 * h;
     int wp[3], wcol[3], wk[3];
@@ -159,8 +160,9 @@ __device__ __forceinline__ void enc_f16_bf16_arm(f32x16 (&acc)[4], const float* 
             }
     };
     auto store_w = [&](int stage) {
+        if (active)
 #pragma unroll
-        for (int u = 0; u < 3; ++u) *reinterpret_cast<bf16x8*>(&wsm[stage][wp[u]][wcol[u]][wk[u]]) = wreg[u];
+            for (int u = 0; u < 3; ++u) *reinterpret_cast<bf16x8*>(&wsm[stage][wp[u]][wcol[u]][wk[u]]) = wreg[u];
     };
 #pragma unroll
     for (int c = 0; c < 4; ++c)
@@ -272,14 +274,10 @@ __device__ __forceinline__ void enc_gemm_f16_body(const EncF16Params p, const En
 #pragma unroll
         for (int i = 0; i < 16; ++i) accA[c][i] = 0.f, accB[c][i] = 0.f;
     float amax = 0.f;
-    // fragment addresses: A from the wave's fp32 ring (row l32, granules 4 s + 2 h and + 1, XOR (l32 >> 1) & 7), B from the W ring
-    // (column 32 c + l32, granule 2 s + h, XOR (column >> 2) & 3 -- the image pack.cpp: w2h_index writes)
+    // fragment addresses: A from the wave's fp32 ring (row l32, granules 4 s + 2 h and + 1, XOR (l32 >> 1) & 7); B from the W ring, whose
+    // image is fragment-major (pack.cpp: w2h_index): piece p, column tile c, k-step s = the 1 KB at (p * 8 + c * 2 + s) * 1024, lane * 16 inside
     const int aswz = (l32 >> 1) & 7;
     const unsigned char* abase = xring + l32 * 128;
-    int boffs[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) boffs[c] = (c * 32 + l32) * 64;
-    const int bswz = (l32 >> 2) & 3;   // ((32 c + l32) >> 2) & 3
     // two waves share every SIMD; the later-dispatched half loses every arbitration at equal priority (stamps: its compute phase took
     // 2650 cycles per chunk against 1900, and the first half then waited for it at the barrier): one static priority for that half
     if (p.prio_late_half && wave >= 4) __builtin_amdgcn_s_setprio(1);
@@ -306,8 +304,8 @@ __device__ __forceinline__ void enc_gemm_f16_body(const EncF16Params p, const En
             f16x8 b0[4], b1[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                b0[c] = *reinterpret_cast<const f16x8*>(b + boffs[c] + (((2 * s + h) ^ bswz) << 4));
-                b1[c] = *reinterpret_cast<const f16x8*>(b + 128 * 64 + boffs[c] + (((2 * s + h) ^ bswz) << 4));
+                b0[c] = *reinterpret_cast<const f16x8*>(b + (c * 2 + s) * 1024 + lane * 16);
+                b1[c] = *reinterpret_cast<const f16x8*>(b + 8192 + (c * 2 + s) * 1024 + lane * 16);
             }
             f16x8 a0, a1;
             if (DIAG & 4) {
@@ -408,5 +406,323 @@ GNNCCA_F16_DIAG_KERNEL(5)
 GNNCCA_F16_DIAG_KERNEL(6)
 GNNCCA_F16_DIAG_KERNEL(7)
 #endif
+
+}  // namespace gnncca
+
+namespace gnncca {
+
+// ------------------------------------------------------------------------------------------------------------
+// The same layer on MID-SIZE batches (4096 ... ~24 000 nodes: the per-GPU share of BASELINE config 4 is 8192), round 5: 32 rows per workgroup,
+// K split over the WAVES of the workgroup instead of over workgroups, the whole rest of the encoder in the epilogue.
+// Up to round 4 these sizes ran the 256-row kernel split-K over the grid: eight [N][128] fp32 slabs to HBM and back (34 + 34 MB at N = 8192,
+// next to 67 MB of x) and a tail launch (22-28 + 9 us).  Here a workgroup owns 32 rows and ALL of K: 8 compute waves = 4 k-quarters x 2 column
+// halves, wave (kg, ch) accumulates x[32 rows][k quarter kg] . W[k quarter][64 columns of half ch]; the four k-quarters are summed through LDS
+// in the epilogue, in fixed order; nothing goes to HBM but h0 and the step-1 projections, and no tail launch follows.
+//   x: TWO LOADER WAVES (waves 8, 9; each serves two k-quarters) fill four rings of raw fp32 by LDS-DMA (32 rows x 128 B per 32-deep chunk
+//      and quarter), five chunks ahead = 80 KB per CU in flight.  Loaders of their own because a wave's vector-memory operations retire IN
+//      ORDER: a compute wave that waits for its next B operands (below) would thereby wait for every x request it issued before them, and
+//      the x stream could never be more than one iteration deep.  One workgroup barrier per chunk publishes a chunk and frees a stage.
+//   W: a compute wave's B operands are private (its k range, its 64 columns), so they never touch LDS: eight fully coalesced 1 KB loads per
+//      chunk straight from the fragment-major fp16 image (BlobHeader::enc_w2h; L2-resident: every workgroup reads all 1 MB of it) into the
+//      NEXT chunk's registers while the current chunk's MFMAs run.
+//   arithmetic: the fp16-split form above (three products, two accumulators), the bf16 arm for out-of-range tiles.
+// 256 workgroups at N = 8192: one per CU.
+// ------------------------------------------------------------------------------------------------------------
+#ifdef GNNCCA_STAMPS   // per-wave phase totals of up to ten waves: g_stamps[6][block < 1024][wave][16] (slot 6's region, 4 KB per block)
+#define R32_STAMP_FLUSH                                                                                                             \
+    do {                                                                                                                           \
+        pt_acc[7] = __builtin_amdgcn_s_memrealtime() - pt_real0;                                                                   \
+        if (g_stamps && (threadIdx.x & 63) == 0 && blockIdx.x < 1024)                                                              \
+            for (int q = 0; q < 8; ++q) g_stamps[(size_t)6 * 4096 * 4 * 16 + ((size_t)blockIdx.x * 16 + (threadIdx.x >> 6)) * 16 + q] = pt_acc[q]; \
+    } while (0)
+#else
+#define R32_STAMP_FLUSH do { } while (0)
+#endif
+constexpr int kF16R32Ahead = 5;                                       // chunks of x in flight per k-quarter
+constexpr int kF16R32Stages = kF16R32Ahead + 1;
+constexpr size_t kF16R32LdsBytes = 100 * 1024;                        // rings 4 x 6 x 4 KB = 96 KB; the epilogue overlays partials [4][32][128] f32 + H1 [32][132] f32
+constexpr int kF16R32Threads = 640;                                   // 8 compute waves + 2 loader waves
+
+__global__ __launch_bounds__(kF16R32Threads) void enc_gemm_f16_rows32_kernel(const EncF16Params p, const EncFuseParams fp) {
+    constexpr int BK = 32;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, l32 = lane & 31;
+    const int M = p.M, K = p.K;
+    if (blockIdx.x == gridDim.x - 1) {   // the plan workgroup
+        if (tid < 256)
+            plan_finish(fp.ei, fp.E, M, fp.seg_ptr, fp.col32, fp.perm, fp.cursor, fp.flags, fp.blockflags, reinterpret_cast<unsigned*>(lds_raw));
+        return;
+    }
+    PHASE_T_DECL;
+    const bool loader = wave >= 8;
+    const int kg = (wave >> 1) & 3, ch = wave & 1;
+    const int row0 = blockIdx.x * 32;
+    const int nkc = K / BK / 4;                     // chunks per k-quarter
+    const int rot = p.k_rotate ? (int)((blockIdx.x * 5u) % (unsigned)nkc) : 0;
+    auto lchunk = [&](int it) {                    // the quarter-local chunk of iteration `it` (clamped past the end: a harmless duplicate)
+        int lc = min(it, nkc - 1) + rot;
+        return lc >= nkc ? lc - nkc : lc;
+    };
+    const int rows_here = min(32, M - row0);
+    const rsrc_t rx = make_rsrc(p.x + (size_t)row0 * K, (unsigned long long)rows_here * K * 4);
+    const rsrc_t rw = make_rsrc(p.w2h, (unsigned long long)(K / BK) * kF16WSlot);
+    float amax = 0.f;
+    unsigned wbad = (wave == 0 && lane < kW2hBadWords) ? p.w_bad[lane] : 0u;
+    f32x16 accA[2], accB[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) accA[c][i] = 0.f, accB[c][i] = 0.f;
+    if (loader) {
+        // ---- loader wave L serves k-quarters 2 L and 2 L + 1: eight 1 KB DMA instructions per chunk ------------------------------------
+        const int L = wave - 8;
+        unsigned xoff[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int rl = 8 * j + (lane >> 3);
+            const int gs = (lane & 7) ^ ((4 * j + (lane >> 4)) & 7);      // source granule that lands in LDS granule slot (lane & 7) of row rl
+            xoff[j] = (unsigned)((size_t)rl * K * 4 + gs * 16);
+        }
+        auto issue = [&](int it) {
+            const int st = it % kF16R32Stages, lc = lchunk(it);
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const int q = 2 * L + g;
+                unsigned char* dst = lds_raw + ((size_t)q * kF16R32Stages + st) * 4096;
+                const unsigned so = (unsigned)((q * nkc + lc) * BK) * 4u;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_dma_ptr)(dst + j * 1024), 16, xoff[j], so, 0, 0);
+            }
+        };
+#pragma unroll
+        for (int d = 0; d < kF16R32Ahead; ++d) issue(d);
+        PHASE_T(4);
+        for (int it = 0; it < nkc; ++it) {
+            asm volatile("s_waitcnt vmcnt(32)" ::: "memory");   // 8 x (kF16R32Ahead - 1): chunk `it` has landed, four later ones may fly
+            PHASE_T(0);
+            __builtin_amdgcn_s_barrier();                       // publishes x(it); every compute wave is past stage (it - 1) % 6 ...
+            PHASE_T(1);
+            issue(it + kF16R32Ahead);                              // ... which this refills
+            PHASE_T(2);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the clamped duplicates must land before the rings are reused
+        PHASE_T(5);
+    } else {
+        // ---- compute wave (kg, ch) --------------------------------------------------------------------------------------------------
+        // B fragments of a chunk: [s][cc][piece], column tile c = 2 ch + cc.  ONE register set: a fragment is re-requested for the NEXT chunk
+        // right behind the MFMAs that consumed it (hipcc counts the waits: the first fragments a chunk needs were requested a whole
+        // iteration earlier, the last ones half of one) -- a second set would put this kernel over the 168 VGPRs that ten waves per
+        // workgroup leave each of them, and any scratch slows a launch by half
+        auto load_b1 = [&](int it, int s, int cc, int pc) {
+            const unsigned base = (unsigned)(kg * nkc + lchunk(it)) * (unsigned)kF16WSlot;
+            return __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rw, (unsigned)lane * 16u, base + (unsigned)(pc * 8192 + ((2 * ch + cc) * 2 + s) * 1024), 0));
+        };
+        f16x8 bq[2][2][2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+                for (int pc = 0; pc < 2; ++pc) bq[s][cc][pc] = load_b1(0, s, cc, pc);
+        const int aswz = (l32 >> 1) & 7;
+        const unsigned char* abase = lds_raw + (size_t)kg * kF16R32Stages * 4096 + l32 * 128;
+        PHASE_T(4);
+        for (int it = 0; it < nkc; ++it) {
+            PHASE_T(3);
+            __builtin_amdgcn_s_barrier();                       // x(it) is published (the loader waited for it before arriving here)
+            PHASE_T(1);
+            const unsigned char* a = abase + (it % kF16R32Stages) * 4096;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(a + (((4 * s + 2 * h) ^ aswz) << 4));
+                const f32x4 v1 = *reinterpret_cast<const f32x4*>(a + (((4 * s + 2 * h + 1) ^ aswz) << 4));
+                f16x8 a0, a1;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x2 v = q < 2 ? f32x2{v0[2 * q], v0[2 * q + 1]} : f32x2{v1[2 * q - 4], v1[2 * q - 3]};
+                    const f16x2 p0 = __builtin_convertvector(v, f16x2);
+                    const f32x2 r = (v - f32x2{(float)p0[0], (float)p0[1]}) * 2048.0f;
+                    const f16x2 p1 = __builtin_convertvector(r, f16x2);
+                    a0[2 * q] = p0[0], a0[2 * q + 1] = p0[1];
+                    a1[2 * q] = p1[0], a1[2 * q + 1] = p1[1];
+                    amax = fmaxf(fmaxf(amax, fabsf(v[0])), fabsf(v[1]));
+                }
+#pragma unroll
+                for (int cc = 0; cc < 2; ++cc) {
+                    accA[cc] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, bq[s][cc][0], accA[cc], 0, 0, 0);
+                    accB[cc] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, bq[s][cc][1], accB[cc], 0, 0, 0);
+                    accB[cc] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, bq[s][cc][0], accB[cc], 0, 0, 0);
+                    bq[s][cc][0] = load_b1(it + 1, s, cc, 0);
+                    bq[s][cc][1] = load_b1(it + 1, s, cc, 1);
+                }
+            }
+        }
+        PHASE_T(3);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    // the epilogue's operands from L2, requested NOW: their round trips run under the partial-tile exchange instead of after every barrier
+    // (stamps: the epilogue took 8 800 cycles per wave, most of it three dependent L2 latencies)
+    float w2v[16], pjv[16];
+    float bias2_pre = 0.f, pb_pre = 0.f;
+    {
+        const int q = wave & 3;
+        const float* w2row = fp.W2 + (size_t)l32 * 128 + 32 * q + 16 * h;
+        const int slot = 32 * (wave & 1) + l32;
+        const bool on = slot < kProjOut;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 b4 = wave < 4 ? *reinterpret_cast<const f32x4*>(w2row + 4 * j) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) w2v[4 * j + t] = b4[t];
+        }
+#pragma unroll
+        for (int sI = 0; sI < 16; ++sI) pjv[sI] = (wave < 2 && on) ? fp.projwT[(16 * h + sI) * kProjOut + slot] : 0.f;
+        if (wave == 0) bias2_pre = fp.b2[l32];
+        if (wave < 2 && on) pb_pre = fp.projb[slot];
+    }
+    // ---- the four k-quarters' partial tiles go to LDS at once (the accumulators die here: the bf16 arm below needs the registers), then:
+    //      bf16 arm?  (workgroup-uniform) ----------------------------------------------------------------------------------------------
+    __syncthreads();                                              // every wave is done with the rings
+    constexpr int LD1 = 132;
+    float* P = reinterpret_cast<float*>(lds_raw);                 // [4 k-quarters][32][128] partial tiles
+    float* H1 = P + 4 * 32 * 128;                                 // [32][132]
+    unsigned* s_flag = reinterpret_cast<unsigned*>(lds_raw + kF16R32LdsBytes - 16);
+    if (tid == 0) *s_flag = 0u;
+    if (!loader) {
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+            const int col = (2 * ch + cc) * 32 + l32;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int rl = (i & 3) + 8 * (i >> 2) + 4 * h;
+                P[(kg * 32 + rl) * 128 + col] = fmaf(accB[cc][i], 1.0f / 2048.0f, accA[cc][i]);
+            }
+        }
+    }
+    __syncthreads();
+    if (!(amax < kF16Limit) || wbad != 0u || p.force_arm) atomicOr(s_flag, 1u);
+    __syncthreads();
+    const bool arm = *s_flag != 0u;
+    if (arm) {
+        __syncthreads();                                          // (the arm's W stages overwrite the partials)
+        // every compute wave recomputes the SAME 32 x 128 tile over all of K on the bf16 arm (its W staging wants all 512 compute threads;
+        // rare by construction); wave 0's copy is the tile.  (The arm's stages end below H1.)
+        f32x16 full[4];
+        enc_f16_bf16_arm(full, p.x, p.w3, M, K, row0, 0, K / BK, lds_raw, !loader);
+        if (wave == 0) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int col = c * 32 + l32;
+                const float bias = fp.b1[col];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int rl = (i & 3) + 8 * (i >> 2) + 4 * h;
+                    const float v = full[c][i] + bias;
+                    H1[rl * LD1 + col] = fp.relu_prev ? fmaxf(v, 0.f) : v;
+                }
+            }
+        }
+    } else {
+        // h1 = [ReLU](((p0 + p1) + p2) + p3 + b1): 1024 float4, two per compute thread
+        if (!loader) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int e4 = tid + 512 * u;                      // float4 index in [32][128 / 4]
+                const int rl = e4 >> 5, c4 = (e4 & 31) * 4;
+                const f32x4 q0 = *reinterpret_cast<const f32x4*>(P + (0 * 32 + rl) * 128 + c4);
+                const f32x4 q1 = *reinterpret_cast<const f32x4*>(P + (1 * 32 + rl) * 128 + c4);
+                const f32x4 q2 = *reinterpret_cast<const f32x4*>(P + (2 * 32 + rl) * 128 + c4);
+                const f32x4 q3 = *reinterpret_cast<const f32x4*>(P + (3 * 32 + rl) * 128 + c4);
+                const f32x4 b = *reinterpret_cast<const f32x4*>(fp.b1 + c4);
+                f32x4 v = ((q0 + q1) + q2) + q3 + b;
+                if (fp.relu_prev) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) v[t] = fmaxf(v[t], 0.f);
+                }
+                *reinterpret_cast<f32x4*>(H1 + rl * LD1 + c4) = v;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- layer 2 and the projections on the 32-row tile: the arithmetic of enc_finish_tile_rows with its four k-quarters dealt to waves 0-3
+    //      (partial tiles summed ((d0 + d1) + d2) + d3 by wave 0, as every other encoder kernel does) and the two projection slot groups to
+    //      waves 0-1 ----------------------------------------------------------------------------------------------------------------------
+    float* DQ = P;                                                // [4][16 regs][64 lanes]: the partial tiles in accumulator layout
+    if (wave < 4) {
+        const int q = wave;
+        const float* hrow = H1 + l32 * LD1 + 32 * q + 16 * h;
+        float av[16];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 a4 = *reinterpret_cast<const f32x4*>(hrow + 4 * j);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) av[4 * j + t] = a4[t];
+        }
+        f32x16 dq;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dq[i] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) dq = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], w2v[s], dq, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) DQ[(q * 16 + i) * 64 + lane] = dq[i];
+    }
+    __syncthreads();
+    constexpr int LD0 = 36;
+    float* H0 = H1;                                               // [32][36] over the consumed h1 tile
+    if (wave == 0) {
+        const float bias2 = bias2_pre;
+        float hv[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float d = ((DQ[(0 * 16 + i) * 64 + lane] + DQ[(1 * 16 + i) * 64 + lane]) + DQ[(2 * 16 + i) * 64 + lane]) + DQ[(3 * 16 + i) * 64 + lane];
+            hv[i] = fmaxf(d + bias2, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int rl = (i & 3) + 8 * (i >> 2) + 4 * h;
+            H0[rl * LD0 + l32] = hv[i];
+            const int row = row0 + rl;
+            if (row < M) {
+                fp.h0[(size_t)row * kH + l32] = hv[i];
+                if (fp.trace_h) fp.trace_h[(size_t)row * kH + l32] = hv[i];
+            }
+        }
+    }
+    __syncthreads();
+    if (wave < 2) {
+        const int t = wave;
+        float a2[16];
+        const float* hr = H0 + l32 * LD0 + 16 * h;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 a4 = *reinterpret_cast<const f32x4*>(hr + 4 * j);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a2[4 * j + q] = a4[q];
+        }
+        const int slot = 32 * t + l32;
+        const bool on = slot < kProjOut;
+        f32x16 pacc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) pacc[i] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[s], pjv[s], pacc, 0, 0, 0);
+        const float pb = pb_pre;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = row0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+            if (row < M && on) {
+                const float v = pacc[i] + pb;
+                if (slot < kPdStride)
+                    fp.pd_out[(size_t)row * kPdStride + slot] = v;
+                else
+                    fp.psq_out[(size_t)row * kPsQStride + slot - kPdStride] = v;
+            }
+        }
+    }
+    PHASE_T(6);
+    R32_STAMP_FLUSH;
+}
 
 }  // namespace gnncca

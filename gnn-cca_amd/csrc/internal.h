@@ -51,8 +51,8 @@ struct BlobHeader {
     int32_t fast_consts;                    // [kFastConsts] contiguous copy of the per-step scalars (see below), or 0
     int32_t enc_w3;                         // first encoder weight as 3 bf16 pieces, [in/32][3][out][32], or 0
     int32_t wne_bf16;                       // [9][64] dwords: W_ne as packed bf16 piece pairs, the B operands of msg_bf16.cuh
-    int32_t enc_w2h;                        // first encoder weight as 2 fp16 pieces (w = w0 + w1 / 2048), the LDS image of enc_f16.cuh:
-                                            // [in/32][2 pieces][out = 128][32] halfs, 16-B granule kc of column c stored at kc ^ ((c >> 2) & 3); or 0
+    int32_t enc_w2h;                        // first encoder weight as 2 fp16 pieces (w = w0 + w1 / 2048), the B-operand image of enc_f16.cuh:
+                                            // [in/32][2 pieces][4 column tiles][2 k-steps][64 lanes][8] halfs (pack.cpp: w2h_index); or 0
     int32_t enc_w2h_bad;                    // [kW2hBadWords] words: non-zero where a weight does not fit fp16 (|w| >= 65520): the fp16 GEMM then
                                             // hands every tile to its bf16 arm
     int32_t pad[3];

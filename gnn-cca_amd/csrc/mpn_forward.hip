@@ -195,9 +195,20 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
             const bool use_r32 = (options & GNNCCA_OPT_ENC_UNSPLIT) != 0 && fusable && O == 128 && K % 256 == 0 && !force_direct && N >= 4096 &&
                                  !(use_lds && ks_split == 1);
             if (use_r32) ks_split = 1;
+            // round 5: mid-size batches on the fp16-split form take 32-row workgroups that split K over their WAVES and finish the encoder in
+            // the epilogue (enc_f16.cuh: enc_gemm_f16_rows32_kernel) -- no slabs, no tail launch.  Range: 4096 ... 8192 nodes, i.e. while the
+            // row tiles fit ONE round of workgroups: every 32-row workgroup pulls all 1 MB of W through its CU's L2 path (~70 GB/s: 14 us), which
+            // a second round doubles (plan + GEMM + tail, same box: 25.3 / 26.4 / 27.4 / 28.6 / 30.4 us at 4096 / 5120 / 6144 / 7168 / 8192 nodes
+            // against 26.6 / 35.0 / 31.2 / 33.0 / 38.3 for the split-K forms; 47.4 against 39.2 at 9216; profiles/r05_logs/ab_r32f_2.log)
+            static const int r32f_min = diag_env_int("GNNCCA_GEMM_R32F_MIN", 4096, 0, 0x7FFFFFFF);
+            static const int r32f_max = diag_env_int("GNNCCA_GEMM_R32F_MAX", 8192, 0, 0x7FFFFFFF);
+            static const bool gemm_bf16_early = diag_env("GNNCCA_GEMM_BF16") != nullptr;
+            const bool use_r32f = !use_r32 && fusable && O == 128 && K % 256 == 0 && hdr.enc_w2h != 0 && !split3 && !gemm_bf16_early && !force_direct &&
+                                  (options & GNNCCA_OPT_ENC_UNSPLIT) == 0 && N >= r32f_min && N <= r32f_max && !(use_lds && ks_split == 1);
+            if (use_r32f) ks_split = 1;
             // un-split and the shipped encoder shape (2048 -> 128 -> 32, no reattach): the rest of the encoder, the step-1
             // projections and the plan fold run in the GEMM's epilogue, on the tile while it is on chip
-            fused_tail = (use_lds && fusable && ks_split == 1) || use_r32;
+            fused_tail = (use_lds && fusable && ks_split == 1) || use_r32 || use_r32f;
             EncFuseParams fp;
             std::memset(&fp, 0, sizeof(fp));
             static const int gemm_x_l2 = diag_env_int("GNNCCA_GEMM_X_L2_ROWS", 0, 1, 256);   // diagnostics: x served from L2 (timing only)
@@ -239,7 +250,7 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
             // of that form) and as the A/B reference (GNNCCA_GEMM_BF16).  K / ks_split is a multiple of 32 on this path.
             static const bool gemm_bf16 = diag_env("GNNCCA_GEMM_BF16") != nullptr;
             static const int f16_force_arm = diag_env_int("GNNCCA_GEMM_F16_ARM", 0, 0, 1);   // diagnostics / tests: every tile on the bf16 arm
-            const bool use_f16 = use_lds && !use_r32 && hdr.enc_w2h != 0 && !split3 && (options & GNNCCA_OPT_ENC_UNSPLIT) == 0 && !gemm_bf16 &&
+            const bool use_f16 = use_lds && !use_r32 && !use_r32f && hdr.enc_w2h != 0 && !split3 && (options & GNNCCA_OPT_ENC_UNSPLIT) == 0 && !gemm_bf16 &&
                                  gemm_x_l2 == 0 && K % 32 == 0 && (K / ks_split) % 32 == 0;
             static thread_local int attr_dev = -1;  // once per device and thread: the attribute is per device
             int dev = 0;
@@ -247,6 +258,7 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
             if (attr_dev != dev) {
                 HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(enc_gemm_f16_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kF16LdsBytes));
                 HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(enc_gemm_f16_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kF16LdsBytes));
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(enc_gemm_f16_rows32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kF16R32LdsBytes));
                 const void* fns[8] = {reinterpret_cast<const void*>(enc_gemm_split_lds_kernel<false, false>),
                                       reinterpret_cast<const void*>(enc_gemm_split_lds_kernel<true, false>),
                                       reinterpret_cast<const void*>(enc_gemm_split_lds_kernel<false, true>),
@@ -263,7 +275,18 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
             // workgroups per CU, half the slabs: correct, and slower at every size: 32.1 vs 27.8 us at N = 8192 with a 7.0 instead of 9.3 us
             // tail, 59 vs 46 at 16 384, 129 vs 96 at 32 768 -- 4x the W traffic from L2 and one accumulation chain per wave; the kernel and
             // the log are kept under profiles/r04_logs/: enc_rows64.cuh.txt, ab_enc64_1.log.)
-            if (use_r32) {
+            if (use_r32f) {
+                EncF16Params q;
+                std::memset(&q, 0, sizeof(q));
+                q.x = cur_in;
+                q.w2h = reinterpret_cast<const unsigned short*>(blob + hdr.enc_w2h);
+                q.w_bad = reinterpret_cast<const unsigned*>(blob + hdr.enc_w2h_bad);
+                q.w3 = w3;
+                q.M = N, q.K = K, q.kslice = K;
+                q.k_rotate = fp.k_rotate;
+                q.force_arm = f16_force_arm;
+                GNNCCA_LAUNCH(enc_gemm_f16_rows32_kernel, dim3((unsigned)((N + 31) / 32) + 1), dim3(kF16R32Threads), kF16R32LdsBytes, st, q, fp);
+            } else if (use_r32) {
                 const dim3 rgrid((unsigned)((N + 31) / 32) + 1);
                 const int nst = r32_nst == 4 || r32_nst == 8 ? r32_nst : ((N + 31) / 32 <= 256 ? 8 : 4);
                 if (nst == 8 && split3)

@@ -213,10 +213,14 @@ static inline float f16_to_float(uint16_t h) {
     std::memcpy(&f, &u, 4);
     return f;
 }
-// position (in halfs) of piece 0 of weight element (output column o, input i) in the enc_w2h image; piece 1 sits 128 * 32 halfs further
+// position (in halfs) of piece 0 of weight element (output column o, input i) in the enc_w2h image; piece 1 sits 128 * 32 halfs further.
+// FRAGMENT-major inside a 32-deep chunk: [piece][column tile c = o / 32][k-step s = (i % 32) / 16][lane = o % 32 + 32 * ((i % 16) / 8)][i % 8] --
+// the 1 KB the 64 lanes of one B operand of v_mfma_f32_32x32x16_f16 hold is one contiguous run, so the same image serves the LDS ring of
+// the 256-row kernel (ds_read_b128 at consecutive addresses: conflict-free without a swizzle) and the straight-to-register loads of the
+// 32-row kernel (one fully coalesced 1 KB load per fragment)
 static inline size_t w2h_index(int o, int i) {
-    const int kc = (i % 32) / 8;
-    return (size_t)(i / 32) * (2 * 128 * 32) + (size_t)o * 32 + (size_t)(((kc ^ ((o >> 2) & 3)) << 3) + (i % 8));
+    const int kk = i % 32, lane = (o % 32) + 32 * ((kk % 16) / 8);
+    return (size_t)(i / 32) * (2 * 128 * 32) + (size_t)((((o / 32) * 2 + kk / 16) * 64 + lane) * 8 + (kk % 8));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -690,7 +694,7 @@ static const char* const kDiagSwitches[] = {
     "GNNCCA_DIAG", "GNNCCA_LIB", "GNNCCA_STAMPS", "GNNCCA_STEP_R2", "GNNCCA_STEP_NOMEM", "GNNCCA_STEP_NOEPI", "GNNCCA_STEP_NOHOOK", "GNNCCA_STEP_EARLYBAR",
     "GNNCCA_STEP_NORANGE", "GNNCCA_RANGE_MAX_E", "GNNCCA_PD_LDS_MIN", "GNNCCA_PD_LDS_MAX", "GNNCCA_TAIL_NPW", "GNNCCA_WPS", "GNNCCA_NO_NT", "GNNCCA_NO_PAD",
     "GNNCCA_GEMM_DIRECT", "GNNCCA_GEMM_SPLIT_MIN", "GNNCCA_GEMM_LDS_MIN", "GNNCCA_GEMM_NOPIPE", "GNNCCA_NO_FUSE", "GNNCCA_NO_MFMA_TAIL",
-    "GNNCCA_TAIL_MFMA_MIN", "GNNCCA_NO_RIDE", "GNNCCA_GEMM_DIRECT_WG", "GNNCCA_GEMM_R32_NST", "GNNCCA_GEN_UNFUSED", "GNNCCA_NPW", "GNNCCA_NPW_MIN_N", "GNNCCA_NPW_MIN_N_FIRST", "GNNCCA_DEFER_CLS", "GNNCCA_GEMM_X_L2_ROWS", "GNNCCA_NPW_MAX_CHUNKS", "GNNCCA_GEMM_NO_KROT", "GNNCCA_GEMM_BF16", "GNNCCA_GEMM_F16_ARM", "GNNCCA_GEMM_F16_DIAG", "GNNCCA_GEMM_F16_PRIO"};
+    "GNNCCA_TAIL_MFMA_MIN", "GNNCCA_NO_RIDE", "GNNCCA_GEMM_DIRECT_WG", "GNNCCA_GEMM_R32_NST", "GNNCCA_GEN_UNFUSED", "GNNCCA_NPW", "GNNCCA_NPW_MIN_N", "GNNCCA_NPW_MIN_N_FIRST", "GNNCCA_DEFER_CLS", "GNNCCA_GEMM_X_L2_ROWS", "GNNCCA_NPW_MAX_CHUNKS", "GNNCCA_GEMM_NO_KROT", "GNNCCA_GEMM_BF16", "GNNCCA_GEMM_F16_ARM", "GNNCCA_GEMM_F16_DIAG", "GNNCCA_GEMM_F16_PRIO", "GNNCCA_GEMM_R32F_MIN", "GNNCCA_GEMM_R32F_MAX"};
 
 extern "C" char** environ;
 

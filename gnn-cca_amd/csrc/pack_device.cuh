@@ -62,7 +62,8 @@ __global__ __launch_bounds__(256) void pack_device_kernel(const PackProgram* __r
             _Float16* w2 = reinterpret_cast<_Float16*>(blob + g.dst);
             const _Float16 h0 = (_Float16)v;
             const float rr = (v - (float)h0) * 2048.0f;
-            const size_t kk = (size_t)(c / 32) * (2 * 128 * 32) + (size_t)r * 32 + (size_t)(((((c % 32) / 8) ^ ((r >> 2) & 3)) << 3) + (c % 8));
+            const int kq = c % 32, ln = (r % 32) + 32 * ((kq % 16) / 8);   // (pack.cpp: w2h_index -- fragment-major inside the chunk)
+            const size_t kk = (size_t)(c / 32) * (2 * 128 * 32) + (size_t)((((r / 32) * 2 + kq / 16) * 64 + ln) * 8 + (kq % 8));
             w2[kk] = h0;
             w2[kk + 128 * 32] = (_Float16)rr;
             if (!(fabsf(v) < kF16Limit)) f16_bad = 1;

@@ -181,16 +181,15 @@ def blob_forward(blob_u8, params, arch, x, edge_index, edge_attr):
     enc = params["encoder_feats_dict"]["nodes"][arch]
     dims = [enc["node_in_dim"]] + list(enc["node_fc_dims"]) + [enc["node_out_dim"]]
     if h.enc_w2h:   # the fp16 piece image of the first encoder weight (csrc/enc_f16.cuh): w0 = fp16(w), w1 = fp16((w - w0) * 2048), bit for bit
-        # numpy's round-to-nearest-even conversions, at [in / 32][piece][out][32] with the 16-B granule kc of column c stored at kc ^ ((c >> 2) & 3)
+        # numpy's round-to-nearest-even conversions, fragment-major inside every 32-deep chunk (csrc/pack.cpp: w2h_index)
         K, O = dims[0], dims[1]
         assert O == 128 and K % 32 == 0
         W = f[h.enc_node_w[0]:h.enc_node_w[0] + K * O].reshape(O, K)
-        img = np.frombuffer(raw, dtype=np.float16)[2 * h.enc_w2h:2 * h.enc_w2h + 2 * K * O].reshape(K // 32, 2, O, 4, 8)
-        o = np.arange(O)[:, None]
-        kc = np.arange(4)[None, :]
-        nat = img[:, :, o, kc ^ ((o >> 2) & 3), :]                      # [chunk][piece][out][kc][8] in natural k order
-        w0 = nat[:, 0].transpose(1, 0, 2, 3).reshape(O, K)
-        w1 = nat[:, 1].transpose(1, 0, 2, 3).reshape(O, K)
+        # [chunk][piece][column tile][k-step][lane half h][column in tile][8]: lane = column % 32 + 32 h holds k = 16 s + 8 h + (0 ... 7)
+        img = np.frombuffer(raw, dtype=np.float16)[2 * h.enc_w2h:2 * h.enc_w2h + 2 * K * O].reshape(K // 32, 2, 4, 2, 2, 32, 8)
+        nat = img.transpose(1, 2, 5, 0, 3, 4, 6)                          # [piece][tile][column][chunk][s][h][8] -> natural (column, k)
+        w0 = nat[0].reshape(O, K)
+        w1 = nat[1].reshape(O, K)
         want0 = W.astype(np.float16)
         want1 = ((W - want0.astype(np.float32)) * np.float32(2048)).astype(np.float16)
         assert np.array_equal(w0.view(np.uint16), want0.view(np.uint16)) and np.array_equal(w1.view(np.uint16), want1.view(np.uint16))
@@ -320,7 +319,8 @@ def run_pack_program(prog, params, nbytes):
         elif g.kind == 4:   # two fp16 pieces in the swizzled chunk image of csrc/enc_f16.cuh + this element's pack-block flag word
             h0 = v.astype(np.float16)
             h1 = ((v - h0.astype(np.float32)) * np.float32(2048)).astype(np.float16)
-            kk = 2 * g.dst + (c // 32) * (2 * 128 * 32) + r * 32 + (((((c % 32) // 8) ^ ((r >> 2) & 3)) << 3) + (c % 8))
+            kq = c % 32
+            kk = 2 * g.dst + (c // 32) * (2 * 128 * 32) + ((((r // 32) * 2 + kq // 16) * 64 + (r % 32) + 32 * ((kq % 16) // 8)) * 8 + (kq % 8))
             u16[kk], u16[kk + 128 * 32] = h0.view(np.uint16), h1.view(np.uint16)
             t = r * g.cols + c
             np.bitwise_or.at(blob.view(np.uint32), g.plane + (t // 256) % 64, (~(np.abs(v) < 65520.0)).astype(np.uint32))

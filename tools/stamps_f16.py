@@ -44,3 +44,16 @@ for label, st in (("waves 0-3", raw[:2048].reshape(-1, 16)), ("waves 4-7", raw[2
         print(f"   {nm:48s} median {np.median(st[:, k]):10.0f}  ({100 * np.median(st[:, k]) / tot:5.1f} %)   per chunk {np.median(st[:, k]) / 64:7.0f}")
     real = np.median(st[:, 7])
     print(f"   loop wall time (s_memrealtime, 100 MHz): {real / 100:.1f} us -> s_memtime rate {tot / (real / 100) / 1e3:.2f} GHz")
+
+# the 32-row kernel (N <= GNNCCA_GEMM_R32F_MAX): ten waves per workgroup, slot 6's region as [1024 blocks][16 waves][16]
+r32 = buf.cpu().numpy().reshape(8, -1)[6][:1024 * 16 * 16].reshape(1024, 16, 16).astype(np.float64)
+if r32[:, :10, :7].sum() > 0 and n_tot <= 20480:
+    for label, sel in (("compute waves 0-7", slice(0, 8)), ("loader waves 8-9", slice(8, 10))):
+        st = r32[:, sel].reshape(-1, 16)
+        st = st[st[:, :7].sum(1) > 0]
+        tot = np.median(st[:, :7].sum(1))
+        print(f"32-row kernel, {label}: {len(st)} waves; total per wave {tot:.0f} ticks")
+        for k, nm in enumerate(["loader: wait for own DMA", "barrier", "loader: issue 8 DMA", "compute (4 ds_read, split, 12 MFMA, 8 B loads)", "prologue", "loader: drain", "epilogue"]):
+            print(f"   {nm:48s} median {np.median(st[:, k]):10.0f}  ({100 * np.median(st[:, k]) / tot:5.1f} %)   per chunk {np.median(st[:, k]) / 16:7.0f}")
+        real = np.median(st[:, 7])
+        print(f"   wall (s_memrealtime): {real / 100:.1f} us -> {tot / (real / 100) / 1e3:.2f} GHz")
