@@ -447,6 +447,15 @@ def terrace_leg(device, args, batch=64, n_batches=16, cpu_budget_s=12.0):
             nodes += b.x.shape[0]
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    # the same batches with the reference's rounding / splitting heuristics (config_inference.yaml:6-8 all True): FrameResult.final() reads the
+    # device chain's trigger words (one synchronisation) and runs the flagged frames through the native host implementation
+    t0 = time.perf_counter()
+    flagged = 0
+    for i in range(n_batches):
+        _, _, _, post = run(i)
+        flagged += len(post["_keep"].final()["frames_finalized"])
+    torch.cuda.synchronize()
+    dt_final = time.perf_counter() - t0
     for i in range(n_batches):   # stage split (synchronised between stages: for the split only, not part of the figure above)
         f, (node, reid) = frames[i], dev_in[i]
         torch.cuda.synchronize(); t = time.perf_counter()
@@ -496,8 +505,21 @@ def terrace_leg(device, args, batch=64, n_batches=16, cpu_budget_s=12.0):
                    "pruned_equal": bool(np.array_equal(post["pruned"].cpu().numpy(), p_pruned)),
                    "clusters_equal": bool(int(post["n_clusters"].item()) == p_k and po.same_partition(post["labels"].cpu().numpy(), p_lab)),
                    "clusters": int(post["n_clusters"].item()), "active_edges": int(post["pruned"].sum().item())}
+            # ... and the FINAL result (ROUNDING / PRUNING / SPLITTING): every frame of the batch through the oracle's restatement of the
+            # reference's heuristics, on the GPU's own probabilities (they compare probabilities for order and equality)
+            fin = post["_keep"].final()
+            f_pred, f_lab, g_probs = fin["predictions"].cpu().numpy(), fin["labels"].cpu().numpy(), post["_keep"].probs.cpu().numpy()
+            f_ok, f_clusters = True, 0
+            for q in range(batch):
+                v0, v1, k0, k1 = b.node_ptr[q], b.node_ptr[q + 1], b.edge_ptr[q], b.edge_ptr[q + 1]
+                _, want, ids, kq = po.finalize(ei[:, k0:k1] - v0, None, v1 - v0, probs=g_probs[k0:k1])
+                f_ok = f_ok and np.array_equal(f_pred[k0:k1], want) and po.same_partition(f_lab[v0:v1], ids)
+                f_clusters += kq
+            one["final_equal_to_reference_heuristics"] = bool(f_ok and int(fin["n_clusters"].item()) == f_clusters)
+            one["final_clusters"], one["frames_through_the_host_heuristics"] = f_clusters, len(fin["frames_finalized"])
             one["ok"] = bool(one["edge_index_equal"] and one["edge_attr_max_abs_err"] <= 1e-5 and one["logit_max_abs_err"] <= 1e-4 and
-                             one["prediction_flips_on_firm_logits"] == 0 and one["pruned_equal"] and one["clusters_equal"])
+                             one["prediction_flips_on_firm_logits"] == 0 and one["pruned_equal"] and one["clusters_equal"] and
+                             one["final_equal_to_reference_heuristics"])
             checks.append(one)
         if cpu_t > cpu_budget_s:
             break
@@ -505,9 +527,14 @@ def terrace_leg(device, args, batch=64, n_batches=16, cpu_budget_s=12.0):
     return {"workload": f"{n_batches} batches of {batch} consecutive valid EPFL-Terrace frames (real per-frame camera / identity "
                         f"structure, synthetic positions and embeddings): {nodes // n_done} detections, {edges // n_done} edges per batch",
             "pipeline": "gnn_cca_amd.pipeline.FramePipeline: graph_build.build_graph_batch -> MOTMPNet.forward (L=4) -> postprocess.threshold -> "
-                        "postprocess.prune_and_cluster as ONE native call per batch (gnncca_frames_forward: the same 15 launches), host planning "
+                        "postprocess.prune_and_cluster (+ trigger words) as ONE native call per batch (gnncca_frames_forward), host planning "
                         "and H2D of the per-detection arrays included; `stage_ms_per_batch_synchronised` times the separate functions",
             "ms_per_batch": dt / n_done * 1e3, "frames_per_s": batch * n_done / dt, "edges_per_s": edges / dt,
+            "with_rounding_and_splitting": {"ms_per_batch": dt_final / n_batches * 1e3, "frames_per_s": batch * n_batches / dt_final,
+                                            "frames_through_the_host_heuristics_per_batch": flagged / n_batches,
+                                            "note": "FrameResult.final(): one synchronisation per batch to read the trigger words, then the reference's "
+                                                    "rounding / splitting for the flagged frames on the host (csrc/post_host.cpp).  The synthetic model's "
+                                                    "predictions are near-random, so MOST frames raise a trigger here; a trained model's rarely do"},
             "stage_ms_per_batch_synchronised": {k: v / n_batches * 1e3 for k, v in stage.items()},
             "parity": {"ok": bool(checks) and all(c["ok"] for c in checks), "tolerance_abs": 1e-4, "batches": checks,
                        "against": "oracle.graph_oracle + oracle.TorchOracle on the same inputs; oracle.post_oracle on the GPU's predictions"},

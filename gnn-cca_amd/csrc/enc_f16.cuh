@@ -24,7 +24,7 @@ namespace gnncca {
 // W (pre-split at pack time, BlobHeader::enc_w2h: the LDS image chunk by chunk) goes through a shared three-slot ring the same way, ONE
 // workgroup barrier per 32-deep chunk.  LDS traffic per chunk and CU: 48 KB written by DMA + 160 KB of fragment reads, against 72 KB of
 // ds_write + 192 KB of reads in the 256-row bf16 kernel (encoder.cuh), and no conversion-store pass.
-// Workgroup b walks its k chunks from chunk (37 b) mod nk on (see enc_gemm_split_lds_kernel: 5.0 -> 6.2 TB/s for this access shape).
+// (Option, off by default: workgroup b walks its k chunks from chunk (37 b) mod nk on -- see enc_gemm_split_lds_kernel and mpn_forward.hip.)
 // LDS: x rings 8 x 3 x 4 KB + W ring 3 x 16 KB = 144 KB (= kLdsGemmBytes); the fused epilogue reuses it.
 // ------------------------------------------------------------------------------------------------------------
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));

@@ -316,7 +316,7 @@ __global__ __launch_bounds__(512) void enc_gemm_split_lds_kernel(const float* __
     const int row0 = blockIdx.x * RA;
     const int kbeg = blockIdx.y * kslice;
     const int nk = min(kslice, K - kbeg) / BK;
-    // k ROTATION (round 5).  Every workgroup of a round reads 128 B from each of its 256 rows (8 KB apart) per chunk, and all of them walk
+    // k ROTATION (round 5; an option, off by default: mpn_forward.hip says why).  Every workgroup of a round reads 128 B from each of its 256 rows (8 KB apart) per chunk, and all of them walk
     // the same k at about the same time: the chip's 256 request streams then agree in the address bits BELOW the row stride chunk after
     // chunk, i.e. they crowd the same memory channels (tools/ubench_xring.hip: this walk streams at 5.0 TB/s, the same walk with every
     // workgroup STARTING at another chunk at 6.2 -- the linear-sweep rate).  A dot product does not care where its sum starts, so

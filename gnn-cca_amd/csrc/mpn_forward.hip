@@ -213,8 +213,13 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
             std::memset(&fp, 0, sizeof(fp));
             static const int gemm_x_l2 = diag_env_int("GNNCCA_GEMM_X_L2_ROWS", 0, 1, 256);   // diagnostics: x served from L2 (timing only)
             fp.diag_x_rows = gemm_x_l2;
-            static const bool no_rot = diag_env("GNNCCA_GEMM_NO_KROT") != nullptr;   // diagnostics: A/B the k rotation of the 256-row GEMM
-            fp.k_rotate = ((options & GNNCCA_OPT_ENC_UNSPLIT) == 0 && !no_rot) ? 1 : 0;
+            // k rotation of the big-batch GEMMs (encoder.cuh / enc_f16.cuh): OFF.  A bare streaming loop of this access shape gains 20 % from it
+            // (tools/ubench_xring.hip: 5.0 -> 6.2 TB/s), the kernels themselves 0-3 % at N = 65 536 and LOSE 4 % at 32 768 (their waves are
+            // not in lockstep across CUs the way the microbenchmark's are; profiles/r05_logs/ab_krot{1,2}.log) -- and it makes a node's encoder
+            // output depend on WHICH row block of the batch it sits in (the summation starts elsewhere), which the un-rotated kernels do not
+            // (tests/test_gpu_fuzz.py: 512 copies of one graph, bitwise).  Kept behind GNNCCA_GEMM_KROT=1 for the record.
+            static const bool k_rot = diag_env("GNNCCA_GEMM_KROT") != nullptr;
+            fp.k_rotate = ((options & GNNCCA_OPT_ENC_UNSPLIT) == 0 && k_rot) ? 1 : 0;
             if (fused_tail) {
                 fp.b1 = blob + hdr.enc_node_b[0];
                 fp.W2 = blob + hdr.enc_node_w[1];
