@@ -104,6 +104,8 @@ _SIGNATURES = {
                                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gnncca_post_finalize_frame_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32,
                                                   C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gnncca_post_finalize_frames_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+                                                   C.c_int32, C.c_void_p, C.c_void_p, C.c_int32]),
     "gnncca_backward_supported": (C.c_int, [C.POINTER(MpnDims)]),
     "gnncca_backward_workspace_bytes": (C.c_size_t, [C.POINTER(MpnDims), C.c_int64, C.c_int64]),
     "gnncca_mpn_backward": (C.c_int, [C.POINTER(MpnDims), C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -47,8 +47,13 @@ __device__ __forceinline__ float wave_sum(float v) {
 template <int MODE>
 __global__ __launch_bounds__(256) void build_edges_kernel(const gnncca_frames fr, const float* __restrict__ reid, int R, int N,
                                                           long long E, long long* __restrict__ ei_out,
-                                                          float* __restrict__ attr_out, float* __restrict__ lab_out) {
+                                                          float* __restrict__ attr_out, float* __restrict__ lab_out,
+                                                          int* __restrict__ zero_ptr, int zero_n) {
     constexpr int NA = MODE == GNNCCA_EDGE_ATTR_FULL ? 4 : 2;
+    // (gnncca_frames_forward: the post-processing counters of the same batch are zeroed here, launches ahead of their first use, instead of
+    // by a memset node of their own)
+    if (zero_ptr && blockIdx.y == 0)
+        for (int t = blockIdx.x * 256 + threadIdx.x; t < zero_n; t += gridDim.x * 256) zero_ptr[t] = 0;
     const int lane = threadIdx.x & 63;
     const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (p >= N) return;
@@ -370,6 +375,14 @@ int gnncca_normalize_columns(const float* x, int64_t n_rows, int64_t n_cols, flo
 int gnncca_build_edges(const gnncca_frames* fr, const float* reid, int32_t reid_dim, int64_t n_nodes, int64_t n_edges,
                        int32_t mode, int64_t* edge_index_out, float* edge_attr_out, float* edge_labels_out,
                        gnncca_stream_t stream) {
+    return gnncca::build_edges_zeroing(fr, reid, reid_dim, n_nodes, n_edges, mode, edge_index_out, edge_attr_out, edge_labels_out, nullptr, 0, stream);
+}
+
+}  // extern "C"
+
+int gnncca::build_edges_zeroing(const gnncca_frames* fr, const float* reid, int32_t reid_dim, int64_t n_nodes, int64_t n_edges,
+                                int32_t mode, int64_t* edge_index_out, float* edge_attr_out, float* edge_labels_out, int32_t* zero_ptr,
+                                int64_t zero_n, gnncca_stream_t stream) {
     if (!fr || n_nodes < 0 || n_edges < 0 || reid_dim < 0) return GNNCCA_ERR_INVALID_ARG;
     if (mode < GNNCCA_EDGE_ATTR_FULL || mode > GNNCCA_EDGE_ATTR_ONLY_DIST) return GNNCCA_ERR_INVALID_ARG;
     if (n_nodes == 0 || n_edges == 0) return GNNCCA_OK;
@@ -387,20 +400,22 @@ int gnncca_build_edges(const gnncca_frames* fr, const float* reid, int32_t reid_
     switch (mode) {
         case GNNCCA_EDGE_ATTR_FULL:
             hipLaunchKernelGGL((build_edges_kernel<GNNCCA_EDGE_ATTR_FULL>), grid, block, 0, st, *fr, reid, (int)reid_dim,
-                               (int)n_nodes, (long long)n_edges, ei, edge_attr_out, edge_labels_out);
+                               (int)n_nodes, (long long)n_edges, ei, edge_attr_out, edge_labels_out, zero_ptr, (int)zero_n);
             break;
         case GNNCCA_EDGE_ATTR_ONLY_APPEARANCE:
             hipLaunchKernelGGL((build_edges_kernel<GNNCCA_EDGE_ATTR_ONLY_APPEARANCE>), grid, block, 0, st, *fr, reid,
-                               (int)reid_dim, (int)n_nodes, (long long)n_edges, ei, edge_attr_out, edge_labels_out);
+                               (int)reid_dim, (int)n_nodes, (long long)n_edges, ei, edge_attr_out, edge_labels_out, zero_ptr, (int)zero_n);
             break;
         default:
             hipLaunchKernelGGL((build_edges_kernel<GNNCCA_EDGE_ATTR_ONLY_DIST>), grid, block, 0, st, *fr, reid, (int)reid_dim,
-                               (int)n_nodes, (long long)n_edges, ei, edge_attr_out, edge_labels_out);
+                               (int)n_nodes, (long long)n_edges, ei, edge_attr_out, edge_labels_out, zero_ptr, (int)zero_n);
             break;
     }
     HIP_TRY_GB(hipGetLastError());
     return GNNCCA_OK;
 }
+
+extern "C" {
 
 // ---- host side of row N1: the edge enumeration of a batch of frames (inference.py:207-212), written straight into the staging image ----
 // Layout of `staging` (what gnn_cca_amd.graph_build uploads in ONE transfer; 8-byte fields first):

@@ -124,6 +124,11 @@ struct GenWorkspace {
 };
 GenWorkspace carve_generic(const gnncca_mpn_dims* d, int64_t n, int64_t e);
 
+// gnncca_build_edges that also zeroes `zero_n` int32 words at `zero_ptr` (graph_build.hip; gnncca_frames_forward hands it the post stage's counters)
+int build_edges_zeroing(const gnncca_frames* fr, const float* reid, int32_t reid_dim, int64_t n_nodes, int64_t n_edges, int32_t mode,
+                        int64_t* edge_index_out, float* edge_attr_out, float* edge_labels_out, int32_t* zero_ptr, int64_t zero_n,
+                        gnncca_stream_t stream);
+
 Family classify(const gnncca_mpn_dims* d);
 bool blob_header(const gnncca_mpn_dims* d, BlobHeader* out);  // false if unsupported
 bool dims_valid(const gnncca_mpn_dims* d);

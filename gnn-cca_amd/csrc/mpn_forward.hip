@@ -813,6 +813,12 @@ struct PostPlan {
     const int* col32;
     const int* perm;
     const unsigned* flags;
+    // gnncca_frames_forward's two other savings: the counters were zeroed by an earlier kernel of the batch (no memset node here), and the
+    // threshold rides in the prune kernel (logits in, probabilities and predictions out)
+    bool counters_zeroed;
+    const float* logits;
+    float* probs_out;
+    int64_t* preds_out;
 };
 static int post_prune_cluster_impl(const int64_t* edge_index, const int64_t* predictions, int64_t n_nodes, int64_t n_edges,
                                    const int32_t* node_ptr_dev, const int32_t* edge_ptr_dev, int32_t n_frames, void* workspace,
@@ -873,7 +879,9 @@ static int post_prune_cluster_impl(const int64_t* edge_index, const int64_t* pre
     // zero the counters: one memset when the caller laid flow_out | flow_in | n_clusters out back to back (gnn_cca_amd.postprocess does)
     const bool one_block = flow_in == flow_out + N && n_clusters_out == flow_in + N;
     const bool trig_block = one_block && triggers_out && sizes_scratch == n_clusters_out + 1 && triggers_out == sizes_scratch + N;
-    if (trig_block) {
+    if (plan && plan->counters_zeroed) {
+        // nothing: done launches ago
+    } else if (trig_block) {
         HIP_TRY(hipMemsetAsync(flow_out, 0, ((size_t)3 * N + 1 + n_trig) * 4, st));
     } else if (one_block) {
         HIP_TRY(hipMemsetAsync(flow_out, 0, ((size_t)2 * N + 1) * 4, st));
@@ -882,7 +890,7 @@ static int post_prune_cluster_impl(const int64_t* edge_index, const int64_t* pre
         HIP_TRY(hipMemsetAsync(flow_in, 0, (size_t)N * 4, st));
         HIP_TRY(hipMemsetAsync(n_clusters_out, 0, sizeof(int32_t), st));
     }
-    if (triggers_out && !trig_block) {
+    if (triggers_out && !trig_block && !(plan && plan->counters_zeroed)) {
         HIP_TRY(hipMemsetAsync(sizes_scratch, 0, (size_t)N * 4, st));
         HIP_TRY(hipMemsetAsync(triggers_out, 0, n_trig * 4, st));
     }
@@ -904,8 +912,14 @@ static int post_prune_cluster_impl(const int64_t* edge_index, const int64_t* pre
         HIP_TRY(hipGetLastError());
     }
     if (E > 0) {
-        hipLaunchKernelGGL(post_prune_kernel, grid1((size_t)E, 256), dim3(256), 0, st, ei, pred, (long long)E, (const int*)seg_ptr,
-                           (const int*)col32, (const int*)perm, (const unsigned*)flags, pruned, flow_out, flow_in);
+        if (plan && plan->logits)
+            hipLaunchKernelGGL(post_prune_kernel<true>, grid1((size_t)E, 256), dim3(256), 0, st, ei, pred, (long long)E, (const int*)seg_ptr,
+                               (const int*)col32, (const int*)perm, (const unsigned*)flags, pruned, flow_out, flow_in, plan->logits,
+                               plan->probs_out, reinterpret_cast<long long*>(plan->preds_out));
+        else
+            hipLaunchKernelGGL(post_prune_kernel<false>, grid1((size_t)E, 256), dim3(256), 0, st, ei, pred, (long long)E, (const int*)seg_ptr,
+                               (const int*)col32, (const int*)perm, (const unsigned*)flags, pruned, flow_out, flow_in, (const float*)nullptr,
+                               (float*)nullptr, (long long*)nullptr);
         HIP_TRY(hipGetLastError());
     }
     hipLaunchKernelGGL(post_cc_kernel, dim3(node_ptr_dev ? (unsigned)n_frames : 1u), dim3(1024), 0, st, ei,
@@ -944,7 +958,10 @@ int gnncca_frames_forward(const gnncca_mpn_dims* d, const void* packed_dev, cons
         if (st != GNNCCA_OK) return st;
         x = io->node_norm, reid = io->reid_norm;
     }
-    st = gnncca_build_edges(&fr, reid, io->reid_dim, n, e, io->mode, io->edge_index, io->edge_attr, io->edge_labels, stream);
+    // (the post stage's counters -- flow_out | flow_in | n_clusters | sizes | triggers -- are zeroed by this launch: no memset node later)
+    const bool zero_here = e > 0 && mpn_workspace != nullptr;
+    st = build_edges_zeroing(&fr, reid, io->reid_dim, n, e, io->mode, io->edge_index, io->edge_attr, io->edge_labels,
+                             zero_here ? io->counters : nullptr, zero_here ? 3 * n + 1 + g : 0, stream);
     if (st != GNNCCA_OK) return st;
     const int n_out = gnncca_num_outputs(d);
     if (n_out < 1) return GNNCCA_ERR_UNSUPPORTED;
@@ -952,8 +969,10 @@ int gnncca_frames_forward(const gnncca_mpn_dims* d, const void* packed_dev, cons
         st = gnncca_mpn_forward_ex(d, packed_dev, x, io->edge_index, io->edge_attr, n, e, mpn_workspace, mpn_workspace_bytes, io->logits, nullptr,
                                    options, stream);
         if (st != GNNCCA_OK) return st;
-        st = gnncca_post_threshold(io->logits + (size_t)(n_out - 1) * e, e, io->probs, io->predictions, stream);
-        if (st != GNNCCA_OK) return st;
+        if (!zero_here) {   // (no shared plan: the threshold keeps its own launch)
+            st = gnncca_post_threshold(io->logits + (size_t)(n_out - 1) * e, e, io->probs, io->predictions, stream);
+            if (st != GNNCCA_OK) return st;
+        }
     }
     // the pruning searches reverse edges in the CSR plan of edge_index -- the one the forward above left in ITS workspace (seg_ptr / col32 /
     // perm / flag word: same plan_block + plan_finish, same stream): handed over instead of being built a second time (two launches less)
@@ -964,12 +983,14 @@ int gnncca_frames_forward(const gnncca_mpn_dims* d, const void* packed_dev, cons
         if (classify(d) == kFamilyMfma32x6) {
             const Workspace ws = carve(d, n, e);
             plan = PostPlan{reinterpret_cast<const int*>(wb + ws.seg_ptr), reinterpret_cast<const int*>(wb + ws.col32),
-                            reinterpret_cast<const int*>(wb + ws.perm), reinterpret_cast<const unsigned*>(wb + ws.flags)};
+                            reinterpret_cast<const int*>(wb + ws.perm), reinterpret_cast<const unsigned*>(wb + ws.flags), false, nullptr, nullptr, nullptr};
         } else {
             const GenWorkspace ws = carve_generic(d, n, e);
             plan = PostPlan{reinterpret_cast<const int*>(wb + ws.seg_ptr), reinterpret_cast<const int*>(wb + ws.col32),
-                            reinterpret_cast<const int*>(wb + ws.perm), reinterpret_cast<const unsigned*>(wb + ws.flags)};
+                            reinterpret_cast<const int*>(wb + ws.perm), reinterpret_cast<const unsigned*>(wb + ws.flags), false, nullptr, nullptr, nullptr};
         }
+        plan.counters_zeroed = zero_here;
+        plan.logits = io->logits + (size_t)(n_out - 1) * e, plan.probs_out = io->probs, plan.preds_out = io->predictions;
         have_plan = &plan;
     }
     int32_t* c = io->counters;   // flow_out | flow_in | n_clusters | sizes (scratch) | triggers [G]

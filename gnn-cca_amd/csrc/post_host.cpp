@@ -17,6 +17,8 @@
 // Written from the reference's behaviour, checked against tests/golden/post2_heuristics.npz (the reference's own functions) and against
 // oracle/post_oracle.py; plain C++17, no GPU, no networkx.
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <cstdint>
 #include <cstring>
 #include <unordered_map>
@@ -32,11 +34,36 @@ struct Frame {
     const int64_t *src, *dst;   // frame-local ids after subtracting `base`
     int64_t base;
     const float* probs;
+    std::vector<std::vector<int>> out_edges, in_edges;   // edge ids by source / by target node, ascending (index())
     int u(int k) const { return (int)(src[k] - base); }
     int v(int k) const { return (int)(dst[k] - base); }
+    void index() {
+        out_edges.assign(n, {}), in_edges.assign(n, {});
+        for (int k = 0; k < E; ++k) out_edges[u(k)].push_back(k), in_edges[v(k)].push_back(k);
+    }
 };
 
 typedef std::vector<int64_t> Pred;
+
+// a set of ordered node pairs (u, v): a dense n x n byte map for frames (n <= 2048: 4 MB at most), a hash set beyond
+struct PairSet {
+    int n;
+    std::vector<char> dense;
+    std::unordered_set<uint64_t> sparse;
+    explicit PairSet(int n_) : n(n_) {
+        if (n <= 2048) dense.assign((size_t)n * n, 0);
+    }
+    bool insert(int u, int v) {   // true if new
+        if (!dense.empty()) {
+            char& c = dense[(size_t)u * n + v];
+            const bool fresh = !c;
+            c = 1;
+            return fresh;
+        }
+        return sparse.insert((uint64_t)u * (uint64_t)n + (uint64_t)v).second;
+    }
+    bool has(int u, int v) const { return !dense.empty() ? dense[(size_t)u * n + v] != 0 : sparse.count((uint64_t)u * (uint64_t)n + (uint64_t)v) != 0; }
+};
 
 static std::vector<int> active_edges(const Frame& f, const Pred& p) {
     std::vector<int> a;
@@ -55,12 +82,12 @@ static DiGraph digraph(const Frame& f, const std::vector<int>& act) {
     DiGraph g;
     g.succ.assign(f.n, {});
     g.present.assign(f.n, 0);
-    std::unordered_set<uint64_t> seen;
+    PairSet seen(f.n);
     for (int k : act) {
         const int u = f.u(k), v = f.v(k);
         if (!g.present[u]) g.present[u] = 1, g.nodes.push_back(u);
         if (!g.present[v]) g.present[v] = 1, g.nodes.push_back(v);
-        if (seen.insert((uint64_t)u * (uint64_t)f.n + (uint64_t)v).second) g.succ[u].push_back(v);
+        if (seen.insert(u, v)) g.succ[u].push_back(v);
     }
     return g;
 }
@@ -125,12 +152,11 @@ static int cluster_ids(const Frame& f, const std::vector<int>& act, std::vector<
 static std::unordered_set<uint64_t> bridge_set(const Frame& f, const std::vector<int>& act) {
     std::vector<std::vector<int>> und(f.n);
     {
-        std::unordered_set<uint64_t> seen;
+        PairSet seen(f.n);
         for (int k : act) {
             const int u = f.u(k), v = f.v(k);
             if (u == v) continue;
-            const uint64_t key = (uint64_t)std::min(u, v) * (uint64_t)f.n + (uint64_t)std::max(u, v);
-            if (seen.insert(key).second) und[u].push_back(v), und[v].push_back(u);
+            if (seen.insert(std::min(u, v), std::max(u, v))) und[u].push_back(v), und[v].push_back(u);
         }
     }
     std::vector<int> disc(f.n, 0), low(f.n, 0), it(f.n, 0), parent(f.n, -1), stack;
@@ -167,12 +193,12 @@ static std::unordered_set<uint64_t> bridge_set(const Frame& f, const std::vector
 
 // utils.remove_edges_single_direction: an active edge survives iff its reverse is active too
 static Pred prune(const Frame& f, const Pred& p) {
-    std::unordered_set<uint64_t> act;
+    PairSet act(f.n);
     for (int k = 0; k < f.E; ++k)
-        if (p[k] == 1) act.insert((uint64_t)f.u(k) * f.n + f.v(k));
+        if (p[k] == 1) act.insert(f.u(k), f.v(k));
     Pred out = p;
     for (int k = 0; k < f.E; ++k)
-        if (p[k] == 1 && !act.count((uint64_t)f.v(k) * f.n + f.u(k))) out[k] = 0;
+        if (p[k] == 1 && !act.has(f.v(k), f.u(k))) out[k] = 0;
     return out;
 }
 
@@ -194,14 +220,17 @@ static bool rounding(const Frame& f, const Pred& pred, Pred& out) {
     if (!violated(fo, fi)) return false;
     out = pred;
     const std::unordered_set<uint64_t> bridges = bridge_set(f, active_edges(f, pred));   // of the graph the call came with, every round
+    std::vector<char> on_bridge(f.E, 0);
+    if (!bridges.empty())
+        for (int k = 0; k < f.E; ++k) on_bridge[k] = (char)bridges.count((uint64_t)f.u(k) * f.n + f.v(k));
     for (;;) {
         std::vector<int> remove;
         if (!bridges.empty()) {
             for (int side = 0; side < 2; ++side)
                 for (int v = 0; v < f.n; ++v) {
                     if ((side == 0 ? fo[v] : fi[v]) <= 3) continue;
-                    for (int k = 0; k < f.E; ++k)
-                        if ((side == 0 ? f.u(k) : f.v(k)) == v && out[k] == 1 && bridges.count((uint64_t)f.u(k) * f.n + f.v(k))) remove.push_back(k);
+                    for (int k : (side == 0 ? f.out_edges[v] : f.in_edges[v]))   // ascending edge ids, as np.intersect1d returns them
+                        if (out[k] == 1 && on_bridge[k]) remove.push_back(k);
                 }
         }
         if (remove.empty()) {   // the weakest active edge of every violating node: first minimum in edge order (np.argmin)
@@ -209,8 +238,8 @@ static bool rounding(const Frame& f, const Pred& pred, Pred& out) {
                 for (int v = 0; v < f.n; ++v) {
                     if ((side == 0 ? fo[v] : fi[v]) <= 3) continue;
                     int best = -1;
-                    for (int k = 0; k < f.E; ++k)
-                        if ((side == 0 ? f.u(k) : f.v(k)) == v && out[k] == 1 && (best < 0 || f.probs[k] < f.probs[best])) best = k;
+                    for (int k : (side == 0 ? f.out_edges[v] : f.in_edges[v]))
+                        if (out[k] == 1 && (best < 0 || f.probs[k] < f.probs[best])) best = k;
                     if (best >= 0) remove.push_back(best);
                 }
         }
@@ -281,9 +310,10 @@ int gnncca_post_finalize_frame_host(const int64_t* src, const int64_t* dst, int6
                                     int32_t* n_clusters_out, int64_t* id_pred_out) {
     if (n_nodes < 0 || n_edges < 0 || n_nodes >= (1ll << 24) || n_edges >= (1ll << 30)) return GNNCCA_ERR_INVALID_ARG;
     if (n_edges > 0 && (!src || !dst || !probs || !predictions)) return GNNCCA_ERR_INVALID_ARG;
-    Frame f{(int)n_nodes, (int)n_edges, src, dst, node_base, probs};
+    Frame f{(int)n_nodes, (int)n_edges, src, dst, node_base, probs, {}, {}};
     for (int k = 0; k < f.E; ++k)
         if (src[k] < node_base || src[k] >= node_base + n_nodes || dst[k] < node_base || dst[k] >= node_base + n_nodes) return GNNCCA_ERR_INVALID_ARG;
+    f.index();
     Pred pred(predictions, predictions + n_edges);
     const bool do_round = (switches & GNNCCA_POST_ROUNDING) != 0, do_prune = (switches & GNNCCA_POST_PRUNING) != 0,
                do_split = (switches & GNNCCA_POST_SPLITTING) != 0;
@@ -310,6 +340,40 @@ int gnncca_post_finalize_frame_host(const int64_t* src, const int64_t* dst, int6
     }
     if (n_clusters_out) *n_clusters_out = k;
     return GNNCCA_OK;
+}
+
+// The same for a list of frames of ONE batch (Batch.from_data_list layout: frame g owns nodes [node_ptr[g], node_ptr[g + 1]) and the contiguous
+// edges [edge_ptr[g], edge_ptr[g + 1]); src / dst / probs / predictions / labels are the BATCH's arrays): frames[i] names a frame to finalize,
+// clusters_out[i] receives its final cluster count; frames are independent, so they are dealt to up to `n_threads` host threads (0: one per
+// hardware thread, at most 16).  Returns the first non-zero status of any frame.
+int gnncca_post_finalize_frames_host(const int64_t* src, const int64_t* dst, const int32_t* node_ptr, const int32_t* edge_ptr,
+                                     const int32_t* frames, int32_t n_listed, const float* probs, int64_t* predictions, int32_t switches,
+                                     int32_t* labels, int32_t* clusters_out, int32_t n_threads) {
+    if (n_listed < 0 || (n_listed > 0 && (!node_ptr || !edge_ptr || !frames || !clusters_out))) return GNNCCA_ERR_INVALID_ARG;
+    if (n_listed == 0) return GNNCCA_OK;
+    int nt = n_threads > 0 ? n_threads : (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    nt = std::min(nt, (int)n_listed);
+    std::atomic<int> next(0), status(GNNCCA_OK);
+    auto work = [&]() {
+        for (int i = next.fetch_add(1); i < n_listed; i = next.fetch_add(1)) {
+            const int g = frames[i];
+            const int64_t v0 = node_ptr[g], v1 = node_ptr[g + 1], k0 = edge_ptr[g], k1 = edge_ptr[g + 1];
+            const int st = gnncca_post_finalize_frame_host(src + k0, dst + k0, v0, v1 - v0, k1 - k0, probs + k0, predictions + k0, switches,
+                                                           labels ? labels + v0 : nullptr, clusters_out + i, nullptr);
+            if (st != GNNCCA_OK) {
+                int expected = GNNCCA_OK;
+                status.compare_exchange_strong(expected, st);
+            }
+        }
+    };
+    if (nt <= 1) {
+        work();
+    } else {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < nt; ++t) pool.emplace_back(work);
+        for (auto& t : pool) t.join();
+    }
+    return status.load();
 }
 
 }  // extern "C"

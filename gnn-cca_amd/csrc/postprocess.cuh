@@ -18,24 +18,42 @@ __global__ __launch_bounds__(256) void post_threshold_kernel(const float* __rest
 
 // out[k] = pred[k] && the reverse edge (col k, row k) exists and is active too.  The reverse edge is searched in the
 // CSR segment of node col[k] (plan of the MPN forward: seg_ptr / col32 / perm), any column order.
+// FUSED_THRESHOLD (gnncca_frames_forward): `logits` instead of `pred` -- the thread computes its edge's probability and prediction with
+// post_threshold_kernel's own expression (same bits), writes both out, and judges a reverse edge by that expression too: one launch less.
+template <bool FUSED_THRESHOLD>
 __global__ __launch_bounds__(256) void post_prune_kernel(const long long* __restrict__ ei, const long long* __restrict__ pred,
                                                          long long E, const int* __restrict__ seg_ptr,
                                                          const int* __restrict__ col32, const int* __restrict__ perm,
                                                          const unsigned* __restrict__ flags, long long* __restrict__ out,
-                                                         int* __restrict__ flow_out, int* __restrict__ flow_in) {
+                                                         int* __restrict__ flow_out, int* __restrict__ flow_in,
+                                                         const float* __restrict__ logits, float* __restrict__ probs_out,
+                                                         long long* __restrict__ preds_out) {
     const long long k = (long long)blockIdx.x * 256 + threadIdx.x;
     if (k >= E) return;
     const unsigned fl = flags[0];
+    auto active = [&](long long q) -> bool {
+        if (FUSED_THRESHOLD) return 1.f / (1.f + expf(-logits[q])) >= 0.5f;
+        return pred[q] == 1;
+    };
+    bool mine;
+    if (FUSED_THRESHOLD) {
+        const float p = 1.f / (1.f + expf(-logits[k]));  // torch.nn.Sigmoid (post_threshold_kernel)
+        probs_out[k] = p;
+        mine = p >= 0.5f;
+        preds_out[k] = mine ? 1 : 0;
+    } else {
+        mine = pred[k] == 1;
+    }
     if (fl & GNNCCA_GRAPH_BAD_INDEX) {
         out[k] = 0;
         return;
     }
     long long keep = 0;
-    if (pred[k] == 1) {
+    if (mine) {
         const bool unsorted = (fl & GNNCCA_GRAPH_UNSORTED) != 0;
         const int i = (int)ei[k], j = (int)ei[E + k];
         for (int q = seg_ptr[j]; q < seg_ptr[j + 1]; ++q) {
-            if (col32[q] == i && pred[unsorted ? perm[q] : q] == 1) {
+            if (col32[q] == i && active(unsorted ? perm[q] : q)) {
                 keep = 1;
                 break;
             }

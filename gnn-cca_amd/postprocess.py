@@ -122,16 +122,15 @@ def finalize(edge_index, probs, pruned, labels, n_clusters, triggers, node_ptr=N
     total = int(n_clusters.cpu().numpy()[0])
     switches = (nat.POST_ROUNDING if rounding else 0) | nat.POST_PRUNING | (nat.POST_SPLITTING if splitting else 0)
     lib = nat.lib()
-    k_new = C.c_int32(0)
-    for g in todo:
-        v0, v1, k0, k1 = node_ptr[g], node_ptr[g + 1], edge_ptr[g], edge_ptr[g + 1]
-        before = int((lab[v0:v1] == np.arange(v0, v1)).sum())
-        st = lib.gnncca_post_finalize_frame_host(src.ctypes.data + 8 * k0, dst.ctypes.data + 8 * k0, v0, v1 - v0, k1 - k0,
-                                                 pr.ctypes.data + 4 * k0, pred.ctypes.data + 8 * k0, switches,
-                                                 lab.ctypes.data + 4 * v0, C.byref(k_new), None)
-        if st:
-            nat.check(st, "gnncca_post_finalize_frame_host")
-        total += int(k_new.value) - before
+    np_h, ep_h = np.asarray(node_ptr, dtype=np.int32), np.asarray(edge_ptr, dtype=np.int32)
+    listed, k_new = np.asarray(todo, dtype=np.int32), np.zeros(len(todo), dtype=np.int32)
+    roots = lab == np.arange(n, dtype=lab.dtype)                       # the device chain's labels: a component's smallest node id
+    before = sum(int(roots[np_h[g]:np_h[g + 1]].sum()) for g in todo)
+    st = lib.gnncca_post_finalize_frames_host(src.ctypes.data, dst.ctypes.data, np_h.ctypes.data, ep_h.ctypes.data, listed.ctypes.data, len(todo),
+                                              pr.ctypes.data, pred.ctypes.data, switches, lab.ctypes.data, k_new.ctypes.data, 0)
+    if st:
+        nat.check(st, "gnncca_post_finalize_frames_host")
+    total += int(k_new.sum()) - before
     dev = pruned.device
     return {"predictions": torch.from_numpy(pred).to(dev), "labels": torch.from_numpy(lab).to(dev),
             "n_clusters": torch.tensor([total], dtype=torch.int32, device=dev), "frames_finalized": todo, "triggers": trig}

@@ -317,6 +317,13 @@ GNNCCA_API int gnncca_post_finalize_frame_host(const int64_t* src, const int64_t
                                                int64_t n_edges, const float* probs, int64_t* predictions, int32_t switches,
                                                int32_t* labels_out, int32_t* n_clusters_out, int64_t* id_pred_out);
 
+/* The same for a list of frames of one batch, dealt to host threads (frames are independent): batch-wide arrays in Batch.from_data_list
+ * layout, node_ptr / edge_ptr [G + 1] on the HOST, frames[i] the i-th frame to finalize (the ones whose trigger word is set),
+ * clusters_out[i] its final cluster count; n_threads 0 = one per hardware thread, at most 16. */
+GNNCCA_API int gnncca_post_finalize_frames_host(const int64_t* src, const int64_t* dst, const int32_t* node_ptr, const int32_t* edge_ptr,
+                                                const int32_t* frames, int32_t n_listed, const float* probs, int64_t* predictions,
+                                                int32_t switches, int32_t* labels, int32_t* clusters_out, int32_t n_threads);
+
 /* ---- rows N1 + the path + N2 in ONE call: a batch of frames from the uploaded staging image to identity clusters -------------------
  * The per-batch body of inference.py:189-345 (normalise the embeddings, build the graph, MOTMPNet.forward, sigmoid / threshold,
  * prune, flow counts, clusters) as the same launches gnncca_normalize_columns2 / gnncca_build_edges / gnncca_mpn_forward_ex /

@@ -98,6 +98,35 @@ def test_host_implementation_matches_the_oracle_on_random_frames():
     assert changed >= 50     # the heuristics had work to do on a good share of the frames
 
 
+def test_threaded_batch_entry_point_matches_the_reference():
+    """gnncca_post_finalize_frames_host: all golden frames as one Batch.from_data_list-style batch, every frame listed, dealt to host threads."""
+    from gnn_cca_amd import _native as nat
+    eis, probs, node_ptr, edge_ptr, want_pred, want_k = [], [], [0], [0], [], []
+    for name in NAMES:
+        n, ei, _, p, g = case(name)
+        eis.append(ei + node_ptr[-1])
+        probs.append(p)
+        want_pred.append(g("pred_final"))
+        want_k.append(len(set(g("id_final").tolist())))
+        node_ptr.append(node_ptr[-1] + n)
+        edge_ptr.append(edge_ptr[-1] + ei.shape[1])
+    ei_all, pr = np.concatenate(eis, axis=1), np.ascontiguousarray(np.concatenate(probs), dtype=np.float32)
+    src, dst = np.ascontiguousarray(ei_all[0]), np.ascontiguousarray(ei_all[1])
+    np_h, ep_h = np.asarray(node_ptr, np.int32), np.asarray(edge_ptr, np.int32)
+    for threads in (1, 4, 0):
+        pred = (pr >= 0.5).astype(np.int64)
+        labels = np.zeros(node_ptr[-1], np.int32)
+        listed, k = np.arange(len(NAMES), dtype=np.int32)[::-1].copy(), np.zeros(len(NAMES), np.int32)
+        st = nat.lib().gnncca_post_finalize_frames_host(src.ctypes.data, dst.ctypes.data, np_h.ctypes.data, ep_h.ctypes.data, listed.ctypes.data,
+                                                        len(NAMES), pr.ctypes.data, pred.ctypes.data, 7, labels.ctypes.data, k.ctypes.data, threads)
+        assert st == 0
+        assert np.array_equal(pred, np.concatenate(want_pred))
+        assert k[::-1].tolist() == want_k
+        for q, name in enumerate(NAMES):
+            assert po.same_partition(labels[node_ptr[q]:node_ptr[q + 1]], case(name)[4]("id_final")), name
+            assert labels[node_ptr[q]:node_ptr[q + 1]].min() >= node_ptr[q]
+
+
 @pytest.mark.gpu
 def test_device_triggers_and_finalize_against_the_reference():
     """All golden frames as ONE batch (Batch.from_data_list layout): the device chain's trigger bits are exactly "a node with flow > 3" /
