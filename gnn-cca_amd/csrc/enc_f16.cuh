@@ -207,6 +207,7 @@ struct EncF16Params {
     int k_rotate;
     int force_arm;                 // diagnostics / tests: 1 = every tile takes the bf16 arm
     int prio_late_half;            // 1: waves 4-7 run the main loop at s_setprio 1
+    int x_nt;                      // 1: the x stream's LDS-DMA requests carry the non-temporal cache policy
 };
 
 // DIAG (GNNCCA_DIAG builds of the ablation matrix, timing only -- the results are garbage): bit 0 = no MFMAs (the fragments stay used), bit 1 = every
@@ -254,9 +255,12 @@ __device__ __forceinline__ void enc_gemm_f16_body(const EncF16Params p, const En
     auto issue_one = [&](int kt, int j) {
         const int kc = kchunk(min(kt, nk - 1));
         const int st = kt % kF16Stages;
-        if (j < 4)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_dma_ptr)(xring + st * kF16XSlot + j * 1024), 16, xoff[j & 3], (unsigned)(kbeg + kc * BK) * 4u, 0, 0);
-        else
+        if (j < 4) {
+            if (p.x_nt)   // x is read once: the non-temporal policy keeps it from displacing what the step kernels left in the caches (and W)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_dma_ptr)(xring + st * kF16XSlot + j * 1024), 16, xoff[j & 3], (unsigned)(kbeg + kc * BK) * 4u, 0, 2);
+            else
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_dma_ptr)(xring + st * kF16XSlot + j * 1024), 16, xoff[j & 3], (unsigned)(kbeg + kc * BK) * 4u, 0, 0);
+        } else
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_dma_ptr)(wring + st * kF16WSlot + wave * 2048 + (j - 4) * 1024), 16, woff + (j - 4) * 1024,
                                                      (unsigned)(kbeg / BK + kc) * (unsigned)kF16WSlot, 0, 0);
     };
@@ -492,8 +496,13 @@ __global__ __launch_bounds__(kF16R32Threads) void enc_gemm_f16_rows32_kernel(con
                 const int q = 2 * L + g;
                 unsigned char* dst = lds_raw + ((size_t)q * kF16R32Stages + st) * 4096;
                 const unsigned so = (unsigned)((q * nkc + lc) * BK) * 4u;
+                if (p.x_nt) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_dma_ptr)(dst + j * 1024), 16, xoff[j], so, 0, 0);
+                    for (int j = 0; j < 4; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_dma_ptr)(dst + j * 1024), 16, xoff[j], so, 0, 2);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_dma_ptr)(dst + j * 1024), 16, xoff[j], so, 0, 0);
+                }
             }
         };
 #pragma unroll

@@ -255,6 +255,13 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
             // of that form) and as the A/B reference (GNNCCA_GEMM_BF16).  K / ks_split is a multiple of 32 on this path.
             static const bool gemm_bf16 = diag_env("GNNCCA_GEMM_BF16") != nullptr;
             static const int f16_force_arm = diag_env_int("GNNCCA_GEMM_F16_ARM", 0, 0, 1);   // diagnostics / tests: every tile on the bf16 arm
+            // x stream of the fp16-split GEMMs: NON-TEMPORAL from 128 MB of x on (N >= 16 384 at K = 2048).  Inside a real forward the caches are full
+            // of what the previous forward's step kernels left (dirty edge state), and a default-policy x stream fights it for every line: BASELINE
+            // config 4 in situ 174 -> 137 us for this launch (0.516 -> 0.485 ms per forward), while an encoder timed alone on clean caches hides
+            // the difference (121 us either way); at the 8 192-node share the policy costs 1 us, so small batches keep the default
+            // (profiles/r05_logs/ab_config4_nt.log).  GNNCCA_GEMM_F16_XNT = 0 / 1 forces it off / on.
+            static const int f16_x_nt_force = diag_env_int("GNNCCA_GEMM_F16_XNT", -1, -1, 1);
+            const int f16_x_nt = f16_x_nt_force >= 0 ? f16_x_nt_force : ((double)N * K * 4.0 >= 128.0 * 1024 * 1024 ? 1 : 0);
             const bool use_f16 = use_lds && !use_r32 && !use_r32f && hdr.enc_w2h != 0 && !split3 && (options & GNNCCA_OPT_ENC_UNSPLIT) == 0 && !gemm_bf16 &&
                                  gemm_x_l2 == 0 && K % 32 == 0 && (K / ks_split) % 32 == 0;
             static thread_local int attr_dev = -1;  // once per device and thread: the attribute is per device
@@ -290,6 +297,7 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
                 q.M = N, q.K = K, q.kslice = K;
                 q.k_rotate = fp.k_rotate;
                 q.force_arm = f16_force_arm;
+                q.x_nt = f16_x_nt;
                 GNNCCA_LAUNCH(enc_gemm_f16_rows32_kernel, dim3((unsigned)((N + 31) / 32) + 1), dim3(kF16R32Threads), kF16R32LdsBytes, st, q, fp);
             } else if (use_r32) {
                 const dim3 rgrid((unsigned)((N + 31) / 32) + 1);
@@ -316,6 +324,7 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
                 q.force_arm = f16_force_arm;
                 static const int f16_prio = diag_env_int("GNNCCA_GEMM_F16_PRIO", 0, 0, 1);   // diagnostics: static priority of waves 4-7 (measured: 122.9 vs 121 us at N = 65 536 -- off)
                 q.prio_late_half = f16_prio;
+                q.x_nt = f16_x_nt;
                 const dim3 fgrid((N + 255) / 256 + 1, 1), sgrid((N + 255) / 256, ks_split);
 #ifdef GNNCCA_F16_ABLATIONS
                 static const int f16_diag = diag_env_int("GNNCCA_GEMM_F16_DIAG", 0, 0, 7);

@@ -251,6 +251,37 @@ def test_lds_staged_split_gemm_vs_fp64_oracle(n_nodes):
         assert np.abs(o.cpu().numpy() - r).max() <= TOL_TIGHT * 2
 
 
+@pytest.mark.parametrize("n_nodes", [4096 + 5, 8192, 9000, 66000])
+def test_fp16_split_gemm_short_k(n_nodes):
+    """arch = 'bdnet_market' (node_in_dim 512): the fp16-split GEMMs with only 16 chunks of K -- the 32-row kernel's k-quarters are then four
+    chunks long, SHORTER than its five-chunk x prefetch (clamped duplicate requests), and the 256-row kernel's split-K slices two chunks."""
+    params, arch, sd, _ = load_case(os.path.join(GOLDEN_DIR, "bdnet512.npz"))
+    rng = np.random.default_rng(n_nodes)
+    k = params["encoder_feats_dict"]["nodes"][arch]["node_in_dim"]
+    assert k == 512
+    x = rng.standard_normal((n_nodes, k)).astype(np.float32)
+    x /= np.linalg.norm(x, axis=0, keepdims=True)
+    src = np.repeat(np.arange(n_nodes), 2)
+    dst = (src + np.tile([1, 5], n_nodes)) % n_nodes
+    ei = np.stack([src, dst]).astype(np.int64)
+    ea = rng.random((ei.shape[1], 4)).astype(np.float32)
+    orc = NumpyOracle(params, arch, sd, np.float32)
+    tr = {}
+    ref = orc.forward(x, ei, ea, tr)
+    m = build(params, arch, sd)
+    d = Data(torch.from_numpy(x).cuda(), torch.from_numpy(ei).cuda(), torch.from_numpy(ea).cuda())
+    trace = {}
+    with torch.no_grad():
+        out = [t.clone() for t in m(d)["classified_edges"]]
+        m(d, trace=trace)
+    h64 = NumpyOracle(params, arch, sd, np.float64)._mlp("encoder.node_mlp", x.astype(np.float64))
+    err_gpu = np.abs(trace["h_enc"].cpu().numpy() - h64).max()
+    err_ref = np.abs(tr["h_enc"] - h64).max()
+    assert err_gpu <= max(4 * err_ref, 2e-7), (err_gpu, err_ref)
+    for o, r in zip(out, ref):
+        assert np.abs(o.cpu().numpy() - r).max() <= TOL_TIGHT * 2
+
+
 @pytest.mark.parametrize("n_nodes", [6144 + 9, 51200 + 33])
 @pytest.mark.parametrize("what", ["x_beyond_fp16", "w_beyond_fp16", "x_tiny"])
 def test_fp16_split_gemm_range_guard(n_nodes, what):
