@@ -33,7 +33,7 @@ MAX_NODES = 4096
 
 
 class FrameResult:
-    """Outputs of one batch; tensors are views of three device buffers owned by this object."""
+    """Outputs of one batch; tensors are views of ONE device buffer owned by this object."""
     __slots__ = ("batch", "outputs", "probs", "preds", "pruned", "flow_out", "flow_in", "labels", "n_clusters", "triggers", "_switches", "_final", "_keep")
 
     def final(self):
@@ -111,9 +111,6 @@ class FramePipeline:
             raise RuntimeError(f"the model takes {d.edge_in} edge attributes, this pipeline's mode builds {n_attr}")
         r_dim, d_in = int(reid_embeds.shape[1]), int(d.node_in)
         with _on(dev):
-            staged = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-            staged.copy_(pinned[:nbytes], non_blocking=True)
-            event.record(_current_stream(dev))
             blob = m._packed_weights(dev)
             hot = m._hot
             if hot.n_out < 0:
@@ -128,11 +125,8 @@ class FramePipeline:
             o_lab = o_attr + up(e * n_attr)
             o_log = o_lab + up(e)
             o_prob = o_log + up(n_out * e)
-            f32 = torch.empty(o_prob + e, dtype=torch.float32, device=dev)
             o_pred, o_prun = up(2 * e), up(2 * e) + up(e)
-            i64 = torch.empty(o_prun + e, dtype=torch.int64, device=dev)
             o_labels = up(3 * n + 1 + g)      # flow_out | flow_in | n_clusters | cluster sizes (scratch) | triggers [G]
-            i32 = torch.empty(o_labels + n, dtype=torch.int32, device=dev)
             if self._shape != (n, e):
                 self._shape = (n, e)
                 self._sizes = (lib.gnncca_workspace_bytes(C.byref(d), n, e) if e > 0 else 0, lib.gnncca_post_workspace_bytes(n, e) + 256)
@@ -140,7 +134,21 @@ class FramePipeline:
             if e > 0 and ws_bytes == 0:
                 nat.check(lib.gnncca_supported(C.byref(d)), "MOTMPNet configuration")
             ws = m._scratch(max(ws_bytes, 256), dev)
-            post_ws = torch.empty(post_bytes, dtype=torch.uint8, device=dev)
+            # ONE allocation per batch (round 5; five until then, 2-3 us of host time each): [staging image | f32 | i64 | i32 | post workspace],
+            # every region on a 256-byte boundary
+            def up256(v):
+                return (v + 255) // 256 * 256
+            b_f32, b_i64 = up256(nbytes), up256(nbytes) + up256(4 * (o_prob + e))
+            b_i32 = b_i64 + up256(8 * (o_prun + e))
+            b_post = b_i32 + up256(4 * (o_labels + n))
+            arena = torch.empty(b_post + post_bytes, dtype=torch.uint8, device=dev)
+            staged = arena[:nbytes]
+            staged.copy_(pinned[:nbytes], non_blocking=True)
+            event.record(_current_stream(dev))
+            f32 = arena[b_f32:b_f32 + 4 * (o_prob + e)].view(torch.float32)
+            i64 = arena[b_i64:b_i64 + 8 * (o_prun + e)].view(torch.int64)
+            i32 = arena[b_i32:b_i32 + 4 * (o_labels + n)].view(torch.int32)
+            post_ws = arena[b_post:b_post + post_bytes]
             io = nat.FramesIO()
             io.staged_dev, io.n_nodes, io.n_frames, io.n_edges = staged.data_ptr(), n, g, e
             io.node_embeds, io.reid_embeds, io.reid_dim, io.mode, io.normalize = node_embeds.data_ptr(), reid_embeds.data_ptr(), r_dim, self.mode, int(self.normalize)
@@ -175,5 +183,5 @@ class FramePipeline:
         r.preds, r.pruned = i64[o_pred:o_pred + e], i64[o_prun:o_prun + e]
         r.flow_out, r.flow_in, r.n_clusters, r.labels = i32[:n], i32[n:2 * n], i32[2 * n:2 * n + 1], i32[o_labels:o_labels + n]
         r.triggers, r._switches, r._final = i32[3 * n + 1:3 * n + 1 + g], self.switches, None
-        r._keep = (staged, f32, i64, i32, ws, post_ws, blob)
+        r._keep = (arena, ws, blob)
         return r
