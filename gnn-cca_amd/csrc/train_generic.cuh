@@ -61,14 +61,15 @@ __global__ __launch_bounds__(256) void tr_cat_kernel(GenSeg s0, GenSeg s1, GenSe
 //   mode 2: out[0][c] += sum g,  out[1][c] += sum g * xhat   with xhat = (z - mean[c]) * invstd[c]
 __global__ __launch_bounds__(256) void tr_col_reduce_kernel(const float* __restrict__ A, const float* __restrict__ Z,
                                                             const float* __restrict__ stat, long long M, int O, int rows_per_block,
-                                                            double* __restrict__ out, int mode) {
+                                                            double* __restrict__ out, int mode, const double* __restrict__ mean_sums) {
     __shared__ double s0[4][64], s1[4][64];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + tx;
     const long long r0 = (long long)blockIdx.y * rows_per_block, r1 = min(r0 + rows_per_block, M);
     double a0 = 0.0, a1 = 0.0;
     if (c < O) {
-        const float mean = mode >= 1 ? stat[c] : 0.f, invstd = mode == 2 ? stat[O + c] : 0.f;
+        // (mode 1 with `mean_sums`: the mean straight from the first pass's column sums -- tr_bn_mean_kernel's expression, same bits)
+        const float mean = mode >= 1 ? (mean_sums ? (float)(mean_sums[c] / (double)M) : stat[c]) : 0.f, invstd = mode == 2 ? stat[O + c] : 0.f;
         for (long long r = r0 + ty; r < r1; r += 4) {
             const float z = Z[(size_t)r * O + c];
             if (mode == 0)
@@ -100,7 +101,7 @@ __global__ __launch_bounds__(256) void tr_col_reduce_kernel(const float* __restr
 // thread keeps ONE column (t % O) for all passes; eight passes are requested before they are added.
 __global__ __launch_bounds__(256) void tr_col_reduce_narrow_kernel(const float* __restrict__ A, const float* __restrict__ Z,
                                                                    const float* __restrict__ stat, long long M, int O, int rows_per_block,
-                                                                   double* __restrict__ out, int mode) {
+                                                                   double* __restrict__ out, int mode, const double* __restrict__ mean_sums) {
     __shared__ double s0[256], s1[256];
     const int RB = 256 / O;                       // rows per pass
     const int t = threadIdx.x;
@@ -109,7 +110,7 @@ __global__ __launch_bounds__(256) void tr_col_reduce_narrow_kernel(const float* 
     const long long r0 = (long long)blockIdx.x * rows_per_block, r1 = min(r0 + rows_per_block, M);
     double a0 = 0.0, a1 = 0.0;
     if (on) {
-        const float mean = mode >= 1 ? stat[c] : 0.f, invstd = mode == 2 ? stat[O + c] : 0.f;
+        const float mean = mode >= 1 ? (mean_sums ? (float)(mean_sums[c] / (double)M) : stat[c]) : 0.f, invstd = mode == 2 ? stat[O + c] : 0.f;
         for (long long rb = r0 + rl; rb < r1; rb += 8LL * RB) {
             float z[8], g[8];
 #pragma unroll
@@ -172,6 +173,39 @@ __global__ __launch_bounds__(256) void tr_bn_apply_kernel(const float* z, const 
     const float alpha = stat[O + c] * gamma[c];
     const float b2 = beta[c] - stat[c] * alpha;
     const float y = z[t] * alpha + b2;
+    a[t] = relu ? fmaxf(y, 0.f) : y;
+}
+
+// Train-mode BatchNorm forward behind the two column passes, in ONE launch (round 5; O <= 256): every block derives mean / invstd of the
+// columns from the sums (tr_bn_mean_kernel's and tr_bn_var_kernel's expressions: same bits) into LDS and normalises its 256 elements; block
+// 0 also stores them in `stat` (the backward reads them there) and updates the running buffers as torch.nn.BatchNorm1d does.
+// sums[0 .. O) = sum z, sums[O .. 2 O) = sum (z - mean)^2.
+__global__ __launch_bounds__(256) void tr_bn_apply_fused_kernel(const float* z, const double* __restrict__ sums, float* __restrict__ stat,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                                float* a, long long M, int O, int relu) {
+    __shared__ float s_alpha[256], s_b2[256];
+    const int tid = threadIdx.x;
+    if (tid < O) {
+        const float mean = (float)(sums[tid] / (double)M);
+        const double var = sums[O + tid] / (double)M;
+        const float invstd = (float)(1.0 / sqrt(var + (double)kBnEps));
+        const float alpha = invstd * gamma[tid];
+        s_alpha[tid] = alpha;
+        s_b2[tid] = beta[tid] - mean * alpha;
+        if (blockIdx.x == 0) {
+            stat[tid] = mean;
+            stat[O + tid] = invstd;
+            const double unb = M > 1 ? sums[O + tid] / (double)(M - 1) : var;
+            running_mean[tid] = (float)((double)kBnMomentum * (double)mean + (1.0 - (double)kBnMomentum) * (double)running_mean[tid]);
+            running_var[tid] = (float)((double)kBnMomentum * unb + (1.0 - (double)kBnMomentum) * (double)running_var[tid]);
+        }
+    }
+    __syncthreads();
+    const long long t = (long long)blockIdx.x * 256 + tid;
+    if (t >= M * O) return;
+    const int c = (int)(t % O);
+    const float y = z[t] * s_alpha[c] + s_b2[c];
     a[t] = relu ? fmaxf(y, 0.f) : y;
 }
 
@@ -380,19 +414,25 @@ struct TrCtx {
     }
 };
 
-static int tr_col_reduce(const TrCtx& c, const float* A, const float* Z, const float* stat, long long M, int O, int mode) {
+// `second_pass` (mode 1 only): the squared deviations go to sums[O .. 2 O) next to the first pass's column sums, which stay (no memset) and
+// supply the mean -- the fused train-mode BatchNorm forward reads both
+static int tr_col_reduce(const TrCtx& c, const float* A, const float* Z, const float* stat, long long M, int O, int mode, bool second_pass = false) {
     double* sums = reinterpret_cast<double*>(c.base + c.P->dsum);
-    HIP_TRY(hipMemsetAsync(sums, 0, 2 * (size_t)O * 8, c.st));
+    const double* mean_sums = second_pass ? sums : nullptr;
+    if (second_pass)
+        sums += O;
+    else
+        HIP_TRY(hipMemsetAsync(sums, 0, 2 * (size_t)O * 8, c.st));
     if (O <= 256) {
         const int RB = 256 / O;
         long long rows = (M + 1023) / 1024;                       // aim at ~1024 blocks ...
         rows = std::max<long long>((rows + 8LL * RB - 1) / (8LL * RB) * (8LL * RB), 8LL * RB);   // ... of whole rounds of 8 passes
         hipLaunchKernelGGL(tr_col_reduce_narrow_kernel, dim3((unsigned)((M + rows - 1) / rows)), dim3(256), 0, c.st, A, Z, stat, M, O,
-                           (int)rows, sums, mode);
+                           (int)rows, sums, mode, mean_sums);
     } else {
         const int rows = 1024;
         hipLaunchKernelGGL(tr_col_reduce_kernel, dim3((unsigned)((O + 63) / 64), (unsigned)((M + rows - 1) / rows)), dim3(256), 0, c.st, A, Z,
-                           stat, M, O, rows, sums, mode);
+                           stat, M, O, rows, sums, mode, mean_sums);
     }
     HIP_TRY(hipGetLastError());
     return GNNCCA_OK;
@@ -424,14 +464,24 @@ static int tr_mlp_forward(const TrCtx& c, const TrCall& call, const float* xin, 
                 const double* sums = reinterpret_cast<const double*>(c.base + c.P->dsum);
                 int s = tr_col_reduce(c, nullptr, dst, nullptr, M, O, 0);
                 if (s != GNNCCA_OK) return s;
-                hipLaunchKernelGGL(tr_bn_mean_kernel, dim3((O + 255) / 256), dim3(256), 0, c.st, sums, M, O, stat);
-                s = tr_col_reduce(c, nullptr, dst, stat, M, O, 1);
-                if (s != GNNCCA_OK) return s;
-                hipLaunchKernelGGL(tr_bn_var_kernel, dim3((O + 255) / 256), dim3(256), 0, c.st, sums, M, O, stat, c.params[pi + 4],
-                                   c.params[pi + 5]);
-                hipLaunchKernelGGL(tr_bn_apply_kernel, grid1((size_t)M * O, 256), dim3(256), 0, c.st, (const float*)dst,
-                                   (const float*)stat, (const float*)c.params[pi + 2], (const float*)c.params[pi + 3],
-                                   c.at(call.lay[l].a), M, O, (int)L.relu);
+                if (O <= 256) {
+                    // round 5: 8 -> 5 operations per train-mode BatchNorm layer (the mean and the variance no longer have kernels of their own;
+                    // one memset for both passes' sums; the statistics, the running buffers and the normalisation in one launch) -- same bits
+                    s = tr_col_reduce(c, nullptr, dst, nullptr, M, O, 1, true);
+                    if (s != GNNCCA_OK) return s;
+                    hipLaunchKernelGGL(tr_bn_apply_fused_kernel, grid1((size_t)M * O, 256), dim3(256), 0, c.st, (const float*)dst, sums, stat,
+                                       (const float*)c.params[pi + 2], (const float*)c.params[pi + 3], c.params[pi + 4], c.params[pi + 5],
+                                       c.at(call.lay[l].a), M, O, (int)L.relu);
+                } else {
+                    hipLaunchKernelGGL(tr_bn_mean_kernel, dim3((O + 255) / 256), dim3(256), 0, c.st, sums, M, O, stat);
+                    s = tr_col_reduce(c, nullptr, dst, stat, M, O, 1);
+                    if (s != GNNCCA_OK) return s;
+                    hipLaunchKernelGGL(tr_bn_var_kernel, dim3((O + 255) / 256), dim3(256), 0, c.st, sums, M, O, stat, c.params[pi + 4],
+                                       c.params[pi + 5]);
+                    hipLaunchKernelGGL(tr_bn_apply_kernel, grid1((size_t)M * O, 256), dim3(256), 0, c.st, (const float*)dst,
+                                       (const float*)stat, (const float*)c.params[pi + 2], (const float*)c.params[pi + 3],
+                                       c.at(call.lay[l].a), M, O, (int)L.relu);
+                }
                 HIP_TRY(hipGetLastError());
             }
             if (L.relu && p > 0.f) {
