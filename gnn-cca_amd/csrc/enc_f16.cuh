@@ -3,7 +3,8 @@
 namespace gnncca {
 
 // ------------------------------------------------------------------------------------------------------------
-// First encoder layer on big batches, round 5: the "fp16-split" GEMM  out = x . W^T  (N >= 6144 nodes, K = in, O = 128).
+// First encoder layer on big batches, round 5: the "fp16-split" GEMM  out = x . W^T  (K = in, O = 128; this kernel from 8193 nodes on, the
+// 32-row kernel at the end of the file for 4096 ... 8192).
 // Replaces the first nn.Linear of encoder.node_mlp (models/mpn.py:131 <- models/mlp.py:13) and, un-split (FUSE), the rest of the encoder.
 //
 // ARITHMETIC.  x = x0 + x1 / 2048 and w = w0 + w1 / 2048 with fp16 pieces: x0 = fp16(x), x1 = fp16((x - x0) * 2048) -- the residual is exact
@@ -21,8 +22,10 @@ namespace gnncca {
 // lines, no VGPR staging, no ds_write) into its own three-slot ring of raw fp32, two chunks ahead, and needs NO barrier for it -- only its
 // own counted vmcnt.  The A fragments are read back as fp32 (lane (r, h): 32 B of row r per 16-deep k-step, granules XOR-swizzled on the
 // SOURCE address so that ds_read_b128 is conflict-free) and split into the two fp16 pieces in registers: each element is converted once.
-// W (pre-split at pack time, BlobHeader::enc_w2h: the LDS image chunk by chunk) goes through a shared three-slot ring the same way, ONE
-// workgroup barrier per 32-deep chunk.  LDS traffic per chunk and CU: 48 KB written by DMA + 160 KB of fragment reads, against 72 KB of
+// W (pre-split at pack time, BlobHeader::enc_w2h: fragment-major, a 16 KB image per 32-deep chunk) goes through a shared three-slot ring the
+// same way, ONE workgroup barrier per 32-deep chunk; a chunk's six DMA instructions per wave are issued one at a time between the MFMA groups
+// of the chunk before (a burst after the barrier stalled half the waves in ISSUE for 1 700 cycles per chunk); from 128 MB of x on the x
+// requests carry the non-temporal policy (mpn_forward.hip).  LDS traffic per chunk and CU: 48 KB written by DMA + 160 KB of fragment reads, against 72 KB of
 // ds_write + 192 KB of reads in the 256-row bf16 kernel (encoder.cuh), and no conversion-store pass.
 // (Option, off by default: workgroup b walks its k chunks from chunk (37 b) mod nk on -- see enc_gemm_split_lds_kernel and mpn_forward.hip.)
 // LDS: x rings 8 x 3 x 4 KB + W ring 3 x 16 KB = 144 KB (= kLdsGemmBytes); the fused epilogue reuses it.
