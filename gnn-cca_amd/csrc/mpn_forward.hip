@@ -587,6 +587,8 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
         const double state_bytes = (double)(sp.e_bf16 ? kEF / 2 : kEF) * (double)ws.e_stride * 4.0;
         sp.nt_store = !no_nt && state_bytes > 150e6;
         sp.nt_load = !no_nt && state_bytes > 256e6;
+        static const int force_nt = diag_env_int("GNNCCA_STEP_NT", -1, -1, 2);   // diagnostics: 0 / 1 / 2 = default policy / nt stores / nt loads too
+        if (force_nt >= 0) sp.nt_store = force_nt >= 1, sp.nt_load = force_nt >= 2;
     }
     const bool re = d->reattach_edges != 0;
     int out_idx = 0;
