@@ -123,8 +123,12 @@ __device__ __forceinline__ void enc_finish_tile_rows(float* H1, int wave, int l3
 // loop -- x straight from global memory into three bf16 fragments, the chunk's W pieces through two LDS stages, one barrier per chunk) in
 // this kernel's tiling (wave = 32 rows x 128 columns).  Rare by construction; written for correctness, not speed.
 // `active`: false for waves beyond the eight that compute (the 32-row kernel's loader waves): they only keep the barriers company.
-__device__ __forceinline__ void enc_f16_bf16_arm(f32x16 (&acc)[4], const float* __restrict__ x, const unsigned short* __restrict__ w3, int M, int K,
-                                                 int row0w, int kbeg, int nk, unsigned char* lds_raw, bool active = true) {
+// NC / cbeg: the wave computes the NC 32-column tiles from tile cbeg on (the 32-row kernel takes its tile in two halves: with all four
+// accumulator tiles next to that kernel's prefetched epilogue operands the arm spilled registers -- and a kernel with ANY scratch starts
+// its waves more slowly, arm or no arm).
+template <int NC = 4>
+__device__ __forceinline__ void enc_f16_bf16_arm(f32x16 (&acc)[NC], const float* __restrict__ x, const unsigned short* __restrict__ w3, int M, int K,
+                                                 int row0w, int kbeg, int nk, unsigned char* lds_raw, bool active = true, int cbeg = 0) {
     constexpr int BN = 128, BK = 32, LDK = 40;
     typedef __bf16 (*wsm_t)[3][BN][LDK];
     wsm_t wsm = reinterpret_cast<wsm_t>(lds_raw);   // [2][3][128][40] bf16 = 61 440 B
@@ -168,7 +172,7 @@ __device__ __forceinline__ void enc_f16_bf16_arm(f32x16 (&acc)[4], const float* 
             for (int u = 0; u < 3; ++u) *reinterpret_cast<bf16x8*>(&wsm[stage][wp[u]][wcol[u]][wk[u]]) = wreg[u];
     };
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
+    for (int c = 0; c < NC; ++c)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[c][i] = 0.f;
     load_next(0);
@@ -181,10 +185,10 @@ __device__ __forceinline__ void enc_f16_bf16_arm(f32x16 (&acc)[4], const float* 
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
+            for (int c = 0; c < NC; ++c) {
                 bf16x8 b[3];
 #pragma unroll
-                for (int p = 0; p < 3; ++p) b[p] = *reinterpret_cast<const bf16x8*>(&wsm[stage][p][c * 32 + (lane & 31)][ks * 16 + 8 * h]);
+                for (int p = 0; p < 3; ++p) b[p] = *reinterpret_cast<const bf16x8*>(&wsm[stage][p][(cbeg + c) * 32 + (lane & 31)][ks * 16 + 8 * h]);
                 acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[ks][2], b[0], acc[c], 0, 0, 0);   // smallest terms first
                 acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[ks][1], b[1], acc[c], 0, 0, 0);
                 acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[ks][0], b[2], acc[c], 0, 0, 0);
@@ -578,9 +582,9 @@ __global__ __launch_bounds__(kF16R32Threads) void enc_gemm_f16_rows32_kernel(con
     // (stamps: the epilogue took 8 800 cycles per wave, most of it three dependent L2 latencies)
     float w2v[16], pjv[16];
     float bias2_pre = 0.f, pb_pre = 0.f;
-    {
+    auto request_epilogue_operands = [&](const float* __restrict__ W2, const float* __restrict__ projwT) {
         const int q = wave & 3;
-        const float* w2row = fp.W2 + (size_t)l32 * 128 + 32 * q + 16 * h;
+        const float* w2row = W2 + (size_t)l32 * 128 + 32 * q + 16 * h;
         const int slot = 32 * (wave & 1) + l32;
         const bool on = slot < kProjOut;
 #pragma unroll
@@ -590,10 +594,11 @@ __global__ __launch_bounds__(kF16R32Threads) void enc_gemm_f16_rows32_kernel(con
             for (int t = 0; t < 4; ++t) w2v[4 * j + t] = b4[t];
         }
 #pragma unroll
-        for (int sI = 0; sI < 16; ++sI) pjv[sI] = (wave < 2 && on) ? fp.projwT[(16 * h + sI) * kProjOut + slot] : 0.f;
+        for (int sI = 0; sI < 16; ++sI) pjv[sI] = (wave < 2 && on) ? projwT[(16 * h + sI) * kProjOut + slot] : 0.f;
         if (wave == 0) bias2_pre = fp.b2[l32];
         if (wave < 2 && on) pb_pre = fp.projb[slot];
-    }
+    };
+    request_epilogue_operands(fp.W2, fp.projwT);
     // ---- the four k-quarters' partial tiles go to LDS at once (the accumulators die here: the bf16 arm below needs the registers), then:
     //      bf16 arm?  (workgroup-uniform) ----------------------------------------------------------------------------------------------
     __syncthreads();                                              // every wave is done with the rings
@@ -621,18 +626,20 @@ __global__ __launch_bounds__(kF16R32Threads) void enc_gemm_f16_rows32_kernel(con
         __syncthreads();                                          // (the arm's W stages overwrite the partials)
         // every compute wave recomputes the SAME 32 x 128 tile over all of K on the bf16 arm (its W staging wants all 512 compute threads;
         // rare by construction); wave 0's copy is the tile.  (The arm's stages end below H1.)
-        f32x16 full[4];
-        enc_f16_bf16_arm(full, p.x, p.w3, M, K, row0, 0, K / BK, lds_raw, !loader);
-        if (wave == 0) {
+        for (int cb = 0; cb < 4; cb += 2) {                       // (two column halves: see enc_f16_bf16_arm on NC)
+            f32x16 part[2];
+            enc_f16_bf16_arm<2>(part, p.x, p.w3, M, K, row0, 0, K / BK, lds_raw, !loader, cb);
+            if (wave == 0) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int col = c * 32 + l32;
-                const float bias = fp.b1[col];
+                for (int c = 0; c < 2; ++c) {
+                    const int col = (cb + c) * 32 + l32;
+                    const float bias = fp.b1[col];
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int rl = (i & 3) + 8 * (i >> 2) + 4 * h;
-                    const float v = full[c][i] + bias;
-                    H1[rl * LD1 + col] = fp.relu_prev ? fmaxf(v, 0.f) : v;
+                    for (int i = 0; i < 16; ++i) {
+                        const int rl = (i & 3) + 8 * (i >> 2) + 4 * h;
+                        const float v = part[c][i] + bias;
+                        H1[rl * LD1 + col] = fp.relu_prev ? fmaxf(v, 0.f) : v;
+                    }
                 }
             }
         }

@@ -39,9 +39,10 @@ __global__ __launch_bounds__(256) GNNCCA_FAST_ATTR void mpn_step_fast_kernel(con
     // ---- prologue: every independent load is issued before the first wait ----------------------------------
     const unsigned gflags = p.flags[0];
     const unsigned rbad = p.flags[1];
-    const int wps = p.wps;
-    const int node = blockIdx.x * (4 / wps) + wave / wps;
-    const int sub = wave % wps;
+    const int wps = p.wps;         // 1, 2 or 4 (mpn_forward.hip): shifts, not the 40-instruction software division of round 1-4
+    const int wl = wps >> 1;       // log2(wps)
+    const int node = (int)(blockIdx.x << (2 - wl)) + (wave >> wl);
+    const int sub = wave & (wps - 1);
     const bool active = node < p.N;
     const int nclamp = active ? node : 0;
     int seg_s = p.seg_ptr[nclamp];
@@ -54,32 +55,39 @@ __global__ __launch_bounds__(256) GNNCCA_FAST_ATTR void mpn_step_fast_kernel(con
         const i32x4 r = reinterpret_cast<const i32x4*>(p.rng)[nclamp];
         rs1 = r[0], rl1 = r[1], rd2 = r[2];
     }
+    // ONE scalar round trip for the flags, the CSR offsets and the column ranges: without this pin the compiler hoists the BAD_INDEX test
+    // (a wait for the flags alone) above the other scalar loads and the launch starts with two dependent L2 round trips instead of one.
+    asm volatile("" ::"s"(gflags), "s"(rbad), "s"(seg_s), "s"(seg_t), "s"(rs1), "s"(rl1), "s"(rd2));
     const int nmax = p.N - 1;
     const int half = lane >> 5, ch = lane & 31;
     const float* __restrict__ psq = p.psq_in + (size_t)nclamp * kPsQStride;
     float psrc[kEF];
-#pragma unroll
-    for (int f = 0; f < kEF; ++f) psrc[f] = psq[f];
     float cinit = 0.f;
     float bw[3] = {0.f, 0.f, 0.f};
     f32x4 stage_proj[2];
     f32x4 stage_pd[8];
     float projb_l = 0.f;
-    if (MSG) {
-        cinit = psq[8 + ch];
-        projb_l = blob[p.off_projb + min(lane, kProjOut - 1)];
-#pragma unroll
-        for (int s = 0; s < 3; ++s) bw[s] = blob[p.off_wneb + s * 64 + lane];
-        const f32x4* __restrict__ g4 = reinterpret_cast<const f32x4*>(blob + p.off_projwT);
-        stage_proj[0] = g4[tid];                                   // 384 float4 in all
-        stage_proj[1] = g4[min(tid + 256, kH * kProjOut / 4 - 1)];
-    }
     const int pd_n4 = p.N * (kPdStride / 4);
-    if (PD_LDS) {  // N <= 1024: at most 8 float4 per thread
-        const f32x4* __restrict__ g4 = reinterpret_cast<const f32x4*>(p.pd_in);
+    // The node's own operands, the weights and the tables staged through LDS.  Requested AFTER the first round's target ids (below): a
+    // wave's loads return in order, so what is waited for first -- the ids, which the P_dst gather's addresses need -- is asked for first.
+    auto request_node_operands = [&]() {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) stage_pd[i] = g4[min(tid + i * 256, pd_n4 - 1)];
-    }
+        for (int f = 0; f < kEF; ++f) psrc[f] = psq[f];
+        if (MSG) {
+            cinit = psq[8 + ch];
+            projb_l = blob[p.off_projb + min(lane, kProjOut - 1)];
+#pragma unroll
+            for (int s = 0; s < 3; ++s) bw[s] = blob[p.off_wneb + s * 64 + lane];
+            const f32x4* __restrict__ g4 = reinterpret_cast<const f32x4*>(blob + p.off_projwT);
+            stage_proj[0] = g4[tid];                                   // 384 float4 in all
+            stage_proj[1] = g4[min(tid + 256, kH * kProjOut / 4 - 1)];
+        }
+        if (PD_LDS) {  // N <= 1024: at most 8 float4 per thread
+            const f32x4* __restrict__ g4 = reinterpret_cast<const f32x4*>(p.pd_in);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) stage_pd[i] = g4[min(tid + i * 256, pd_n4 - 1)];
+        }
+    };
     if (gflags & GNNCCA_GRAPH_BAD_INDEX) {
         if (CLS)
             for (size_t k = (size_t)blockIdx.x * 256 + tid; k < (size_t)p.E; k += (size_t)gridDim.x * 256)
@@ -118,13 +126,21 @@ __global__ __launch_bounds__(256) GNNCCA_FAST_ATTR void mpn_step_fast_kernel(con
     auto load_index = [&](int base, Chunk& c) {
         const int kk = max(min(base + lane, last), 0);   // (an empty segment: slot 0, never used)
         c.ko = unsorted ? p.perm[kk] : kk;
-        if (use_range) {   // kernel-uniform: the node's columns are <= 2 contiguous runs -- the id is computed, no load, no round trip
+        // kernel-uniform choice.  use_range: the node's columns are <= 2 contiguous runs -- the id is computed, no load, no round trip.
+        // The arithmetic comes FIRST and unconditionally, the load overwrites it: written as if / else the compiler puts the load arm first
+        // and, the two arms sharing the destination register, guards the computed arm with s_waitcnt vmcnt(0) -- a full round trip for
+        // every load of the prologue before the edge state is even requested (rounds 3-5 until this was seen in the listing).
+        int cj = 0;
+        if (!FIRST) {
             const int q = kk - seg_s;
-            c.j = max(min(q + (q < rl1 ? rs1 : rd2), nmax), 0);   // (clamped: lanes of an empty segment gather a real row, never used)
-        } else {
-            c.j = p.col32[kk];
+            cj = max(min(q + (q < rl1 ? rs1 : rd2), nmax), 0);   // (clamped: lanes of an empty segment gather a real row, never used)
+            asm volatile("" : "+v"(cj));                           // (pins the arithmetic above the branch)
+        }
+        if (!use_range) {
+            cj = p.col32[kk];
             if (DERIVE) c.jp = p.col32[max(kk - 1, 0)];   // same lines: an L1 hit
         }
+        c.j = cj;
     };
     // Step 1 derives each node's column ranges from the target ids it has loaded anyway: a break is an edge whose target is not its
     // predecessor's + 1.  Wave-uniform bookkeeping on the scalar unit.
@@ -303,8 +319,18 @@ __global__ __launch_bounds__(256) GNNCCA_FAST_ATTR void mpn_step_fast_kernel(con
     Chunk c0, c1;
     load_index(base, c0);
     load_index(base + stride, c1);
+    __builtin_amdgcn_sched_barrier(0);   // (the scheduler would cluster these loads in its own order)
+    request_node_operands();
+    __builtin_amdgcn_sched_barrier(0);
     load_state(base, c0);
     load_state(base + stride, c1);
+    // the first round's P_dst gathers go out before the staging stores too (not when they read the LDS table): with computed target ids
+    // they need no wait at all, and the staging wait -- a full round trip for the first loads of the launch -- runs under them
+    __builtin_amdgcn_sched_barrier(0);   // (and would put the gathers' address arithmetic -- a wait for the ids -- ahead of the state requests)
+    if (!PD_LDS) {
+        load_target(c0);
+        load_target(c1);
+    }
     if (MSG) {
         f32x4* l4 = reinterpret_cast<f32x4*>(s_proj);
         l4[tid] = stage_proj[0];
@@ -324,9 +350,11 @@ __global__ __launch_bounds__(256) GNNCCA_FAST_ATTR void mpn_step_fast_kernel(con
     // this into a silent race: GNNCCA_STEP_EARLYBAR (diag bit 3) restores the early barrier to bisect such a change.
     if (PD_LDS || (MSG && (wps == 1 || (p.diag & 8)))) __syncthreads();   // (diag bit 3: A/B with the early barrier of rounds 1-2)
     GNNCCA_STAMP(p.stamp_slot, 2);
-    auto round_body = [&](int rb, Chunk& a, Chunk& b) {
-        load_target(a);
-        load_target(b);
+    auto round_body = [&](int rb, Chunk& a, Chunk& b, bool requested = false) {
+        if (!requested) {
+            load_target(a);
+            load_target(b);
+        }
         if (DERIVE && p.rng != nullptr) {
             derive(rb, a);
             if (rb + stride < seg_t) derive(rb + stride, b);
@@ -346,7 +374,7 @@ __global__ __launch_bounds__(256) GNNCCA_FAST_ATTR void mpn_step_fast_kernel(con
             load_index(base2, d0);
             load_index(base2 + stride, d1);
         }
-        round_body(base, c0, c1);
+        round_body(base, c0, c1, !PD_LDS);
         if (base2 < seg_t) {
             if (PD_LDS) {
                 load_index(base2, d0);

@@ -84,9 +84,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MSG ? (NPW 
     // ---- prologue: every independent load is issued before the first wait ----------------------------------
     const unsigned gflags = p.flags[0];
     const unsigned rbad = p.flags[1];
-    const int wps = NPW == 2 ? 1 : p.wps;
-    int node = NPW == 2 ? (blockIdx.x * 4 + wave) * 2 : blockIdx.x * (4 / wps) + wave / wps;
-    const int sub = NPW == 2 ? 0 : wave % wps;
+    const int wps = NPW == 2 ? 1 : p.wps;   // 1, 2 or 4 (mpn_forward.hip): shifts, not a software division
+    const int wl = wps >> 1;                // log2(wps)
+    int node = NPW == 2 ? (blockIdx.x * 4 + wave) * 2 : (int)(blockIdx.x << (2 - wl)) + (wave >> wl);
+    const int sub = NPW == 2 ? 0 : wave & (wps - 1);
     bool active = node < p.N;
     int nclamp = active ? node : 0;
     int seg_s = p.seg_ptr[nclamp];
@@ -102,32 +103,40 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MSG ? (NPW 
         const i32x4 r = reinterpret_cast<const i32x4*>(p.rng)[nclamp];
         rbk = seg_s + r[1], rA = r[0] - seg_s, rB = r[2] - seg_s;
     }
+    // ONE scalar round trip for the flags, the CSR offsets and the column ranges (see mpn_step_fast_kernel)
+    if (NPW == 1) asm volatile("" ::"s"(gflags), "s"(rbad), "s"(seg_s), "s"(seg_t), "s"(rbk), "s"(rA), "s"(rB));
     const int ch = lane & 31;
     const float* __restrict__ psq = p.psq_in + (size_t)nclamp * kPsQStride;
     float psrc[kEF];
-#pragma unroll
-    for (int f = 0; f < kEF; ++f) psrc[f] = psq[f];
     MsgB mb;                // B operands of the message MFMAs (msg_bf16.cuh)
     float cinit = 0.f;
     float cinit2 = 0.f;     // NPW == 2: Q[node + 1][ch]
-    if (NPW == 2) cinit2 = p.psq_in[(size_t)(active2 ? node + 1 : 0) * kPsQStride + 8 + ch];
     f32x4 stage_proj[2];
     f32x4 stage_pd[8];
     float projb_l = 0.f;
+    const int pd_n4 = p.N * (kPdStride / 4);
+    // requested AFTER the first round's target ids (see mpn_step_fast_kernel: loads return in order, the ids are waited for first)
+    auto request_node_operands = [&]() {
+#pragma unroll
+    for (int f = 0; f < kEF; ++f) psrc[f] = psq[f];
+    if (NPW == 2) cinit2 = p.psq_in[(size_t)(active2 ? node + 1 : 0) * kPsQStride + 8 + ch];
     if (MSG) {
         cinit = psq[8 + ch];
         projb_l = blob[p.off_projb + min(lane, kProjOut - 1)];
         msg_b_weights(blob + p.off_wnebf, lane, mb);
         const f32x4* __restrict__ g4 = reinterpret_cast<const f32x4*>(blob + p.off_projwT);
-        stage_proj[0] = g4[tid];                                   // 384 float4 in all
-        stage_proj[1] = g4[min(tid + 256, kH * kProjOut / 4 - 1)];
+        // 384 float4 in all.  The second request and its store are UNCONDITIONAL (threads 128 ... 255 repeat their first float4): under
+        // `if (tid + 256 < 384)` the compiler sinks the load into the branch, next to its store, behind s_waitcnt vmcnt(0) -- a round trip
+        // for every load of the prologue, in waves 0-1, which the other waves then sit out at the barrier
+        stage_proj[0] = g4[tid];
+        stage_proj[1] = g4[tid + 256 < kH * kProjOut / 4 ? tid + 256 : tid];
     }
-    const int pd_n4 = p.N * (kPdStride / 4);
     if (PD_LDS) {  // N <= 1024: at most 8 float4 per thread
         const f32x4* __restrict__ g4 = reinterpret_cast<const f32x4*>(p.pd_in);
 #pragma unroll
         for (int i = 0; i < 8; ++i) stage_pd[i] = g4[min(tid + i * 256, pd_n4 - 1)];
     }
+    };
     if (gflags & GNNCCA_GRAPH_BAD_INDEX) {
         if (CLS || CIN)
             for (size_t k = (size_t)blockIdx.x * 256 + tid; k < (size_t)p.E; k += (size_t)gridDim.x * 256) {
@@ -139,7 +148,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MSG ? (NPW 
     const bool unsorted = (gflags & GNNCCA_GRAPH_UNSORTED) != 0;
     if (!active) seg_s = seg_t = 0;
     if (NPW == 2 && !active2) seg_t2 = seg_t;   // (no second node: an empty segment)
-    if (MSG) msg_b_bias(cinit, lane, mb);
     // padded layout: see mpn_step_fast_kernel
     const bool padded = p.ell_S > 0 && !(gflags & (GNNCCA_GRAPH_UNSORTED | GNNCCA_GRAPH_IRREGULAR));
     int eoff = padded ? nclamp * p.ell_S - seg_s : 0;
@@ -168,14 +176,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MSG ? (NPW 
     const int stride = 64 * wps;
     int base = seg_s + 64 * sub;
     Chunk c0, c1;
+    // (register budget: the two-node forms sit at 126-128 VGPRs and spill with the ids requested first -- they keep the order of round 4)
+    constexpr bool IDS_FIRST = NPW == 1;
+    if (!IDS_FIRST) {
+        request_node_operands();
+        if (MSG) msg_b_bias(cinit, lane, mb);
+    }
     load_index(base, c0);
     load_index(base + stride, c1);
+    if (IDS_FIRST) {
+        GNNCCA_SB();   // (the scheduler would cluster these loads in its own order)
+        request_node_operands();
+        GNNCCA_SB();
+    }
     load_state(base, c0);
     load_state(base + stride, c1);
+    if (IDS_FIRST) GNNCCA_SB();   // (and would put the gathers' address arithmetic -- a wait for the ids -- ahead of the state requests)
+    // the first round's P_dst gathers go out before the staging stores and the barrier (not when they read the LDS table): the barrier's
+    // skew runs under their round trip instead of ahead of it
+    // (register budget: the two-node forms and step 1 classifying sit at 126-128 VGPRs and would spill -- they keep the old order)
+    constexpr bool PRE_GATHER = !PD_LDS && NPW == 1 && !(FIRST && CLS);
+    if (PRE_GATHER) {
+        load_target(c0);
+        load_target(c1);
+    }
     if (MSG) {
         f32x4* l4 = reinterpret_cast<f32x4*>(s_proj);
         l4[tid] = stage_proj[0];
-        if (tid + 256 < kH * kProjOut / 4) l4[tid + 256] = stage_proj[1];
+        l4[tid + 256 < kH * kProjOut / 4 ? tid + 256 : tid] = stage_proj[1];
     }
     if (PD_LDS) {
         f32x4* l4 = reinterpret_cast<f32x4*>(s_pd);
@@ -184,6 +212,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MSG ? (NPW 
             if (tid + i * 256 < pd_n4) l4[tid + i * 256] = stage_pd[i];
         if (tid < kPdStride / 4) l4[pd_n4 + tid] = f32x4{0.f, 0.f, 0.f, 0.f};   // row N: what a lane beyond its segment gathers
     }
+    if (MSG && IDS_FIRST) msg_b_bias(cinit, lane, mb);
     GNNCCA_STAMP(p.stamp_slot, 1);
     // INVARIANT (shared with mpn_step_fast_kernel): between the staging stores above and the combine's __syncthreads() below NOTHING reads
     // s_proj or s_part, and no wave returns or skips that barrier (the BAD_INDEX return above is block-uniform and precedes the stores).
@@ -200,9 +229,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MSG ? (NPW 
             compute1(rb, a);
         }
     };
-    auto round_body = [&](int rb, Chunk& a, Chunk& b, int sid, int sland, int sdone) {
-        load_target(a);
-        load_target(b);
+    auto round_body = [&](int rb, Chunk& a, Chunk& b, int sid, int sland, int sdone, bool requested = false) {
+        if (!requested) {
+            load_target(a);
+            load_target(b);
+        }
         if (DERIVE) {
             derive(rb, a);
             if (rb + stride < seg_t) derive(rb + stride, b);
@@ -301,7 +332,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MSG ? (NPW 
             // 36 B of scratch at four waves per SIMD, and a kernel with ANY scratch starts its waves far more slowly; it requests the state
             // after the hand-over, with the gather: one exposed round trip instead of three, 127 VGPRs)
             if (!CIN) hook_base = seg_t, hook_end = seg_t2, hook_eoff = eoff2;
-            round_body(base, c0, c1, 3, 15, 4);
+            round_body(base, c0, c1, 3, 15, 4, PRE_GATHER);
             // the second node's gather: before the first node's epilogue where the registers allow it (12 more across the epilogue)
             if (!CLS && !CIN) {
                 load_target(n0);
@@ -326,7 +357,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MSG ? (NPW 
                 load_index(base2 + stride, n1);
                 if (use_hook) hook_base = base2, hook_end = seg_t, hook_eoff = eoff;
             }
-            round_body(base, c0, c1, 3, 15, 4);
+            round_body(base, c0, c1, 3, 15, 4, PRE_GATHER);
             if (base2 < seg_t) {
                 if (PD_LDS) {
                     load_index(base2, n0);
