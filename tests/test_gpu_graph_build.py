@@ -83,7 +83,11 @@ def test_end_to_end_into_mpn():
         assert np.abs(o.cpu().numpy() - r).max() <= 1e-5
 
 
-@pytest.mark.parametrize("rows,cols,cols2", [(1229, 2048, 256), (37, 512, 0), (4096, 130, 7), (1, 5, 3), (65, 33, 2048)])
+# (rows <= 2304 with 16-byte aligned matrices of widths % 4 == 0: the LDS-resident kernel; 2304 / 2305 straddle its limit, 20 / 12 / 2052 leave a
+#  workgroup's last column groups empty, 1 / 15 / 17 rows the DMA's 16-row groups)
+@pytest.mark.parametrize("rows,cols,cols2", [(1229, 2048, 256), (37, 512, 0), (4096, 130, 7), (1, 5, 3), (65, 33, 2048), (2304, 2048, 256),
+                                             (2305, 2048, 256), (63, 20, 12), (1100, 2052, 0), (1, 2048, 256), (15, 64, 16), (17, 64, 4),
+                                             (129, 256, 0)])
 def test_one_launch_normalisation_is_bitwise_the_three_kernel_form(rows, cols, cols2):
     """gnncca_normalize_columns2 (one launch, up to two matrices: what build_graph_batch uses for batches of <= 4096 detections) against
     gnncca_normalize_columns (three launches, any size) on the same matrices: the same bits, and the oracle within rounding."""
