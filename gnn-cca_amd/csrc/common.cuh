@@ -114,6 +114,25 @@ static int prof_end(Profiler* p, hipStream_t st) {
         if (_s != GNNCCA_OK) return _s;                  \
     } while (0)
 
+// One scalar load per 64-byte line of the kernel-argument segment, all in flight behind the kernel's FIRST scalar wait.  The compiler fetches
+// kernel arguments lazily, cluster by cluster, each right before its first use; the scalar cache is cold at a launch's start, so every cluster
+// on a new line is an L2 round trip of its own -- four or five of them, one after the other, between a wave's start and its first vector
+// load in the latency-bound step kernels.  Touched up front the lines arrive together and the later fetches hit the scalar cache.
+// (A value, not a statement: the caller hands it to the asm that pins its first round of scalar loads -- an `asm volatile` AHEAD of those
+// loads would make the compiler treat the memory behind them as clobbered and turn them into vector loads.)
+__device__ __forceinline__ int touch_kernargs(unsigned bytes) {
+    typedef const int __attribute__((address_space(4))) cint;
+    cint* ka = (cint*)__builtin_amdgcn_kernarg_segment_ptr();
+    int t = 0;
+    if (bytes > 64) t |= ka[16];
+    if (bytes > 128) t |= ka[32];
+    if (bytes > 192) t |= ka[48];
+    if (bytes > 256) t |= ka[64];
+    if (bytes > 320) t |= ka[80];
+    if (bytes > 384) t |= ka[96];
+    return t;
+}
+
 // Kernel launch of the forward path: plain, or with the profiler's events attached to this very dispatch.
 #define GNNCCA_LAUNCH(kernel, grid, block, lds, st, ...)                                                              \
     do {                                                                                                              \

@@ -37,6 +37,7 @@ __global__ __launch_bounds__(256) GNNCCA_FAST_ATTR void mpn_step_fast_kernel(con
 
     GNNCCA_STAMP(p.stamp_slot, 0);
     // ---- prologue: every independent load is issued before the first wait ----------------------------------
+    const int ktouch = touch_kernargs(sizeof(StepParams));
     const unsigned gflags = p.flags[0];
     const unsigned rbad = p.flags[1];
     const int wps = p.wps;         // 1, 2 or 4 (mpn_forward.hip): shifts, not the 40-instruction software division of round 1-4
@@ -57,7 +58,7 @@ __global__ __launch_bounds__(256) GNNCCA_FAST_ATTR void mpn_step_fast_kernel(con
     }
     // ONE scalar round trip for the flags, the CSR offsets and the column ranges: without this pin the compiler hoists the BAD_INDEX test
     // (a wait for the flags alone) above the other scalar loads and the launch starts with two dependent L2 round trips instead of one.
-    asm volatile("" ::"s"(gflags), "s"(rbad), "s"(seg_s), "s"(seg_t), "s"(rs1), "s"(rl1), "s"(rd2));
+    asm volatile("" ::"s"(gflags), "s"(rbad), "s"(seg_s), "s"(seg_t), "s"(rs1), "s"(rl1), "s"(rd2), "s"(ktouch));
     const int nmax = p.N - 1;
     const int half = lane >> 5, ch = lane & 31;
     const float* __restrict__ psq = p.psq_in + (size_t)nclamp * kPsQStride;

@@ -82,6 +82,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MSG ? (NPW 
 
     GNNCCA_STAMP(p.stamp_slot, 0);
     // ---- prologue: every independent load is issued before the first wait ----------------------------------
+    const int ktouch = NPW == 1 ? touch_kernargs(sizeof(StepParams)) : 0;   // (common.cuh; the two-node forms have no SGPRs to spare)
     const unsigned gflags = p.flags[0];
     const unsigned rbad = p.flags[1];
     const int wps = NPW == 2 ? 1 : p.wps;   // 1, 2 or 4 (mpn_forward.hip): shifts, not a software division
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MSG ? (NPW 
         rbk = seg_s + r[1], rA = r[0] - seg_s, rB = r[2] - seg_s;
     }
     // ONE scalar round trip for the flags, the CSR offsets and the column ranges (see mpn_step_fast_kernel)
-    if (NPW == 1) asm volatile("" ::"s"(gflags), "s"(rbad), "s"(seg_s), "s"(seg_t), "s"(rbk), "s"(rA), "s"(rB));
+    if (NPW == 1) asm volatile("" ::"s"(gflags), "s"(rbad), "s"(seg_s), "s"(seg_t), "s"(rbk), "s"(rA), "s"(rB), "s"(ktouch));
     const int ch = lane & 31;
     const float* __restrict__ psq = p.psq_in + (size_t)nclamp * kPsQStride;
     float psrc[kEF];
