@@ -104,6 +104,27 @@ if what == "pd_lds":
         with torch.no_grad():
             out = m(Data(torch.from_numpy(x).cuda(), torch.from_numpy(ei).cuda(), torch.from_numpy(ea).cuda()))["classified_edges"]
         res[f"{g}x{n}"] = [o.cpu().numpy().tolist() for o in out][-1][:2000]
+elif what == "npw":
+    import hashlib
+    # batches of 3000 ... 5000 nodes with <= 2 chunks of 64 edges per node: the shapes the two-nodes-per-wave step kernels accept
+    for seed, (n, g, drop) in enumerate(((100, 36, 0), (120, 30, 7), (90, 50, 3))):
+        params, arch, sd = _default_model(1.0 / (n - 1))
+        rng = np.random.default_rng(100 + seed)
+        parts = []
+        for k in range(g):
+            e = _dense_graph(n, k * n)
+            if drop:                                        # ragged: every drop-th edge removed, one node left without out-edges
+                keep = (np.arange(e.shape[1]) % drop != 0) & (e[0] != k * n + 5)
+                e = e[:, keep]
+            parts.append(e)
+        ei = np.concatenate(parts, axis=1)
+        x = rng.standard_normal((g * n, 2048)).astype(np.float32); x /= np.linalg.norm(x, axis=0, keepdims=True)
+        ea = rng.random((ei.shape[1], 4)).astype(np.float32)
+        m = build(params, arch, sd)
+        with torch.no_grad():
+            out = m(Data(torch.from_numpy(x).cuda(), torch.from_numpy(ei).cuda(), torch.from_numpy(ea).cuda()))["classified_edges"]
+        assert all(np.isfinite(o.cpu().numpy()).all() for o in out)
+        res[f"{g}x{n}/{drop}"] = hashlib.sha256(b"".join(o.cpu().numpy().tobytes() for o in out)).hexdigest()
 else:
     params, arch, sd, a = load_case(os.path.join(sys.argv[1], "tests", "golden", "generic_dims.npz"))
     m = build(params, arch, sd)
@@ -132,6 +153,17 @@ def test_lds_gather_table_variant_gives_the_same_bits():
     assert sorted(base) == sorted(lds)
     for k in base:
         assert base[k] == lds[k], k
+
+
+def test_one_and_two_nodes_per_wave_give_the_same_bits():
+    """The message steps of batches below 16 384 nodes run one node per wave (since round 5 with the ids-first prologue), above that two
+    nodes per wave (round 4's prologue order; GNNCCA_NPW = 2 forces that form wherever it is eligible).  Same arithmetic in the same order per
+    node: the logits of three 3 000 ... 4 500-node batches -- regular and ragged, one node without out-edges -- hash the same either way."""
+    one = _child("npw", {"GNNCCA_DIAG": "1", "GNNCCA_NPW": "1"})
+    two = _child("npw", {"GNNCCA_DIAG": "1", "GNNCCA_NPW": "2"})
+    assert sorted(one) == sorted(two) and len(one) == 3
+    for k in one:
+        assert one[k] == two[k], k
 
 
 def test_generic_op_by_op_path_agrees_with_the_fused_step():
