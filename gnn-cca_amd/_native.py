@@ -6,7 +6,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GNNCCA_LIB") or os.path.join(HERE, "lib", "libgnncca_mpn.so")  # GNNCCA_LIB: diagnostic builds
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_LAYERS = 8
 OK, ERR_INVALID_ARG, ERR_UNSUPPORTED, ERR_WORKSPACE, ERR_HIP, ERR_NO_DEVICE = range(6)
 AGG = {"sum": 0, "mean": 1, "max": 2}
@@ -39,7 +39,7 @@ class FramesIO(C.Structure):
                 ("node_embeds", C.c_void_p), ("reid_embeds", C.c_void_p), ("reid_dim", C.c_int32), ("mode", C.c_int32), ("normalize", C.c_int32),
                 ("node_norm", C.c_void_p), ("reid_norm", C.c_void_p), ("edge_index", C.c_void_p), ("edge_attr", C.c_void_p),
                 ("edge_labels", C.c_void_p), ("logits", C.c_void_p), ("probs", C.c_void_p), ("predictions", C.c_void_p), ("pruned", C.c_void_p),
-                ("counters", C.c_void_p), ("labels", C.c_void_p)]
+                ("counters", C.c_void_p), ("labels", C.c_void_p), ("counters_len", C.c_int64)]
 
 
 class Trace(C.Structure):

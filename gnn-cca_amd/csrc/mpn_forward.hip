@@ -951,6 +951,7 @@ int gnncca_frames_forward(const gnncca_mpn_dims* d, const void* packed_dev, cons
     if (!io->node_embeds || !io->reid_embeds || !io->edge_index || !io->edge_attr || !io->edge_labels || !io->logits || !io->probs ||
         !io->predictions || !io->pruned || !io->counters || !io->labels || (io->normalize && (!io->node_norm || !io->reid_norm)))
         return GNNCCA_ERR_INVALID_ARG;
+    if (io->counters_len < 3 * n + 1 + g) return GNNCCA_ERR_INVALID_ARG;   // flow_out | flow_in | n_clusters | sizes | triggers (ABI 2: stated, not assumed)
     // the staging image (gnncca_plan_frames): f64 xw[n], yw[n], max_dist[g]; i64 ids[n]; i32 person, cam, graph_of, graph_ptr, src_order, edge_ptr, edge_ptr_g
     const char* base = static_cast<const char*>(io->staged_dev);
     gnncca_frames fr;

@@ -158,7 +158,7 @@ class FramePipeline:
             io.edge_attr, io.edge_labels = fp + 4 * o_attr, fp + 4 * o_lab
             io.logits, io.probs = fp + 4 * o_log, fp + 4 * o_prob
             io.edge_index, io.predictions, io.pruned = ip, ip + 8 * o_pred, ip + 8 * o_prun
-            io.counters, io.labels = cp, cp + 4 * o_labels
+            io.counters, io.labels, io.counters_len = cp, cp + 4 * o_labels, o_labels
             st = lib.gnncca_frames_forward(C.byref(d), blob.data_ptr(), C.byref(io), ws.data_ptr(), ws.numel(), post_ws.data_ptr(), post_ws.numel(),
                                            m._options(), _raw_stream(dev))
         if st:

@@ -25,7 +25,9 @@
 extern "C" {
 #endif
 
-#define GNNCCA_ABI_VERSION 1
+/* 2 (round 6): gnncca_frames_io gained `counters_len` -- gnncca_frames_forward writes [3 N + 1 + G] int32 through `counters` (round 5 grew
+ * it from [2 N + 1] without a version change: a caller built against that header would have been overrun) and now refuses a shorter buffer. */
+#define GNNCCA_ABI_VERSION 2
 #define GNNCCA_MAX_LAYERS 8
 
 #if defined(GNNCCA_BUILD)
@@ -348,6 +350,7 @@ typedef struct gnncca_frames_io {
     int64_t* pruned;               /* [E] out                                                                          */
     int32_t* counters;             /* [3 N + 1 + G] out: flow_out | flow_in | n_clusters | cluster sizes (scratch) | triggers [G] */
     int32_t* labels;               /* [N] out                                                                          */
+    int64_t counters_len;          /* int32 words the caller allocated behind `counters`: < 3 N + 1 + G -> GNNCCA_ERR_INVALID_ARG  */
 } gnncca_frames_io;
 GNNCCA_API int gnncca_frames_forward(const gnncca_mpn_dims* dims, const void* packed_dev, const gnncca_frames_io* io,
                                      void* mpn_workspace, size_t mpn_workspace_bytes, void* post_workspace,

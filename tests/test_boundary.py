@@ -37,6 +37,29 @@ def test_library_exports_every_declared_symbol():
     assert lib.gnncca_status_string(2).decode().startswith("GRAPH_NET_PARAMS not supported")
 
 
+def test_frames_forward_refuses_a_short_counters_buffer():
+    """ABI 2: gnncca_frames_forward writes [3 N + 1 + G] int32 through io.counters; the caller states the length it allocated and a
+    shorter one is refused BEFORE anything is launched (no device needed: the argument checks come first; the pointers are never followed)."""
+    import ctypes as C
+    from gnn_cca_amd import _native as nat
+    m, *_ = _model("terrace32")
+    d = m.native_dims()
+    assert d.abi_version == 2 == nat.ABI_VERSION
+    n, g, e = 10, 2, 40
+    io = nat.FramesIO()
+    fake = 0x10000
+    for name, _t in nat.FramesIO._fields_:
+        if _t is C.c_void_p:
+            setattr(io, name, fake)
+    io.n_nodes, io.n_frames, io.n_edges, io.reid_dim, io.mode, io.normalize = n, g, e, 8, 0, 0
+    lib = nat.lib()
+    for short in (0, 2 * n + 1, 3 * n + g):
+        io.counters_len = short
+        assert lib.gnncca_frames_forward(C.byref(d), fake, C.byref(io), None, 0, None, 0, 0, None) == nat.ERR_INVALID_ARG
+    header = open(os.path.join(ROOT, "include", "gnncca_mpn.h")).read()
+    assert "int64_t counters_len;" in header and "#define GNNCCA_ABI_VERSION 2" in header
+
+
 def test_forward_options_match_the_header():
     """The option bits of gnncca_mpn_forward_ex: the Python constants equal the header's #defines, and the module attributes
     (edge_state_dtype, encoder_products, encoder_unsplit) map onto them; illegal values raise before anything is launched."""
