@@ -121,6 +121,25 @@ def step_algorithmic_bytes(E, L, n_cls, msg_only=True, e_bytes=24):
     return per_launch
 
 
+def forward_algorithmic_bytes(N, E, L=4, n_cls=3, node_in=2048, e_bytes=24):
+    """Algorithmic HBM bytes of one whole forward (DESIGN.md section 4's per-kernel figures added up): every step launch (edge state in / out,
+    col32, logits), the plan (16 B of int64 ids read + 4 B of col32 written per edge), the encoder's x stream + 1 MB of first-layer weights."""
+    return float(sum(step_algorithmic_bytes(E, L, n_cls, msg_only=False, e_bytes=e_bytes)) + 20 * E + N * node_in * 4 + (1 << 20))
+
+
+def leg_fractions(kernels_us, N, E, ms_per_step, msg_bytes_mean):
+    """HBM fractions of a batch forward from its per-kernel times: encoder (x stream + weights over the enc_gemm launch), mean message step,
+    whole forward (algorithmic bytes of the forward over its wall time per step)."""
+    out = {}
+    if kernels_us.get("enc_gemm"):
+        out["enc_frac"] = (N * 2048 * 4 + (1 << 20)) / (kernels_us["enc_gemm"] * 1e-6) / 1e9 / HBM_PEAK_GBPS
+    if kernels_us.get("step"):
+        out["step_frac"] = msg_bytes_mean / (kernels_us["step"] * 1e-6) / 1e9 / HBM_PEAK_GBPS
+    if ms_per_step:
+        out["forward_frac"] = forward_algorithmic_bytes(N, E) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS
+    return out
+
+
 def scale_probe(params, device, args, graphs=64):
     """The SAME step kernel on a batch of `graphs` graphs of the headline size, where the edge state (200 MB) no longer
     fits any cache: the HBM-relevant operating point of the dominant kernel, measured live (HIP events attached to each
@@ -204,9 +223,8 @@ def cpu_baseline(params, model, n_nodes, n_graphs, budget_s=20.0):
     except Exception as exc:  # noqa: BLE001
         parity = {"error": f"{type(exc).__name__}: {exc}"}
     return {"value": E / med, "unit": "edges/s", "cores": best, "kind": "port", "parity": parity,
-            "sample": f"{n_runs} forwards of {g_sample} x dense{n_nodes} (E={E}), median {med * 1e3:.2f} ms at {best} "
-                      f"threads (host: {_cpu_model()}, {ncpu} hardware threads; medians: {others}); torch CPU op-for-op "
-                      f"restatement (oracle.TorchOracle), fp32"}
+            "sample": f"{n_runs} fwd of {g_sample} x dense{n_nodes}, median {med * 1e3:.2f} ms @ {best} thr, oracle.TorchOracle fp32",
+            "ms_per_forward": med * 1e3, "host": f"{_cpu_model()}, {ncpu} hw threads"[:100], "medians_by_threads": others[:100]}
 
 
 class LazyDenseGraphs:
@@ -269,6 +287,114 @@ def timed_blocks(run, steps, warmup, dist, device, backend, min_blocks=10, min_t
             t = float(tt.item())
         blocks.append(t)
     return sorted(blocks), out
+
+
+FORM_ORDER = ["eager", "graph", "graph_block", "graph_block_chains"]
+
+
+def agree_forms(have, dist, device, backend):
+    """Multi-rank runs: the issue forms EVERY rank holds.  Each rank captures its HIP graphs under its own try / except, so a capture that fails
+    on one rank only would leave that rank skipping a form whose timed blocks the others enter -- the barriers / all-reduces inside
+    `timed_blocks` would then pair up across DIFFERENT forms and the job would hang.  One all-reduce (MIN) over a 0 / 1
+    vector in FORM_ORDER before anything is timed: a form missing anywhere is dropped everywhere.  Returns the agreed names in FORM_ORDER."""
+    mine = [1 if k in have else 0 for k in FORM_ORDER]
+    if dist is not None:
+        t = torch.tensor(mine, dtype=torch.int32, device=device if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        mine = [int(v) for v in t.tolist()]
+    return [k for k, ok in zip(FORM_ORDER, mine) if ok]
+
+
+def agree_flag(flag, dist, device, backend):
+    """True only if `flag` is true on every rank (same all-reduce, one word): eligibility decisions that gate a COLLECTIVE region."""
+    if dist is None:
+        return bool(flag)
+    t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=device if backend == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(int(t.item()))
+
+
+def flat_evidence(res):
+    """The scalars the line's claims rest on, copied into `config` / `roofline` under short flat keys: the driver's record
+    keeps the scalar entries of those two objects and only the NAMES of the nested legs, so rows (d), (e), N1-N3 could not be checked from
+    BENCH_rNN.json alone.  Every value here is a copy of a figure of the nested objects of the same line, nothing is computed twice."""
+    c, r = res["config"], res["roofline"]
+
+    def put(dst, key, val):
+        if val is not None and not isinstance(val, (dict, list)):
+            dst[key] = val
+
+    for k, v in (res["config"].get("ms_per_step_by_mode") or {}).items():
+        put(c, f"ms_{k}", v)
+    sh, c4 = res.get("config4_share"), res.get("config4_sharded")
+    if c4:
+        put(c, "cfg4_graphs_per_rank", c4.get("graphs_per_rank"))
+        put(c, "cfg4_ms", c4.get("ms_per_step"))
+        put(c, "cfg4_edges_per_s", c4.get("value"))
+        rr = c4.get("roofline_rank0") or {}
+        put(r, "cfg4_step_frac", rr.get("frac"))
+        put(r, "cfg4_step_us", rr.get("avg_launch_us"))
+        put(r, "cfg4_enc_frac", c4.get("enc_frac_rank0"))
+        put(r, "cfg4_enc_us", (c4.get("kernels_us_rank0") or {}).get("enc_gemm"))
+        put(r, "cfg4_forward_frac", c4.get("forward_frac_rank0"))
+    if sh:
+        put(c, "share_ms", sh.get("ms_per_step"))
+        put(c, "union_ms", sh.get("union_ms_per_step"))
+        put(c, "projected_8gpu_speedup", sh.get("projected_8gpu_speedup"))
+        put(c, "projected_8gpu_is", "a PROJECTION: union ms / share ms on ONE GPU, not an 8-GPU measurement")
+        put(r, "share_enc_frac", sh.get("enc_frac"))
+        put(r, "share_step_frac", sh.get("step_frac"))
+        put(r, "share_forward_frac", sh.get("forward_frac"))
+        for k, v in (sh.get("kernels_us") or {}).items():
+            put(r, f"share_{k}_us", v)
+    ras = res.get("roofline_at_scale")
+    if ras:
+        put(r, "at_scale_frac", ras.get("frac"))
+        put(r, "at_scale_step_us", ras.get("avg_launch_us"))
+    tp = res.get("terrace_pipeline")
+    if tp and "error" not in tp:
+        put(c, "terrace_ms_per_batch", tp.get("ms_per_batch"))
+        put(c, "terrace_frames_per_s", tp.get("frames_per_s"))
+        fin = tp.get("with_rounding_and_splitting") or {}
+        put(c, "terrace_final_ms_per_batch", fin.get("ms_per_batch"))
+        put(c, "terrace_final_frames_per_s", fin.get("frames_per_s"))
+        put(c, "terrace_final_overlapped_ms_per_batch", fin.get("overlapped_ms_per_batch"))
+        put(c, "terrace_final_overlapped_frames_per_s", fin.get("overlapped_frames_per_s"))
+        put(c, "terrace_flagged_per_batch", fin.get("frames_through_the_host_heuristics_per_batch"))
+        put(c, "terrace_parity_ok", (tp.get("parity") or {}).get("ok"))
+    tr = res.get("train_step")
+    if tr and "error" not in tr:
+        put(c, "train_ms_per_iteration", tr.get("ms_per_iteration"))
+        put(c, "train_grad_err", (tr.get("parity") or {}).get("grad_max_abs_err"))
+        put(c, "train_parity_ok", (tr.get("parity") or {}).get("ok"))
+    short = {"config2_dense64_L4_fp32": "cfg2", "config3_dense256_L4_bf16_state": "cfg3bf16", "config5_dense1024_L8_fp32": "cfg5",
+             "config5_dense1024_L8_bf16_state": "cfg5bf16"}
+    for key, leg in (res.get("configs") or {}).items():
+        if "error" in leg:
+            put(c, f"{short.get(key, key)}_error", str(leg["error"])[:90])
+            continue
+        k = short.get(key, key)
+        put(c, f"{k}_ms", leg.get("ms_per_step"))
+        put(c, f"{k}_err", max((leg.get("parity") or {}).get("max_abs_err") or [float("nan")]))
+        put(r, f"{k}_step_frac", (leg.get("roofline") or {}).get("frac"))
+    par = res.get("parity")
+    if par:
+        put(c, "headline_err", max(par.get("max_abs_err") or [float("nan")]))
+        put(c, "headline_parity_ok", par.get("ok"))
+    dr = res.get("dynamic_range")
+    if dr and "error" not in dr:
+        for k, v in dr.items():
+            put(c, f"dynrange_{k}", v)
+    # the record truncates strings near 120 characters: every string of `config` / `roofline` / `cpu_baseline` stays under 100, the long form
+    # moves to `notes` (a nested object: in the line, not in the record)
+    notes = res.setdefault("notes", {})
+    for name in ("config", "roofline", "cpu_baseline"):
+        d_ = res.get(name) or {}
+        for k, v in list(d_.items()):
+            if isinstance(v, str) and len(v) > 100:
+                notes[f"{name}.{k}"] = v
+                d_[k] = v[:96] + " ..."
+    return res
 
 
 def state_hash(model):
@@ -616,6 +742,34 @@ def config_leg(nodes, L, edge_state, device, args, steps, cpu_budget_s=6.0, fuse
     return res
 
 
+def dynamic_range_leg(device, nodes=64):
+    """`dynamic_range` (SURVEY 7.3 / 8d "report relative error too"): the headline architecture with torch's default initialisation left
+    UNconditioned (`sum` aggregation grows the activations ~N per step: max |logit| tens to hundreds instead of 0.5), one dense `nodes`-node
+    graph; the HIP logits with fp32 and with bf16 edge-state storage against the fp64 oracle, relative to max |logit|, next to the fp32 oracle's
+    own distance from fp64 (the reference arithmetic's gap: the yardstick tests/test_gpu_dynamic_range.py bounds the HIP path by)."""
+    import copy
+
+    from oracle.mpn_oracle import NumpyOracle
+    params = graph_net_params(L=4)
+    model = build_model(copy.deepcopy(params), 2).to(device)          # 1 / (2 - 1): the node MLP is left as initialised
+    data = make_data(nodes, 1, 1, device)
+    sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    x, ei, ea = data.x.cpu().numpy(), data.edge_index.cpu().numpy(), data.edge_attr.cpu().numpy()
+    ref64 = NumpyOracle(copy.deepcopy(params), "resnet50", sd, np.float64).forward(x, ei, ea)
+    ref32 = NumpyOracle(copy.deepcopy(params), "resnet50", sd, np.float32).forward(x, ei, ea)
+    scale = max(float(np.abs(r).max()) for r in ref64)
+    out = {"nodes": nodes, "max_abs_logit": scale,
+           "oracle_fp32_rel": max(float(np.abs(a.astype(np.float64) - r).max()) for a, r in zip(ref32, ref64)) / scale}
+    for state in ("fp32", "bf16"):
+        model.edge_state_dtype = state
+        with torch.no_grad():
+            got = model(data)["classified_edges"]
+        torch.cuda.synchronize()
+        out[f"hip_{state}_state_rel"] = max(float(np.abs(o.cpu().numpy().astype(np.float64) - r).max()) for o, r in zip(got, ref64)) / scale
+    out["ok"] = bool(out["hip_fp32_state_rel"] <= 4 * out["oracle_fp32_rel"] + 1e-7)
+    return out
+
+
 def train_leg(device, args, frames=64, cams=4, per=5, cpu_reps=3):
     """`train_step`: one training iteration of the reference (train.py:454-494: forward, BCE loss over the classified steps, backward,
     SGD step) on a batch of 64 Terrace-shaped frames (4 cameras x 5 detections, cross-camera edges only; config_training.yaml's model:
@@ -750,6 +904,8 @@ def main():
     ap.add_argument("--profile-reps", type=int, default=20)
     ap.add_argument("--min-blocks", type=int, default=10)
     ap.add_argument("--launch-timeout", type=float, default=900.0, help="launcher: seconds before the rank processes are stopped")
+    ap.add_argument("--fail-capture-rank", type=int, default=-1,
+                    help="(diagnostic) HIP-graph capture 'fails' on this rank: every rank must then time the same remaining forms (eager) and exit 0")
     args = ap.parse_args()
 
     if args.train_leg_only:
@@ -826,6 +982,8 @@ def main():
         gf = GraphedForward(model, warmup=0)
         if args.mode in ("graph", "graphk", "graphs", "auto"):
             try:
+                if rank == args.fail_capture_rank:
+                    raise RuntimeError("--fail-capture-rank: simulated capture failure on this rank")
                 static = gf.static_inputs(data)
                 static.x.copy_(data.x), static.edge_index.copy_(data.edge_index), static.edge_attr.copy_(data.edge_attr)
                 gf(static)
@@ -859,9 +1017,13 @@ def main():
                     torch.cuda.synchronize()
         want = {"eager": ["eager"], "graph": ["graph"], "graphk": ["graph_block"], "graphs": ["graph_block_chains"],
                 "auto": ["eager", "graph", "graph_block", "graph_block_chains"]}[args.mode]
+        # every rank times the SAME forms, in the same order (a capture that failed on one rank drops the form on all of them)
+        agreed = agree_forms(forms, dist, device, args.backend)
+        if rank == 0 and sorted(agreed) != sorted(forms):
+            print(f"[bench] forms dropped because a rank could not capture them: {sorted(set(forms) - set(agreed))}", file=sys.stderr)
         timed = {}
         for name in want:
-            if name not in forms:
+            if name not in agreed:
                 continue
             run_f, run_b = forms[name]
             timed[name] = timed_blocks(run_f, args.steps, args.warmup, dist, device, args.backend, min_blocks=args.min_blocks,
@@ -873,12 +1035,11 @@ def main():
         one_at_a_time = {k: v for k, v in by_mode.items() if k != "graph_block_chains"} or by_mode
         best = min(one_at_a_time, key=one_at_a_time.get)
         blocks, out = timed[best]
-        api = {"eager": "gnn_cca_amd.MOTMPNet.forward, one call per step (eager)",
-               "graph": "gnn_cca_amd.inference.GraphedForward.__call__, one HIP-graph replay per step (static inputs, no copies)",
-               "graph_block": f"gnn_cca_amd.inference.GraphedForward.block, one HIP graph of {args.steps} forwards per block",
-               "graph_block_chains": f"gnn_cca_amd.inference.GraphedForward.block(chains={args.streams}), the {args.steps} forwards of a block "
-                                     f"as small HIP graphs (1-4 frames each) round robin on {args.streams} streams ({args.streams} frames in flight)"}
-        mode_used = api[best] + (" (auto: fastest one-forward-at-a-time form of " + ", ".join(sorted(one_at_a_time)) + ")" if args.mode == "auto" else "")
+        api = {"eager": "eager: MOTMPNet.forward, one call per step",
+               "graph": "graph: GraphedForward.__call__, one HIP-graph replay per step",
+               "graph_block": f"graph_block: GraphedForward.block, one HIP graph of {args.steps} forwards",
+               "graph_block_chains": f"graph_block_chains: GraphedForward.block(chains={args.streams}), {args.streams} frames in flight"}
+        mode_used = api[best] + (" (auto: fastest one-at-a-time form)" if args.mode == "auto" else "")
         run = forms[best][0] or eager_run
         t = blocks[len(blocks) // 2]      # median block of K steps (max over ranks inside every block)
         # one frame at a time vs frames in flight, side by side (both are in ms_per_step_by_mode; `value` is the one-at-a-time form)
@@ -908,7 +1069,9 @@ def main():
 
         # ---- BASELINE config 4: 512 independent dense128 graphs, sharded 512/N per rank (forward_sharded) ----------
         cfg4, share = None, None
-        if not args.no_config4:
+        # (the leg's timed blocks are collective: every rank must enter it or none -- eligibility is a pure function of the arguments, and
+        # is all-reduced anyway so that a rank with a different command line cannot desynchronise the job)
+        if agree_flag(not args.no_config4 and args.config4_graphs >= 1, dist, device, args.backend):
             from gnn_cca_amd.sharding import forward_sharded, shard_batch
             m4 = build_model(graph_net_params(L=4), 128, seed=rank).to(device)
             m4.edge_state_dtype = args.edge_state
@@ -952,6 +1115,8 @@ def main():
                                           "avg_launch_us": us4, "algorithmic_bytes_per_launch": alg4, "achieved": alg4 / (us4 * 1e-6) / 1e9,
                                           "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": alg4 / (us4 * 1e-6) / 1e9 / HBM_PEAK_GBPS,
                                           "two_nodes_per_wave_and_deferred_classification": bool(deferred)}
+                fr4 = leg_fractions(cfg4["kernels_us_rank0"], n4, e4_local, cfg4["ms_per_step"], alg4)
+                cfg4["enc_frac_rank0"], cfg4["forward_frac_rank0"] = fr4.get("enc_frac"), fr4.get("forward_frac")
             # N = 1: the per-GPU share of the 8-GPU run of the same job (graphs [0, 512/8) of the SAME lazy sequence, as rank 0 of 8
             # would build it) timed on this GPU, same box, same run: the only strong-scaling evidence obtainable without an 8-GPU
             # node -- projected_8gpu_speedup = union ms / share ms (no collective on the data path; the broadcast is one-time)
@@ -973,6 +1138,9 @@ def main():
                          "kernels_us": {k: float(np.mean(v)) * 1e3 for k, v in k8.items()},
                          "note": "projection from one-GPU measurements, not an 8-GPU measurement: every rank runs this share "
                                  "concurrently with no data-path collective"}
+                e8 = batch8.edge_index.shape[1]
+                share.update(leg_fractions(share["kernels_us"], (hi8 - lo8) * 128, e8, share["ms_per_step"],
+                                           float(np.mean(step_algorithmic_bytes(e8, 4, 3)))))
                 del batch8
             del m4, graphs4, batch4, res4
 
@@ -1019,16 +1187,14 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",   # the arithmetic type of the path (every product and sum is fp32-accurate; see config.edge_state for storage)
             "data": "synthetic",
-            "config": {"workload": f"{args.graphs} x dense{args.nodes} graph(s) per GPU per step "
-                                   f"(N={N}, E={E}), feat 2048, L={args.L}, 3 classified steps, fp32 arithmetic, "
-                                   f"{args.edge_state} edge state, eval",
+            "config": {"workload": f"{args.graphs} x dense{args.nodes} per GPU per step (N={N}, E={E}), feat 2048, L={args.L}, 3 cls steps, "
+                                   f"fp32, {args.edge_state} state, eval",
                        "mode": mode_used, "ms_per_step_by_mode": by_mode,
                        "frames_in_flight": args.streams if best == "graph_block_chains" else 1, "edge_state": args.edge_state, "edge_state_storage": "bf16" if args.edge_state == "bf16" else "f32",
                        "encoder_products": args.enc_products, "encoder_unsplit": args.enc_unsplit,
                        "outputs_finite": bool(ok),
                        "edge_steps_per_s": world * E * args.L * args.steps / t,
-                       "timing": f"median of {len(blocks)} blocks of {args.steps} steps (each: barrier + synchronize on both "
-                                 f"sides, MAX over ranks)",
+                       "timing": f"median of {len(blocks)} blocks of {args.steps} steps (barrier + sync both sides, MAX over ranks)",
                        "block_ms": {"min": blocks[0] * 1e3, "median": t * 1e3, "max": blocks[-1] * 1e3},
                        "launcher": "single process" if world == 1 else "torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ
                        else "bench.py (self-launched rank processes)", "backend": args.backend if world > 1 else None,
@@ -1037,7 +1203,7 @@ def main():
                        "rank_ms_per_step": ({"min": min(rank_ms), "max": max(rank_ms), "all": rank_ms} if rank_ms else None)},
             "roofline": {"bound": "latency" if cache_resident else "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": ("mpn_step_fast_kernel" if N <= 512 else "mpn_step_pipe_kernel") + "<FIRST|CLS, MSG> (message-passing step, L-1 launches/forward)",
+                         "kernel": ("mpn_step_fast_kernel" if N <= 512 else "mpn_step_pipe_kernel") + "<FIRST|CLS, MSG>: message step, L-1 launches/forward",
                          "avg_launch_us": step_ms * 1e3, "rocprof_avg_launch_us": rocprof_us,
                          "algorithmic_bytes_per_launch": alg,
                          "note": "edge state is L2/Infinity-Cache resident at this size: the launch is bounded by its dependent "
@@ -1072,6 +1238,12 @@ def main():
                 except Exception as exc:  # noqa: BLE001
                     res["configs"][key] = {"error": f"{type(exc).__name__}: {exc}"}
                     torch.cuda.synchronize()
+        if world == 1 and not args.no_configs:
+            try:
+                res["dynamic_range"] = dynamic_range_leg(device)
+            except Exception as exc:  # noqa: BLE001
+                res["dynamic_range"] = {"error": f"{type(exc).__name__}: {exc}"}
+                torch.cuda.synchronize()
         if world == 1 and not args.no_train:
             # in a child process of its own: the leg captures torch's autograd + optimizer into a HIP graph, and a crash inside that
             # machinery must cost this leg, not the line (the parent waits; one process on the GPU at a time computes)
@@ -1092,6 +1264,8 @@ def main():
                 res["cpu_baseline_fused"] = cpu_baseline_fused(params, model, args.nodes, args.graphs)
             except Exception as exc:  # noqa: BLE001
                 res["cpu_baseline_fused"] = {"error": f"{type(exc).__name__}: {exc}"}
+        res["config"]["forms_timed"] = ",".join(k for k in FORM_ORDER if k in by_mode)
+        flat_evidence(res)
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(res) + "\n").encode())
     if dist:
