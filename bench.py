@@ -525,6 +525,11 @@ def terrace_frames(batch, n_batches, seed=0):
     return out
 
 
+def nat_threads(pipe):
+    from gnn_cca_amd import _native as nat
+    return nat.lib().gnncca_post_pool_threads(pipe._pool_handle())
+
+
 def terrace_leg(device, args, batch=64, n_batches=16, cpu_budget_s=12.0):
     """`terrace_pipeline`: batches of 64 real-shaped frames (train BATCH_SIZE, config_training.yaml:53-54) through
     build_graph_batch -> MOTMPNet -> threshold -> prune_and_cluster (inference.py:189-345 without the bridge heuristics), every
@@ -582,6 +587,25 @@ def terrace_leg(device, args, batch=64, n_batches=16, cpu_budget_s=12.0):
         flagged += len(post["_keep"].final()["frames_finalized"])
     torch.cuda.synchronize()
     dt_final = time.perf_counter() - t0
+    # ... and OVERLAPPED (round 6): FrameResult.final_async() hands batch k to the pipeline's pool of host threads behind one D2H copy on the
+    # pool's own stream -- no synchronisation -- while this loop enqueues batch k + 1's chain; a batch is collected two batches later.  Every
+    # batch still ends with its FINAL host-side predictions / labels (what the reference's loop has after inference.py:345).
+    depth, pend, flagged_o, done_o = 2, [], 0, 0
+    for i in range(min(4, n_batches)):      # pool threads, pinned buffers, the copy stream: created on first use
+        run(i)[3]["_keep"].final_async().result()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        for i in range(n_batches):
+            pend.append(run(i)[3]["_keep"].final_async())
+            if len(pend) > depth:
+                flagged_o += len(pend.pop(0).result()["frames_finalized"])
+                done_o += 1
+    while pend:
+        flagged_o += len(pend.pop(0).result()["frames_finalized"])
+        done_o += 1
+    torch.cuda.synchronize()
+    dt_over = time.perf_counter() - t0
     for i in range(n_batches):   # stage split (synchronised between stages: for the split only, not part of the figure above)
         f, (node, reid) = frames[i], dev_in[i]
         torch.cuda.synchronize(); t = time.perf_counter()
@@ -658,9 +682,13 @@ def terrace_leg(device, args, batch=64, n_batches=16, cpu_budget_s=12.0):
             "ms_per_batch": dt / n_done * 1e3, "frames_per_s": batch * n_done / dt, "edges_per_s": edges / dt,
             "with_rounding_and_splitting": {"ms_per_batch": dt_final / n_batches * 1e3, "frames_per_s": batch * n_batches / dt_final,
                                             "frames_through_the_host_heuristics_per_batch": flagged / n_batches,
-                                            "note": "FrameResult.final(): one synchronisation per batch to read the trigger words, then the reference's "
-                                                    "rounding / splitting for the flagged frames on the host (csrc/post_host.cpp).  The synthetic model's "
-                                                    "predictions are near-random, so MOST frames raise a trigger here; a trained model's rarely do"},
+                                            "overlapped_ms_per_batch": dt_over / done_o * 1e3, "overlapped_frames_per_s": batch * done_o / dt_over,
+                                            "overlapped_flagged_per_batch": flagged_o / done_o, "overlapped_depth": depth,
+                                            "overlapped_host_threads": int(nat_threads(pipe)),
+                                            "note": "ms_per_batch: FrameResult.final() per batch, one after the other (waits for the batch, host pass, results "
+                                                    "uploaded again); overlapped_*: FrameResult.final_async(), batch k's host pass (pool of host threads, "
+                                                    "csrc/post_host.cpp) overlaps batch k + 1's GPU chain, results collected two batches later.  The synthetic "
+                                                    "model's predictions are near-random, so MOST frames raise a trigger here; a trained model's rarely do"},
             "stage_ms_per_batch_synchronised": {k: v / n_batches * 1e3 for k, v in stage.items()},
             "parity": {"ok": bool(checks) and all(c["ok"] for c in checks), "tolerance_abs": 1e-4, "batches": checks,
                        "against": "oracle.graph_oracle + oracle.TorchOracle on the same inputs; oracle.post_oracle on the GPU's predictions"},

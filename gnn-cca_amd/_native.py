@@ -42,6 +42,13 @@ class FramesIO(C.Structure):
                 ("counters", C.c_void_p), ("labels", C.c_void_p), ("counters_len", C.c_int64)]
 
 
+class PostBatch(C.Structure):
+    """gnncca_post_batch (include/gnncca_mpn.h): one batch's HOST copies for the asynchronous finalizer pool."""
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("node_ptr", C.c_void_p), ("edge_ptr", C.c_void_p), ("n_frames", C.c_int32),
+                ("switches", C.c_int32), ("triggers", C.c_void_p), ("probs", C.c_void_p), ("predictions", C.c_void_p), ("labels", C.c_void_p),
+                ("n_clusters", C.c_void_p), ("ready_event", C.c_void_p), ("device", C.c_int32)]
+
+
 class Trace(C.Structure):
     _fields_ = [("h_enc", C.c_void_p), ("e_enc", C.c_void_p), ("h_steps", C.c_void_p), ("e_steps", C.c_void_p)]
 
@@ -106,6 +113,12 @@ _SIGNATURES = {
                                                   C.c_void_p, C.c_void_p, C.c_void_p]),
     "gnncca_post_finalize_frames_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                                    C.c_int32, C.c_void_p, C.c_void_p, C.c_int32]),
+    "gnncca_post_pool_create": (C.c_void_p, [C.c_int32]),
+    "gnncca_post_pool_threads": (C.c_int32, [C.c_void_p]),
+    "gnncca_post_pool_destroy": (None, [C.c_void_p]),
+    "gnncca_post_pool_submit": (C.c_int64, [C.c_void_p, C.POINTER(PostBatch)]),
+    "gnncca_post_pool_submit_copy": (C.c_int64, [C.c_void_p, C.POINTER(PostBatch), C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p]),
+    "gnncca_post_pool_wait": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "gnncca_backward_supported": (C.c_int, [C.POINTER(MpnDims)]),
     "gnncca_backward_workspace_bytes": (C.c_size_t, [C.POINTER(MpnDims), C.c_int64, C.c_int64]),
     "gnncca_mpn_backward": (C.c_int, [C.POINTER(MpnDims), C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -14,7 +14,14 @@ and the Python between five calls is a third of it: 0.143 -> 0.11 ms per batch.
     f = r.final()                                                   # the reference's FINAL predictions / ID_pred partition under
     f['predictions'], f['labels'], f['n_clusters']                  # ROUNDING / PRUNING / SPLITTING (config_inference.yaml:6-8)
 
-`r.final()` (= `postprocess.finalize`) synchronises once to read the trigger words; frames that raised none keep the device chain's result
+`r.final_async()` (round 6) hands the batch to a persistent pool of host threads WITHOUT synchronising -- one D2H copy of the batch's trigger
+words / edges / probabilities / pruned predictions / labels on the pool's own stream behind an event, the flagged frames finalized by the
+pool while the caller enqueues the next batch -- and returns a `PendingFinal`; `.result()` waits for that batch only:
+
+    pending = [pipe(*batch_k).final_async() for ...]                # batch k's host pass overlaps batch k + 1's GPU chain
+    f = pending[k].result()                                         # host arrays: f['predictions'], f['labels'], f['n_clusters'], ...
+
+`r.final()` is `final_async().result()` with the results uploaded again (device tensors, as `postprocess.finalize` returns them); frames that raised none keep the device chain's result
 (it is final for them), the others go through the reference's rounding / splitting heuristics on the host (csrc/post_host.cpp), frame by
 frame as the reference's batch-size-1 validation loop does.  The constructor's `rounding` / `pruning` / `splitting` mirror CONFIG's keys.
 
@@ -32,19 +39,92 @@ from .sharding import GraphBatch
 MAX_NODES = 4096
 
 
+class PendingFinal:
+    """A batch on its way through the host heuristics (gnncca_post_pool_*).  `result()` blocks until THIS batch is final -- it never
+    synchronises the device -- and returns host arrays: predictions int64 [E], labels int32 [N] (a cluster's smallest node id), n_clusters
+    int, frames_finalized (the frames that went through the heuristics), triggers int32 [G].  The arrays are copies unless `copy=False`
+    (views of this object's pinned buffer: valid while the object lives)."""
+
+    def __init__(self, pipe, ticket, host, views, keep):
+        self._pipe, self._ticket, self._host, self._views, self._keep = pipe, ticket, host, views, keep
+        self._res = None
+
+    def done(self):
+        return self._res is not None
+
+    def result(self, copy=True):
+        if self._res is None:
+            g = self._views["triggers"].shape[0]
+            frames, count = np.empty(max(g, 1), dtype=np.int32), C.c_int32(0)
+            st = nat.lib().gnncca_post_pool_wait(self._pipe._pool_handle(), self._ticket, frames.ctypes.data, C.byref(count))
+            self._keep = None      # the device buffers may go: everything is on the host now
+            if st:
+                nat.check(st, "gnncca_post_pool_wait")
+            v = self._views
+            self._res = {"predictions": v["pruned"], "labels": v["labels"], "n_clusters": int(v["n_clusters"][0]),
+                         "frames_finalized": frames[:count.value].tolist(), "triggers": v["triggers"]}
+        if not copy:
+            return self._res
+        return {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in self._res.items()}
+
+    def __del__(self):
+        try:
+            if self._res is None and self._ticket is not None:   # never collected: wait, or the pool would write into freed memory
+                nat.lib().gnncca_post_pool_wait(self._pipe._pool_handle(), self._ticket, None, None)
+            self._pipe._give_back(self._host)
+        except Exception:  # noqa: BLE001  (interpreter shutdown)
+            pass
+
+
 class FrameResult:
     """Outputs of one batch; tensors are views of ONE device buffer owned by this object."""
-    __slots__ = ("batch", "outputs", "probs", "preds", "pruned", "flow_out", "flow_in", "labels", "n_clusters", "triggers", "_switches", "_final", "_keep")
+    __slots__ = ("batch", "outputs", "probs", "preds", "pruned", "flow_out", "flow_in", "labels", "n_clusters", "triggers", "_switches", "_final", "_keep",
+                 "_pipe", "_d2h", "_pending")
+
+    def final_async(self):
+        """Hand this batch to the pipeline's pool of host threads (no synchronisation) -> PendingFinal.  Results that did not come from the
+        one-call path (more than 4096 detections, hooks, train mode) are finalized on the spot."""
+        if self._pending is None:
+            self._pending = self._pipe._submit_final(self) if self._d2h is not None else _Finished(self)
+        return self._pending
 
     def final(self):
         """The reference's final predictions and identity clusters for this batch (inference.py:306-345 under the pipeline's ROUNDING /
-        PRUNING / SPLITTING switches): `postprocess.finalize` on this result, computed once.  Synchronises."""
+        PRUNING / SPLITTING switches) as DEVICE tensors, computed once: `final_async().result()` uploaded again (or, for results of the
+        step-by-step path, `postprocess.finalize`).  Waits for this batch."""
         if self._final is None:
-            b = self.batch
-            r, p, s = self._switches
-            self._final = finalize(b.edge_index, self.probs, self.pruned, self.labels, self.n_clusters, self.triggers, b.node_ptr, b.edge_ptr,
-                                   rounding=r, pruning=p, splitting=s)
+            if self._d2h is None:
+                b = self.batch
+                r, p, s = self._switches
+                self._final = finalize(b.edge_index, self.probs, self.pruned, self.labels, self.n_clusters, self.triggers, b.node_ptr, b.edge_ptr,
+                                       rounding=r, pruning=p, splitting=s)
+            else:
+                res = self.final_async().result(copy=False)
+                dev = self.pruned.device
+                if not res["frames_finalized"]:      # nothing changed: the device chain's tensors ARE the final result
+                    self._final = {"predictions": self.pruned, "labels": self.labels, "n_clusters": self.n_clusters,
+                                   "frames_finalized": [], "triggers": res["triggers"]}
+                else:
+                    self._final = {"predictions": torch.from_numpy(res["predictions"]).to(dev, non_blocking=True),
+                                   "labels": torch.from_numpy(res["labels"]).to(dev, non_blocking=True),
+                                   "n_clusters": torch.tensor([res["n_clusters"]], dtype=torch.int32, device=dev),
+                                   "frames_finalized": res["frames_finalized"], "triggers": res["triggers"]}
         return self._final
+
+
+class _Finished:
+    """PendingFinal of a result that was finalized synchronously (the step-by-step path)."""
+
+    def __init__(self, r):
+        f = r.final()
+        self._res = {"predictions": f["predictions"].cpu().numpy(), "labels": f["labels"].cpu().numpy(), "n_clusters": int(f["n_clusters"].item()),
+                     "frames_finalized": f["frames_finalized"], "triggers": f["triggers"]}
+
+    def done(self):
+        return True
+
+    def result(self, copy=True):
+        return dict(self._res)
 
 
 class FramePipeline:
@@ -58,6 +138,69 @@ class FramePipeline:
         self._post_ws = {}   # (stream, bytes) -> workspace tensor
         self._shape = None   # (n, e) of the cached workspace sizes
         self._sizes = (0, 0)
+        self._pool = None    # gnncca_post_pool (created on the first final_async)
+        self._pinned = {}    # bytes (power of two) -> free pinned host buffers of that size
+        self.host_threads = 0   # 0: the library's default (hardware threads - 2, at most 12)
+
+    def _pool_handle(self):
+        if self._pool is None:
+            self._pool = nat.lib().gnncca_post_pool_create(int(self.host_threads))
+            if not self._pool:
+                raise nat.NativeError("gnncca_post_pool_create failed")
+        return self._pool
+
+    def close(self):
+        """Stops the pool's threads (every PendingFinal must have been collected)."""
+        if self._pool is not None:
+            nat.lib().gnncca_post_pool_destroy(self._pool)
+            self._pool = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+    def _take_pinned(self, nbytes):
+        size = 1 << max(12, int(nbytes - 1).bit_length())
+        free = self._pinned.setdefault(size, [])
+        return free.pop() if free else torch.empty(size, dtype=torch.uint8, pin_memory=True)
+
+    def _give_back(self, host):
+        if host is not None and self._pinned is not None:
+            self._pinned.setdefault(host.numel(), []).append(host)
+
+    def _submit_final(self, r):
+        """One D2H copy of [probs | edge_index | pruned | counters | labels] (contiguous in the batch's arena) behind the chain, on the pool's own
+        stream, and the job behind that copy: nothing here waits for the device."""
+        arena, start, end, off, n, e, g = r._d2h
+        dev = arena.device
+        nbytes = end - start
+        host = self._take_pinned(nbytes)
+        hp = host.data_ptr()
+        hn = host.numpy()
+
+        def view(key, dtype, count):
+            o = off[key] - start
+            return hn[o:o + count * np.dtype(dtype).itemsize].view(dtype)
+
+        views = {"probs": view("probs", np.float32, e), "src": view("edge_index", np.int64, e), "pruned": view("pruned", np.int64, e),
+                 "triggers": view("triggers", np.int32, g), "labels": view("labels", np.int32, n), "n_clusters": view("n_clusters", np.int32, 1)}
+        node_ptr, edge_ptr = np.asarray(r.batch.node_ptr, dtype=np.int32), np.asarray(r.batch.edge_ptr, dtype=np.int32)
+        b = nat.PostBatch()
+        b.src, b.dst = hp + off["edge_index"] - start, hp + off["edge_index"] - start + 8 * e
+        b.node_ptr, b.edge_ptr, b.n_frames = node_ptr.ctypes.data, edge_ptr.ctypes.data, g
+        rr, _, ss = r._switches
+        b.switches = (nat.POST_ROUNDING if rr else 0) | nat.POST_PRUNING | (nat.POST_SPLITTING if ss else 0)
+        b.triggers, b.probs = hp + off["triggers"] - start, hp + off["probs"] - start
+        b.predictions, b.labels, b.n_clusters = hp + off["pruned"] - start, hp + off["labels"] - start, hp + off["n_clusters"] - start
+        with _on(dev):
+            ticket = nat.lib().gnncca_post_pool_submit_copy(self._pool_handle(), C.byref(b), arena.data_ptr() + start, hp, nbytes, dev.index,
+                                                            _raw_stream(dev))
+        if ticket < 0:
+            self._give_back(host)
+            nat.check(int(-ticket), "gnncca_post_pool_submit_copy")
+        return PendingFinal(self, ticket, host, views, (r._keep, node_ptr, edge_ptr))
 
     def _slow(self, xw, yw, ids, id_cam, sizes, max_dist, node, reid):
         b = build_graph_batch(xw, yw, ids, id_cam, sizes, max_dist, node, reid, only_appearance=self.mode == MODE_ONLY_APPEARANCE,
@@ -71,6 +214,7 @@ class FramePipeline:
         r.pruned, r.flow_out, r.flow_in, r.labels, r.n_clusters = post["pruned"], post["flow_out"], post["flow_in"], post["labels"], post["n_clusters"]
         r.triggers, r._switches, r._final = post["triggers"], self.switches, None
         r._keep = post
+        r._pipe, r._d2h, r._pending = self, None, None
         return r
 
     def __call__(self, xw, yw, ids, id_cam, graph_sizes, max_dist, node_embeds, reid_embeds):
@@ -125,7 +269,8 @@ class FramePipeline:
             o_lab = o_attr + up(e * n_attr)
             o_log = o_lab + up(e)
             o_prob = o_log + up(n_out * e)
-            o_pred, o_prun = up(2 * e), up(2 * e) + up(e)
+            o_ei, o_prun = 0, up(2 * e)       # (the thresholded predictions live in front of the f32 block: final_async's D2H region is
+            #                                      [probs | edge_index | pruned | counters | labels] and does not carry them)
             o_labels = up(3 * n + 1 + g)      # flow_out | flow_in | n_clusters | cluster sizes (scratch) | triggers [G]
             if self._shape != (n, e):
                 self._shape = (n, e)
@@ -134,11 +279,13 @@ class FramePipeline:
             if e > 0 and ws_bytes == 0:
                 nat.check(lib.gnncca_supported(C.byref(d)), "MOTMPNet configuration")
             ws = m._scratch(max(ws_bytes, 256), dev)
-            # ONE allocation per batch (round 5; five until then, 2-3 us of host time each): [staging image | f32 | i64 | i32 | post workspace],
+            # ONE allocation per batch (round 5; five until then, 2-3 us of host time each): [staging image | predictions | f32 | i64 | i32 | post workspace],
             # every region on a 256-byte boundary
             def up256(v):
                 return (v + 255) // 256 * 256
-            b_f32, b_i64 = up256(nbytes), up256(nbytes) + up256(4 * (o_prob + e))
+            b_pred = up256(nbytes)
+            b_f32 = b_pred + up256(8 * e)
+            b_i64 = b_f32 + up256(4 * (o_prob + e))
             b_i32 = b_i64 + up256(8 * (o_prun + e))
             b_post = b_i32 + up256(4 * (o_labels + n))
             arena = torch.empty(b_post + post_bytes, dtype=torch.uint8, device=dev)
@@ -147,6 +294,7 @@ class FramePipeline:
             event.record(_current_stream(dev))
             f32 = arena[b_f32:b_f32 + 4 * (o_prob + e)].view(torch.float32)
             i64 = arena[b_i64:b_i64 + 8 * (o_prun + e)].view(torch.int64)
+            preds = arena[b_pred:b_pred + 8 * e].view(torch.int64)
             i32 = arena[b_i32:b_i32 + 4 * (o_labels + n)].view(torch.int32)
             post_ws = arena[b_post:b_post + post_bytes]
             io = nat.FramesIO()
@@ -157,7 +305,7 @@ class FramePipeline:
                 io.node_norm, io.reid_norm = fp + 4 * o_node, fp + 4 * o_reid
             io.edge_attr, io.edge_labels = fp + 4 * o_attr, fp + 4 * o_lab
             io.logits, io.probs = fp + 4 * o_log, fp + 4 * o_prob
-            io.edge_index, io.predictions, io.pruned = ip, ip + 8 * o_pred, ip + 8 * o_prun
+            io.edge_index, io.predictions, io.pruned = ip + 8 * o_ei, preds.data_ptr(), ip + 8 * o_prun
             io.counters, io.labels, io.counters_len = cp, cp + 4 * o_labels, o_labels
             st = lib.gnncca_frames_forward(C.byref(d), blob.data_ptr(), C.byref(io), ws.data_ptr(), ws.numel(), post_ws.data_ptr(), post_ws.numel(),
                                            m._options(), _raw_stream(dev))
@@ -168,7 +316,7 @@ class FramePipeline:
         reid_n = f32[o_reid:o_reid + n * r_dim].view(n, r_dim) if self.normalize else reid_embeds
         i32_off = 8 * (3 * n + g)
         host_i32 = pinned[i32_off:nbytes].numpy().view(np.int32)
-        batch = GraphBatch(x, i64[:2 * e].view(2, e), f32[o_attr:o_attr + e * n_attr].view(e, n_attr),
+        batch = GraphBatch(x, i64[o_ei:o_ei + 2 * e].view(2, e), f32[o_attr:o_attr + e * n_attr].view(e, n_attr),
                            host_i32[5 * n + g + 2:5 * n + 2 * g + 3].tolist(), host_i32[3 * n:3 * n + g + 1].tolist())
         i32_dev = staged[i32_off:].view(torch.int32)
         batch.node_ptr_dev = i32_dev[3 * n:3 * n + g + 1]
@@ -180,8 +328,13 @@ class FramePipeline:
         r.batch = batch
         r.outputs = {"classified_edges": list(f32[o_log:o_log + n_out * e].view(n_out, e, 1).unbind(0))}
         r.probs = f32[o_prob:o_prob + e]
-        r.preds, r.pruned = i64[o_pred:o_pred + e], i64[o_prun:o_prun + e]
+        r.preds, r.pruned = preds, i64[o_prun:o_prun + e]
         r.flow_out, r.flow_in, r.n_clusters, r.labels = i32[:n], i32[n:2 * n], i32[2 * n:2 * n + 1], i32[o_labels:o_labels + n]
         r.triggers, r._switches, r._final = i32[3 * n + 1:3 * n + 1 + g], self.switches, None
         r._keep = (arena, ws, blob)
+        # final_async: ONE contiguous D2H region of the arena, [probs .. labels] (byte offsets inside the arena)
+        off = {"probs": b_f32 + 4 * o_prob, "edge_index": b_i64 + 8 * o_ei, "pruned": b_i64 + 8 * o_prun, "n_clusters": b_i32 + 4 * (2 * n),
+               "triggers": b_i32 + 4 * (3 * n + 1), "labels": b_i32 + 4 * o_labels}
+        r._pipe, r._pending = self, None
+        r._d2h = (arena, off["probs"], b_i32 + 4 * (o_labels + n), off, n, e, g)
         return r

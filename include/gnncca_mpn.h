@@ -326,6 +326,45 @@ GNNCCA_API int gnncca_post_finalize_frames_host(const int64_t* src, const int64_
                                                 const int32_t* frames, int32_t n_listed, const float* probs, int64_t* predictions,
                                                 int32_t switches, int32_t* labels, int32_t* clusters_out, int32_t n_threads);
 
+/* The ASYNCHRONOUS form (round 6): a persistent pool of host threads finalizes batches while the caller enqueues the next batch's GPU
+ * chain -- the reference's loop pays its heuristics between two forwards (inference.py:294-345 runs on the host while the GPU waits); here
+ * batch k's host pass overlaps batch k + 1's launches.  The caller copies the batch's results to HOST memory (pinned) on a side stream
+ * behind an event and submits pointers into that copy: `triggers` [G] (gnncca_post_prune_cluster_frames_ex's words), src / dst [E],
+ * probs [E], `predictions` [E] in: the pruned predictions, out: the final ones, `labels` [N] in / out (the device chain's convention: a
+ * component's smallest batch-global node id), `n_clusters` [1] in: the device chain's count, out: the final count.  A pool thread waits for
+ * `ready_event` (a hipEvent_t recorded behind the copy; null: the data is already there) on device `device`, lists the frames whose
+ * trigger word meets the switches and the pool's threads finalize them (gnncca_post_finalize_frame_host per frame; no allocation per
+ * frame).  gnncca_post_pool_submit returns a ticket >= 0 (or -status); gnncca_post_pool_wait blocks until that batch is final, writes
+ * the finalized frame ids to frames_out [<= G] / their number to *n_frames_out (either may be null), releases the ticket and returns
+ * the first non-zero status of any frame.  The buffers must stay valid until the wait returns.  n_threads 0 = hardware threads - 2,
+ * at most 12. */
+typedef struct gnncca_post_pool gnncca_post_pool;
+typedef struct gnncca_post_batch {
+    const int64_t* src;
+    const int64_t* dst;
+    const int32_t* node_ptr;       /* [G + 1] host */
+    const int32_t* edge_ptr;       /* [G + 1] host */
+    int32_t n_frames;
+    int32_t switches;              /* GNNCCA_POST_ROUNDING | GNNCCA_POST_PRUNING | GNNCCA_POST_SPLITTING */
+    const int32_t* triggers;       /* [G] */
+    const float* probs;
+    int64_t* predictions;
+    int32_t* labels;
+    int32_t* n_clusters;
+    void* ready_event;             /* hipEvent_t or null */
+    int32_t device;
+} gnncca_post_batch;
+GNNCCA_API gnncca_post_pool* gnncca_post_pool_create(int32_t n_threads);
+GNNCCA_API int32_t gnncca_post_pool_threads(const gnncca_post_pool* pool);
+GNNCCA_API void gnncca_post_pool_destroy(gnncca_post_pool* pool);
+GNNCCA_API int64_t gnncca_post_pool_submit(gnncca_post_pool* pool, const gnncca_post_batch* batch);
+/* gnncca_post_pool_submit for results that still sit in DEVICE memory: records an event on `stream` (the stream the batch's chain was
+ * enqueued on), makes the pool's own copy stream wait for it, copies `nbytes` from device_src to host_dst (pinned) there and submits
+ * `batch` -- whose pointers point into host_dst -- behind that copy.  One call, no synchronisation. */
+GNNCCA_API int64_t gnncca_post_pool_submit_copy(gnncca_post_pool* pool, const gnncca_post_batch* batch, const void* device_src,
+                                                void* host_dst, size_t nbytes, int32_t device, gnncca_stream_t stream);
+GNNCCA_API int gnncca_post_pool_wait(gnncca_post_pool* pool, int64_t ticket, int32_t* frames_out, int32_t* n_frames_out);
+
 /* ---- rows N1 + the path + N2 in ONE call: a batch of frames from the uploaded staging image to identity clusters -------------------
  * The per-batch body of inference.py:189-345 (normalise the embeddings, build the graph, MOTMPNet.forward, sigmoid / threshold,
  * prune, flow counts, clusters) as the same launches gnncca_normalize_columns2 / gnncca_build_edges / gnncca_mpn_forward_ex /

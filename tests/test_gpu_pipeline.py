@@ -125,3 +125,49 @@ def test_shapes_alternate_and_fallbacks_agree():
         pipe(f["xw"][:-1], f["yw"], f["ids"], f["id_cam"], f["sizes"], f["max_dist"], node, reid)
     with pytest.raises(RuntimeError):
         pipe(f["xw"], f["yw"], f["ids"], f["id_cam"], f["sizes"], f["max_dist"], node.cpu(), reid)
+
+
+def test_final_async_overlaps_batches_and_equals_the_synchronous_finalize():
+    """FrameResult.final_async (round 6): several batches in flight -- each handed to the pool of host threads behind ONE D2H copy on the
+    pool's own stream, no synchronisation in between -- collected OUT OF ORDER; every result equals postprocess.finalize (the synchronous
+    host pass, pinned against the reference's goldens) on the same device tensors, and FrameResult.final() returns the same as device tensors.
+    A result of the step-by-step path (more than 4096 detections) goes through the same interface."""
+    from gnn_cca_amd.pipeline import FramePipeline
+    from gnn_cca_amd.postprocess import finalize
+    rng = np.random.default_rng(77)
+    m = _model(seed=2)
+    pipe = FramePipeline(m)
+    pipe.host_threads = 4
+    fs = [_frames(rng, g) for g in (64, 20, 64, 5, 90)] + [_frames(rng, 260, lo=14, hi=20)]
+    dev_in = [(torch.from_numpy(f["node"]).cuda(), torch.from_numpy(f["reid"]).cuda()) for f in fs]
+    # centre the logits so that the heuristics have work to do
+    r0 = pipe(fs[0]["xw"], fs[0]["yw"], fs[0]["ids"], fs[0]["id_cam"], fs[0]["sizes"], fs[0]["max_dist"], *dev_in[0])
+    with torch.no_grad():
+        sd = m.state_dict()
+        key = [k for k in sd if k.startswith("classifier.") and k.endswith(".bias")][-1]
+        sd[key] -= r0.outputs["classified_edges"][-1].median()
+        m.load_state_dict(sd)
+    results, pending = [], []
+    for f, (node, reid) in zip(fs, dev_in):                    # no synchronisation anywhere in this loop
+        r = pipe(f["xw"], f["yw"], f["ids"], f["id_cam"], f["sizes"], f["max_dist"], node, reid)
+        results.append(r)
+        pending.append(r.final_async())
+    assert pending[0] is results[0].final_async()
+    touched = 0
+    for i in (3, 0, 5, 4, 1, 2):
+        r, got = results[i], pending[i].result()
+        b = r.batch
+        want = finalize(b.edge_index, r.probs, r.pruned, r.labels, r.n_clusters, r.triggers, b.node_ptr, b.edge_ptr)
+        assert np.array_equal(got["predictions"], want["predictions"].cpu().numpy()), i
+        assert np.array_equal(got["labels"], want["labels"].cpu().numpy()), i
+        assert got["n_clusters"] == int(want["n_clusters"].item()) and got["frames_finalized"] == want["frames_finalized"], i
+        assert np.array_equal(got["triggers"], r.triggers.cpu().numpy())
+        fin = r.final()
+        assert torch.equal(fin["predictions"], want["predictions"]) and torch.equal(fin["labels"], want["labels"])
+        assert int(fin["n_clusters"].item()) == got["n_clusters"]
+        touched += len(got["frames_finalized"])
+        # the device chain's own tensors are untouched by the host pass
+        assert torch.equal(r.pruned, want["predictions"]) == (not got["frames_finalized"] or torch.equal(r.pruned, want["predictions"]))
+    assert touched >= 10
+    del pending, results, r, got, fin
+    pipe.close()

@@ -127,6 +127,69 @@ def test_threaded_batch_entry_point_matches_the_reference():
             assert labels[node_ptr[q]:node_ptr[q + 1]].min() >= node_ptr[q]
 
 
+def test_asynchronous_pool_matches_the_reference():
+    """gnncca_post_pool_* (round 6): the persistent pool of host threads.  All golden frames as one batch, submitted several times (jobs in
+    flight together, collected out of order, with and without a SPLITTING switch); the pool lists the flagged frames from the trigger words
+    itself, finalizes exactly those, and returns the reference's final predictions / partition / cluster count.  Host data, no event."""
+    from gnn_cca_amd import _native as nat
+    lib = nat.lib()
+    eis, probs, node_ptr, edge_ptr = [], [], [0], [0]
+    for name in NAMES:
+        n, ei, _, p, g = case(name)
+        eis.append(ei + node_ptr[-1]), probs.append(p)
+        node_ptr.append(node_ptr[-1] + n), edge_ptr.append(edge_ptr[-1] + ei.shape[1])
+    ei_all, pr = np.concatenate(eis, axis=1), np.ascontiguousarray(np.concatenate(probs), dtype=np.float32)
+    src, dst = np.ascontiguousarray(ei_all[0]), np.ascontiguousarray(ei_all[1])
+    np_h, ep_h = np.asarray(node_ptr, np.int32), np.asarray(edge_ptr, np.int32)
+    G, N = len(NAMES), node_ptr[-1]
+    # what the device chain hands over: pruned predictions, labels = smallest node id of the component, its cluster count, the trigger words
+    pruned = np.concatenate([case(nm)[4]("pred_pruned") for nm in NAMES]).astype(np.int64)
+    labels0, k0, trig = np.zeros(N, np.int32), 0, np.zeros(G, np.int32)
+    for q, nm in enumerate(NAMES):
+        n, ei, _, _, g = case(nm)
+        ids = g("id_pruned")
+        for v in range(n):
+            labels0[node_ptr[q] + v] = node_ptr[q] + min(u for u in range(n) if ids[u] == ids[v])
+        k0 += len(set(ids.tolist()))
+        fo, fi = po.flows(ei, g("pred_pruned"), n)
+        trig[q] = (1 if (fo > 3).any() or (fi > 3).any() else 0) | (2 if np.bincount(ids).max() > 4 else 0)
+    pool = lib.gnncca_post_pool_create(3)
+    assert pool and lib.gnncca_post_pool_threads(pool) == 3
+    try:
+        jobs = []
+        for rep, (tag, sw) in enumerate([("final", 7), ("rounded", 3), ("final", 7), ("split_only", 6), ("final", 7)]):
+            pred, lab, kk = pruned.copy(), labels0.copy(), np.asarray([k0], np.int32)
+            b = nat.PostBatch()
+            b.src, b.dst, b.node_ptr, b.edge_ptr, b.n_frames, b.switches = src.ctypes.data, dst.ctypes.data, np_h.ctypes.data, ep_h.ctypes.data, G, sw
+            b.triggers, b.probs, b.predictions, b.labels, b.n_clusters = trig.ctypes.data, pr.ctypes.data, pred.ctypes.data, lab.ctypes.data, kk.ctypes.data
+            b.ready_event, b.device = None, 0
+            t = lib.gnncca_post_pool_submit(pool, C.byref(b))
+            assert t >= 0
+            jobs.append((t, tag, sw, pred, lab, kk, b))
+        for t, tag, sw, pred, lab, kk, _b in reversed(jobs):
+            frames, cnt = np.zeros(G, np.int32), C.c_int32(0)
+            assert lib.gnncca_post_pool_wait(pool, t, frames.ctypes.data, C.byref(cnt)) == 0
+            want_mask = (1 if sw & 1 else 0) | (2 if sw & 4 else 0)
+            assert frames[:cnt.value].tolist() == [q for q in range(G) if trig[q] & want_mask]
+            assert np.array_equal(pred, np.concatenate([case(nm)[4]("pred_" + tag) for nm in NAMES])), tag
+            want_ids = np.concatenate([case(nm)[4]("id_" + tag) + 1000 * q for q, nm in enumerate(NAMES)])
+            assert po.same_partition(lab, want_ids), tag
+            assert int(kk[0]) == len(set(want_ids.tolist())), tag
+            assert lib.gnncca_post_pool_wait(pool, t, None, None) == nat.ERR_INVALID_ARG      # a ticket is collected once
+        # a batch nobody flagged: final at once, nothing touched
+        pred, lab, kk, none = pruned.copy(), labels0.copy(), np.asarray([k0], np.int32), np.zeros(G, np.int32)
+        b = nat.PostBatch()
+        b.src, b.dst, b.node_ptr, b.edge_ptr, b.n_frames, b.switches = src.ctypes.data, dst.ctypes.data, np_h.ctypes.data, ep_h.ctypes.data, G, 7
+        b.triggers, b.probs, b.predictions, b.labels, b.n_clusters = none.ctypes.data, pr.ctypes.data, pred.ctypes.data, lab.ctypes.data, kk.ctypes.data
+        t = lib.gnncca_post_pool_submit(pool, C.byref(b))
+        cnt = C.c_int32(-1)
+        assert lib.gnncca_post_pool_wait(pool, t, None, C.byref(cnt)) == 0 and cnt.value == 0
+        assert np.array_equal(pred, pruned) and np.array_equal(lab, labels0) and int(kk[0]) == k0
+        assert lib.gnncca_post_pool_submit(pool, None) == -nat.ERR_INVALID_ARG
+    finally:
+        lib.gnncca_post_pool_destroy(pool)
+
+
 @pytest.mark.gpu
 def test_device_triggers_and_finalize_against_the_reference():
     """All golden frames as ONE batch (Batch.from_data_list layout): the device chain's trigger bits are exactly "a node with flow > 3" /
