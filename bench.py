@@ -330,6 +330,9 @@ def flat_evidence(res):
     if c4:
         put(c, "cfg4_graphs_per_rank", c4.get("graphs_per_rank"))
         put(c, "cfg4_ms", c4.get("ms_per_step"))
+        put(c, "cfg4_ms_eager", c4.get("ms_per_step_eager"))
+        put(c, "cfg4_ms_graph", c4.get("ms_per_step_graph"))
+        put(c, "cfg4_graph_equals_eager", c4.get("graph_equals_eager_bitwise"))
         put(c, "cfg4_edges_per_s", c4.get("value"))
         rr = c4.get("roofline_rank0") or {}
         put(r, "cfg4_step_frac", rr.get("frac"))
@@ -341,6 +344,9 @@ def flat_evidence(res):
         put(c, "share_ms", sh.get("ms_per_step"))
         put(c, "union_ms", sh.get("union_ms_per_step"))
         put(c, "projected_8gpu_speedup", sh.get("projected_8gpu_speedup"))
+        put(c, "share_ms_eager", sh.get("ms_per_step_eager"))
+        put(c, "share_ms_graph", sh.get("ms_per_step_graph"))
+        put(c, "projected_8gpu_speedup_eager", sh.get("projected_8gpu_speedup_eager"))
         put(c, "projected_8gpu_is", "a PROJECTION: union ms / share ms on ONE GPU, not an 8-GPU measurement")
         put(r, "share_enc_frac", sh.get("enc_frac"))
         put(r, "share_step_frac", sh.get("step_frac"))
@@ -588,9 +594,9 @@ def terrace_leg(device, args, batch=64, n_batches=16, cpu_budget_s=12.0):
     torch.cuda.synchronize()
     dt_final = time.perf_counter() - t0
     # ... and OVERLAPPED (round 6): FrameResult.final_async() hands batch k to the pipeline's pool of host threads behind one D2H copy on the
-    # pool's own stream -- no synchronisation -- while this loop enqueues batch k + 1's chain; a batch is collected two batches later.  Every
+    # pool's own stream -- no synchronisation -- while this loop enqueues batch k + 1's chain; a batch is collected three batches later.  Every
     # batch still ends with its FINAL host-side predictions / labels (what the reference's loop has after inference.py:345).
-    depth, pend, flagged_o, done_o = 2, [], 0, 0
+    depth, pend, flagged_o, done_o = 3, [], 0, 0
     for i in range(min(4, n_batches)):      # pool threads, pinned buffers, the copy stream: created on first use
         run(i)[3]["_keep"].final_async().result()
     torch.cuda.synchronize()
@@ -687,7 +693,7 @@ def terrace_leg(device, args, batch=64, n_batches=16, cpu_budget_s=12.0):
                                             "overlapped_host_threads": int(nat_threads(pipe)),
                                             "note": "ms_per_batch: FrameResult.final() per batch, one after the other (waits for the batch, host pass, results "
                                                     "uploaded again); overlapped_*: FrameResult.final_async(), batch k's host pass (pool of host threads, "
-                                                    "csrc/post_host.cpp) overlaps batch k + 1's GPU chain, results collected two batches later.  The synthetic "
+                                                    "csrc/post_host.cpp) overlaps batch k + 1's GPU chain, results collected three batches later.  The synthetic "
                                                     "model's predictions are near-random, so MOST frames raise a trigger here; a trained model's rarely do"},
             "stage_ms_per_batch_synchronised": {k: v / n_batches * 1e3 for k, v in stage.items()},
             "parity": {"ok": bool(checks) and all(c["ok"] for c in checks), "tolerance_abs": 1e-4, "batches": checks,
@@ -1114,6 +1120,27 @@ def main():
             steps4 = max(1, min(args.steps, 50))
             blocks4, res4 = timed_blocks(lambda: forward_sharded(m4, graphs4, rank, world, batch=batch4), steps4,
                                          min(args.warmup, 10), dist, device, args.backend, min_blocks=5, min_total_s=0.1)
+            t4_eager = blocks4[len(blocks4) // 2]
+            # the same forward as ONE HIP-graph replay per step (forward_sharded(..., graphed=GraphedForward): captured on the resident union's
+            # own tensors, no copies; bit for bit the eager logits).  Timed on every rank or on none (the capture's success is all-reduced).
+            gf4, t4_graph = None, None
+            try:
+                if rank == args.fail_capture_rank:
+                    raise RuntimeError("--fail-capture-rank: simulated capture failure on this rank")
+                gf4 = GraphedForward(m4, warmup=0)
+                if batch4 is not None:
+                    forward_sharded(m4, graphs4, rank, world, batch=batch4, graphed=gf4)
+            except Exception as exc:  # noqa: BLE001
+                print(f"[bench] config 4: HIP graph capture failed on rank {rank} ({type(exc).__name__}: {exc})", file=sys.stderr)
+                gf4 = None
+                torch.cuda.synchronize()
+            if agree_flag(gf4 is not None, dist, device, args.backend):
+                blocks4g, res4g = timed_blocks(lambda: forward_sharded(m4, graphs4, rank, world, batch=batch4, graphed=gf4), steps4,
+                                               min(args.warmup, 10), dist, device, args.backend, min_blocks=5, min_total_s=0.1)
+                t4_graph = blocks4g[len(blocks4g) // 2]
+                same4 = all(torch.equal(a_, b_) for ga, gb in zip(res4[2][:2], res4g[2][:2]) for a_, b_ in zip(ga, gb))
+                if t4_graph < t4_eager:
+                    blocks4, res4 = blocks4g, res4g
             t4 = blocks4[len(blocks4) // 2]
             ok4 = all(torch.isfinite(o).all().item() for g in res4[2][:2] for o in g)
             k4 = {}
@@ -1127,6 +1154,9 @@ def main():
                     "value": e4_total * steps4 / t4, "unit": "edges/s", "scaling": "strong", "n_gpus": world,
                     "graphs_per_rank": hi4 - lo4, "edges_rank0": e4_local, "steps": steps4, "blocks": len(blocks4),
                     "ms_per_step": t4 / steps4 * 1e3, "outputs_finite": bool(ok4),
+                    "ms_per_step_eager": t4_eager / steps4 * 1e3, "ms_per_step_graph": (t4_graph / steps4 * 1e3) if t4_graph else None,
+                    "graph_equals_eager_bitwise": bool(same4) if t4_graph else None,
+                    "mode": "graph: one HIP-graph replay per forward" if t4_graph and t4_graph < t4_eager else "eager",
                     "kernels_us_rank0": {k: float(np.mean(v)) * 1e3 for k, v in k4.items()}}
             if "step" in k4 and e4_local > 0:
                 # this rank's message steps against HBM: the step kernel at its config-4 operating point (batches of >= 16 384 nodes of
@@ -1153,7 +1183,18 @@ def main():
                 lo8, hi8, batch8 = shard_batch(graphs4, 0, 8)
                 blocks8, _ = timed_blocks(lambda: forward_sharded(m4, graphs4, 0, 8, batch=batch8), steps4, min(args.warmup, 10), None,
                                           device, args.backend, min_blocks=5, min_total_s=0.1)
-                t8 = blocks8[len(blocks8) // 2]
+                t8_eager = t8 = blocks8[len(blocks8) // 2]
+                t8_graph = None
+                if gf4 is not None:       # the share the same way as the union: one HIP-graph replay per forward
+                    try:
+                        forward_sharded(m4, graphs4, 0, 8, batch=batch8, graphed=gf4)
+                        blocks8g, _ = timed_blocks(lambda: forward_sharded(m4, graphs4, 0, 8, batch=batch8, graphed=gf4), steps4, min(args.warmup, 10),
+                                                   None, device, args.backend, min_blocks=5, min_total_s=0.1)
+                        t8_graph = blocks8g[len(blocks8g) // 2]
+                        t8 = min(t8, t8_graph)
+                    except Exception as exc:  # noqa: BLE001
+                        print(f"[bench] config 4 share: HIP graph capture failed ({type(exc).__name__}: {exc})", file=sys.stderr)
+                        torch.cuda.synchronize()
                 k8 = {}
                 for _ in range(5):
                     _, times8 = m4.forward_profiled(batch8)
@@ -1162,7 +1203,8 @@ def main():
                 share = {"workload": f"{hi8 - lo8} x dense128 graphs (E={batch8.edge_index.shape[1]}): rank 0's share of "
                                      f"{args.config4_graphs} graphs over 8 GPUs, run on this one GPU",
                          "ms_per_step": t8 / steps4 * 1e3, "union_ms_per_step": t4 / steps4 * 1e3,
-                         "projected_8gpu_speedup": t4 / t8, "target": 6.0,
+                         "ms_per_step_eager": t8_eager / steps4 * 1e3, "ms_per_step_graph": (t8_graph / steps4 * 1e3) if t8_graph else None,
+                         "projected_8gpu_speedup": t4 / t8, "projected_8gpu_speedup_eager": t4_eager / t8_eager, "target": 6.0,
                          "kernels_us": {k: float(np.mean(v)) * 1e3 for k, v in k8.items()},
                          "note": "projection from one-GPU measurements, not an 8-GPU measurement: every rank runs this share "
                                  "concurrently with no data-path collective"}
@@ -1170,7 +1212,7 @@ def main():
                 share.update(leg_fractions(share["kernels_us"], (hi8 - lo8) * 128, e8, share["ms_per_step"],
                                            float(np.mean(step_algorithmic_bytes(e8, 4, 3)))))
                 del batch8
-            del m4, graphs4, batch4, res4
+            del m4, graphs4, batch4, res4, gf4
 
         # per-kernel durations (HIP events attached to every dispatch; separate pass so the timed region is undisturbed)
         kernel_ms = {}

@@ -444,11 +444,7 @@ static int finalize_frame(const int64_t* src, const int64_t* dst, int64_t node_b
 // ---- the persistent pool ------------------------------------------------------------------------------------------------------------
 struct Job {
     gnncca_post_batch b;
-    hipEvent_t e_chain = nullptr, e_copy = nullptr;   // gnncca_post_pool_submit_copy's events (owned)
-    ~Job() {
-        if (e_chain) (void)hipEventDestroy(e_chain);
-        if (e_copy) (void)hipEventDestroy(e_copy);
-    }
+    hipEvent_t e_chain = nullptr, e_copy = nullptr;   // gnncca_post_pool_submit_copy's events (the pool's: returned to its free list by wait)
     std::vector<int32_t> flagged, k_new;
     std::atomic<int> next{0}, left{0}, status{GNNCCA_OK};
     int before = 0;
@@ -473,6 +469,7 @@ struct gnncca_post_pool {
     int64_t next_ticket = 0;
     bool stop = false;
     std::unordered_map<int, hipStream_t> copy_streams;   // device -> the pool's own D2H stream (gnncca_post_pool_submit_copy)
+    std::vector<hipEvent_t> free_events;                 // recycled (creating and destroying two events per batch cost 4 us of the caller's thread)
 
     void finish(Job* j) {
         {
@@ -603,7 +600,7 @@ int gnncca_post_finalize_frames_host(const int64_t* src, const int64_t* dst, con
 }
 
 gnncca_post_pool* gnncca_post_pool_create(int32_t n_threads) {
-    int nt = n_threads > 0 ? n_threads : (int)std::min(12u, std::max(1u, std::thread::hardware_concurrency() > 2 ? std::thread::hardware_concurrency() - 2 : 1u));
+    int nt = n_threads > 0 ? n_threads : (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency() > 2 ? std::thread::hardware_concurrency() - 2 : 1u));
     nt = std::min(nt, 64);
     gnncca_post_pool* p = new (std::nothrow) gnncca_post_pool();
     if (!p) return nullptr;
@@ -628,6 +625,11 @@ void gnncca_post_pool_destroy(gnncca_post_pool* pool) {
     for (auto& t : pool->threads)
         if (t.joinable()) t.join();   // (queued tasks are drained first: loop() leaves only on an empty queue)
     for (auto& kv : pool->copy_streams) (void)hipStreamDestroy(kv.second);
+    for (hipEvent_t e : pool->free_events) (void)hipEventDestroy(e);
+    for (auto& kv : pool->jobs) {   // (tickets nobody collected)
+        if (kv.second->e_chain) (void)hipEventDestroy(kv.second->e_chain);
+        if (kv.second->e_copy) (void)hipEventDestroy(kv.second->e_copy);
+    }
     delete pool;
 }
 
@@ -669,7 +671,15 @@ int64_t gnncca_post_pool_submit_copy(gnncca_post_pool* pool, const gnncca_post_b
         auto ins = pool->copy_streams.emplace(device, cs);
         if (!ins.second) (void)hipStreamDestroy(cs), cs = ins.first->second;
     }
-    if (hipEventCreateWithFlags(&j->e_chain, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&j->e_copy, hipEventDisableTiming) != hipSuccess)
+    {
+        std::lock_guard<std::mutex> g(pool->m);
+        if (pool->free_events.size() >= 2) {
+            j->e_chain = pool->free_events.back(), pool->free_events.pop_back();
+            j->e_copy = pool->free_events.back(), pool->free_events.pop_back();
+        }
+    }
+    if (!j->e_chain && (hipEventCreateWithFlags(&j->e_chain, hipEventDisableTiming) != hipSuccess ||
+                        hipEventCreateWithFlags(&j->e_copy, hipEventDisableTiming) != hipSuccess))
         return -(int64_t)GNNCCA_ERR_HIP;
     if (hipEventRecord(j->e_chain, static_cast<hipStream_t>(stream)) != hipSuccess || hipStreamWaitEvent(cs, j->e_chain, 0) != hipSuccess ||
         hipMemcpyAsync(host_dst, device_src, nbytes, hipMemcpyDeviceToHost, cs) != hipSuccess || hipEventRecord(j->e_copy, cs) != hipSuccess)
@@ -714,6 +724,8 @@ int gnncca_post_pool_wait(gnncca_post_pool* pool, int64_t ticket, int32_t* frame
         for (size_t i = 0; i < j->flagged.size(); ++i) frames_out[i] = j->flagged[i];
     {
         std::lock_guard<std::mutex> g(pool->m);
+        if (j->e_chain) pool->free_events.push_back(j->e_chain), j->e_chain = nullptr;
+        if (j->e_copy) pool->free_events.push_back(j->e_copy), j->e_copy = nullptr;
         pool->jobs.erase(ticket);
     }
     return st;

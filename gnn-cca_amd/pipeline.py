@@ -54,15 +54,21 @@ class PendingFinal:
 
     def result(self, copy=True):
         if self._res is None:
-            g = self._views["triggers"].shape[0]
+            host, start, off, n, e, g = self._views
             frames, count = np.empty(max(g, 1), dtype=np.int32), C.c_int32(0)
             st = nat.lib().gnncca_post_pool_wait(self._pipe._pool_handle(), self._ticket, frames.ctypes.data, C.byref(count))
             self._keep = None      # the device buffers may go: everything is on the host now
             if st:
                 nat.check(st, "gnncca_post_pool_wait")
-            v = self._views
-            self._res = {"predictions": v["pruned"], "labels": v["labels"], "n_clusters": int(v["n_clusters"][0]),
-                         "frames_finalized": frames[:count.value].tolist(), "triggers": v["triggers"]}
+            hn = host.numpy()
+
+            def view(key, dtype, cnt):
+                o = off[key] - start
+                return hn[o:o + cnt * np.dtype(dtype).itemsize].view(dtype)
+
+            self._res = {"predictions": view("pruned", np.int64, e), "labels": view("labels", np.int32, n),
+                         "n_clusters": int(view("n_clusters", np.int32, 1)[0]),
+                         "frames_finalized": frames[:count.value].tolist(), "triggers": view("triggers", np.int32, g)}
         if not copy:
             return self._res
         return {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in self._res.items()}
@@ -140,7 +146,7 @@ class FramePipeline:
         self._sizes = (0, 0)
         self._pool = None    # gnncca_post_pool (created on the first final_async)
         self._pinned = {}    # bytes (power of two) -> free pinned host buffers of that size
-        self.host_threads = 0   # 0: the library's default (hardware threads - 2, at most 12)
+        self.host_threads = 0   # 0: the library's default (hardware threads - 2, at most 16)
 
     def _pool_handle(self):
         if self._pool is None:
@@ -178,14 +184,7 @@ class FramePipeline:
         nbytes = end - start
         host = self._take_pinned(nbytes)
         hp = host.data_ptr()
-        hn = host.numpy()
-
-        def view(key, dtype, count):
-            o = off[key] - start
-            return hn[o:o + count * np.dtype(dtype).itemsize].view(dtype)
-
-        views = {"probs": view("probs", np.float32, e), "src": view("edge_index", np.int64, e), "pruned": view("pruned", np.int64, e),
-                 "triggers": view("triggers", np.int32, g), "labels": view("labels", np.int32, n), "n_clusters": view("n_clusters", np.int32, 1)}
+        views = (host, start, off, n, e, g)      # numpy views are made when the result is collected
         node_ptr, edge_ptr = np.asarray(r.batch.node_ptr, dtype=np.int32), np.asarray(r.batch.edge_ptr, dtype=np.int32)
         b = nat.PostBatch()
         b.src, b.dst = hp + off["edge_index"] - start, hp + off["edge_index"] - start + 8 * e

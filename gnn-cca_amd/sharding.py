@@ -131,10 +131,15 @@ def shard_batch(graphs, rank, world):
     return lo, hi, union_graphs(graphs[lo:hi])
 
 
-def forward_sharded(model, graphs, rank, world, batch=None):
+def forward_sharded(model, graphs, rank, world, batch=None, graphed=None):
     """Run this rank's share of `graphs` (see shard_batch; pass the `batch` it returned to reuse a union that is already
     resident instead of concatenating again).  No collective: every rank runs the ordinary single-GPU forward on its own
-    union.  Returns (lo, hi, per-graph logits: list over this rank's graphs of list over classified steps)."""
+    union.  Returns (lo, hi, per-graph logits: list over this rank's graphs of list over classified steps).
+
+    `graphed`: a gnn_cca_amd.inference.GraphedForward of `model` -- with a resident `batch` the rank's forward is then ONE replay of a HIP
+    graph captured on that union's own tensors (`GraphedForward.block([batch], adopt_inputs=True)`: no copies; the producer overwrites
+    the union in place between replays), the same kernels with the same arguments as the eager call, bit for bit its logits.  The
+    returned views are the graph's static outputs: valid until the next replay."""
     if batch is None:
         lo, hi, batch = shard_batch(graphs, rank, world)
     else:
@@ -143,5 +148,8 @@ def forward_sharded(model, graphs, rank, world, batch=None):
             raise ValueError(f"batch holds {len(batch.node_ptr) - 1} graphs, this rank's share is [{lo}, {hi})")
     if batch is None:
         return lo, hi, []
-    out = model(batch)
+    if graphed is not None:
+        out = graphed.block([batch], adopt_inputs=True).replay()[0]
+    else:
+        out = model(batch)
     return lo, hi, split_logits(out, batch)

@@ -337,7 +337,7 @@ GNNCCA_API int gnncca_post_finalize_frames_host(const int64_t* src, const int64_
  * frame).  gnncca_post_pool_submit returns a ticket >= 0 (or -status); gnncca_post_pool_wait blocks until that batch is final, writes
  * the finalized frame ids to frames_out [<= G] / their number to *n_frames_out (either may be null), releases the ticket and returns
  * the first non-zero status of any frame.  The buffers must stay valid until the wait returns.  n_threads 0 = hardware threads - 2,
- * at most 12. */
+ * at most 16. */
 typedef struct gnncca_post_pool gnncca_post_pool;
 typedef struct gnncca_post_batch {
     const int64_t* src;

@@ -232,3 +232,32 @@ def test_refusals():
     empty.x, empty.edge_index, empty.edge_attr = d.x, d.edge_index[:, :0].contiguous(), d.edge_attr[:0].contiguous()
     out = gf(empty)["classified_edges"]
     assert all(t.shape == (0, 1) for t in out)
+
+
+def test_sharded_forward_as_one_graph_replay_per_step():
+    """sharding.forward_sharded(..., graphed=GraphedForward): a rank's resident union replayed as ONE HIP graph captured on the union's own
+    tensors -- bit for bit the eager forward_sharded, replay after replay, and a union overwritten IN PLACE is seen by the next replay
+    (no copies, no stale inputs).  Two shares of one sequence through one GraphedForward (what bench.py's config-4 legs do)."""
+    from gnn_cca_amd.inference import GraphedForward
+    from gnn_cca_amd.sharding import forward_sharded, shard_batch
+    m, *_ = _model("dense64")
+    graphs = []
+    for g, n in enumerate((24, 64, 33, 64, 12, 40, 64, 50)):
+        d = _dense(n, 100 + g)
+        graphs.append((d.x, d.edge_index, d.edge_attr))
+    gf = GraphedForward(m, warmup=0)
+    with torch.no_grad():
+        for rank, world in ((0, 1), (1, 3)):
+            lo, hi, batch = shard_batch(graphs, rank, world)
+            want = [[t.clone() for t in steps] for steps in forward_sharded(m, graphs, rank, world, batch=batch)[2]]
+            for _ in range(3):
+                lo2, hi2, got = forward_sharded(m, graphs, rank, world, batch=batch, graphed=gf)
+                assert (lo2, hi2) == (lo, hi) and len(got) == hi - lo
+                for a, b in zip(got, want):
+                    _eq(a, b)
+            batch.edge_attr.mul_(0.5)              # the producer overwrites the resident union in place
+            want2 = [[t.clone() for t in steps] for steps in forward_sharded(m, graphs, rank, world, batch=batch)[2]]
+            _, _, got2 = forward_sharded(m, graphs, rank, world, batch=batch, graphed=gf)
+            for a, b, c in zip(got2, want2, want):
+                _eq(a, b)
+                assert not torch.equal(b[-1], c[-1])
