@@ -40,20 +40,59 @@ def build_f16_ablations(verbose=False):
     return build(force=True, verbose=verbose, out=os.path.join(LIB_DIR, "libgnncca_mpn_f16abl.so"), defs=["-DGNNCCA_F16_ABLATIONS"])
 
 
+def _deps(src_path):
+    """The quoted includes of a source, transitively (csrc/ and include/): what its object file has to be newer than."""
+    import re
+    seen, todo = set(), [src_path]
+    while todo:
+        f = todo.pop()
+        if f in seen or not os.path.exists(f):
+            continue
+        seen.add(f)
+        for inc in re.findall(r'^\s*#\s*include\s+"([^"]+)"', open(f).read(), flags=re.M):
+            for base in (CSRC, os.path.join(ROOT, "include")):
+                cand = os.path.join(base, inc)
+                if os.path.exists(cand):
+                    todo.append(cand)
+    return seen
+
+
 def build(force=False, verbose=False, out=None, defs=()):
+    """One object per source (lib/obj/, rebuilt when the source, one of ITS includes or this script is newer), then the link: a change to
+    the host-side sources does not recompile the 90-second kernel translation unit."""
     if out is None and not force and not needs_build():
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
     out = out or LIB_PATH
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-x", "hip",
-           "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-Wall", "-Wno-unused-function",
-           "-fvisibility=hidden", "-DGNNCCA_BUILD",
-           # keep MFMA accumulators in VGPRs: the step kernels post-process every accumulator element on the VALU
-           # (ReLU + segment sum), and AGPR results would cost one v_accvgpr_read per element
-           "-mllvm", "-amdgpu-mfma-vgpr-form"]
-    cmd += list(defs)
-    cmd += [os.path.join(CSRC, s) for s in SOURCES]
-    cmd += ["-o", out + ".tmp"]
+    tag = "".join(sorted(defs)).replace("-D", "_") if defs else ""
+    obj_dir = os.path.join(LIB_DIR, "obj" + tag)
+    os.makedirs(obj_dir, exist_ok=True)
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip",
+             "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-Wall", "-Wno-unused-function",
+             "-fvisibility=hidden", "-DGNNCCA_BUILD",
+             # keep MFMA accumulators in VGPRs: the step kernels post-process every accumulator element on the VALU
+             # (ReLU + segment sum), and AGPR results would cost one v_accvgpr_read per element
+             "-mllvm", "-amdgpu-mfma-vgpr-form"] + list(defs)
+    objs, procs = [], []
+    for src in SOURCES:
+        sp = os.path.join(CSRC, src)
+        obj = os.path.join(obj_dir, src + ".o")
+        objs.append(obj)
+        newest = max(os.path.getmtime(d) for d in _deps(sp) | {os.path.abspath(__file__)})
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < newest:
+            cmd = [_hipcc()] + flags + ["-c", sp, "-o", obj + ".tmp"]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            procs.append((subprocess.Popen(cmd), obj))
+    failed = False
+    for pr, obj in procs:       # the sources compile side by side
+        if pr.wait() != 0:
+            failed = True
+        else:
+            os.replace(obj + ".tmp", obj)
+    if failed:
+        raise subprocess.CalledProcessError(1, "hipcc -c")
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", out + ".tmp"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)

@@ -104,10 +104,9 @@ struct Solver {
     // bridges
     std::vector<int> u_ptr, u_adj, u_cur, disc, low, parent, stack;
     // rounding / splitting
-    std::vector<int> fo, fi, act, act2, remove, ids, count;
+    std::vector<int> fo, fi, act, remove, ids, count;
     std::vector<char> on_bridge;
-    std::vector<Pred> pool;                                    // Pred buffers by nesting level
-    Pred work, tmp;
+    Pred work;
 
     bool load(const int64_t* src, const int64_t* dst, int64_t base, int64_t n_nodes, int64_t n_edges, const float* p) {
         n = (int)n_nodes, E = (int)n_edges, probs = p;
@@ -124,12 +123,6 @@ struct Solver {
         g_cur.assign(out_ptr.begin(), out_ptr.end() - 1), u_cur.assign(in_ptr.begin(), in_ptr.end() - 1);
         for (int k = 0; k < E; ++k) out_idx[g_cur[eu[k]]++] = k, in_idx[u_cur[ev[k]]++] = k;
         return true;
-    }
-
-    void active_edges(const Pred& p, std::vector<int>& a) const {
-        a.clear();
-        for (int k = 0; k < E; ++k)
-            if (p[k] == 1) a.push_back(k);
     }
 
     void digraph(const std::vector<int>& a) {
@@ -275,20 +268,29 @@ struct Solver {
         }
     }
 
-    // utils.remove_edges_single_direction: an active edge survives iff its reverse is active too (out may alias nothing of p)
-    void prune(const Pred& p, Pred& out) {
-        pairs.reset(n);
-        for (int k = 0; k < E; ++k)
-            if (p[k] == 1) pairs.insert(eu[k], ev[k]);
-        out = p;
-        for (int k = 0; k < E; ++k)
-            if (p[k] == 1 && !pairs.has(ev[k], eu[k])) out[k] = 0;
+    // Every routine below works on the LIST of active edges (`a`, ascending edge ids: the order the reference's np.nonzero / list
+    // comprehensions produce) next to the 0 / 1 vector `p`; an edge that goes is zeroed in `p` and the list is compacted -- a frame has 343
+    // edges and ~70 active ones, and the heuristics' loops run tens of rounds (the first version re-scanned all E edges eight times a round).
+    void compact(const Pred& p, std::vector<int>& a) const {
+        size_t w = 0;
+        for (size_t i = 0; i < a.size(); ++i)
+            if (p[a[i]] == 1) a[w++] = a[i];
+        a.resize(w);
     }
 
-    void flows(const Pred& p) {
+    // utils.remove_edges_single_direction, in place: an active edge survives iff its reverse is active too
+    void prune(Pred& p, std::vector<int>& a) {
+        pairs.reset(n);
+        for (int k : a) pairs.insert(eu[k], ev[k]);
+        bool any = false;
+        for (int k : a)
+            if (!pairs.has(ev[k], eu[k])) p[k] = 0, any = true;
+        if (any) compact(p, a);
+    }
+
+    void flows(const std::vector<int>& a) {
         fo.assign(n, 0), fi.assign(n, 0);
-        for (int k = 0; k < E; ++k)
-            if (p[k] == 1) fo[eu[k]]++, fi[ev[k]]++;
+        for (int k : a) fo[eu[k]]++, fi[ev[k]]++;
     }
     bool violated() const {
         for (int v = 0; v < n; ++v)
@@ -296,16 +298,15 @@ struct Solver {
         return false;
     }
 
-    // utils.compute_rounding on `p` in place; false where the reference returns [] (no node with flow > 3: the caller keeps its predictions)
-    bool rounding(Pred& p) {
-        flows(p);
+    // utils.compute_rounding on (p, a) in place; false where the reference returns [] (no node with flow > 3: the caller keeps its predictions)
+    bool rounding(Pred& p, std::vector<int>& a) {
+        flows(a);
         if (!violated()) return false;
-        active_edges(p, act);
-        bridge_set(act);                                        // of the graph the call came with, every round
+        bridge_set(a);                                          // of the graph the call came with, every round
         const bool have_bridges = !bridge_list.empty();
         if (have_bridges) {
-            on_bridge.resize(E);
-            for (int k = 0; k < E; ++k) on_bridge[k] = (char)bridge_tab.has(eu[k], ev[k]);
+            on_bridge.assign(E, 0);
+            for (int k : a) on_bridge[k] = (char)bridge_tab.has(eu[k], ev[k]);
         }
         for (;;) {
             remove.clear();
@@ -334,7 +335,8 @@ struct Solver {
                     }
             }
             for (int k : remove) p[k] = 0;
-            flows(p);
+            compact(p, a);
+            flows(a);
             if (!violated()) return true;
         }
     }
@@ -350,9 +352,10 @@ struct Solver {
         return -1;
     }
 
-    // one removal round of utils.disjoint_big_clusters on `cur` (in place): the weakest bridge of the frame, or -- with no bridge anywhere --
-    // the weakest active edge touching label `lab`; EVERY edge with that probability goes.  false: nothing to remove.
-    bool remove_weakest(Pred& cur, const std::vector<int>& a, const std::vector<int>& lab_of, int lab) {
+    // one removal round of utils.disjoint_big_clusters on (cur, a), in place: the weakest bridge of the frame, or -- with no bridge anywhere --
+    // the weakest active edge touching label `lab`; EVERY edge with that probability goes (the reference zeroes inactive edges of that
+    // probability too: they are 0 already).  false: nothing to remove.
+    bool remove_weakest(Pred& cur, std::vector<int>& a, const std::vector<int>& lab_of, int lab) {
         bridge_set(a);
         float mn = 0.f;
         bool have = false;
@@ -370,33 +373,28 @@ struct Solver {
                     if (!have || probs[k] < mn) mn = probs[k], have = true;
         }
         if (!have) return false;   // the reference would raise on an empty minimum; unreachable with a cluster of five
-        for (int k = 0; k < E; ++k)
+        for (int k : a)
             if (probs[k] == mn) cur[k] = 0;
+        compact(cur, a);
         return true;
     }
 
-    // utils.disjoint_big_clusters on `pred` with the labelling `ids` (both in / out): afterwards `pred` is the reference's RETURN value.  The
-    // reference modifies its argument in place until its first pruning makes a new object, and recurses once the big cluster is down to four
-    // members -- dropping the recursive call's return value, so that of the recursion only its first in-place removal (on the caller's
+    // utils.disjoint_big_clusters on (pred, a) with the labelling `ids` (all in / out): afterwards `pred` is the reference's RETURN value.
+    // The reference modifies its argument in place until its first pruning makes a new object, and recurses once the big cluster is down to
+    // four members -- dropping the recursive call's return value, so that of the recursion only its first in-place removal (on the caller's
     // current object) survives: that removal is all that is evaluated here.
-    void split_big_clusters(Pred& pred) {
-        int lab = big_label(ids);
+    void split_big_clusters(Pred& pred, std::vector<int>& a) {
+        const int lab = big_label(ids);
         if (lab < 0) return;
         for (;;) {
-            active_edges(pred, act);
-            if (!remove_weakest(pred, act, ids, lab)) return;
-            active_edges(pred, act);
-            cluster_ids(act, ids);
+            if (!remove_weakest(pred, a, ids, lab)) return;
+            cluster_ids(a, ids);
             int members = 0;
             for (int v : ids) members += v == lab;
-            prune(pred, tmp);
-            pred.swap(tmp);
+            prune(pred, a);
             if (members <= 4) {
                 const int lab2 = big_label(ids);                // the recursive call: its first removal round, in place, nothing else
-                if (lab2 >= 0) {
-                    active_edges(pred, act);
-                    (void)remove_weakest(pred, act, ids, lab2);
-                }
+                if (lab2 >= 0) (void)remove_weakest(pred, a, ids, lab2);
                 return;
             }
         }
@@ -416,17 +414,23 @@ static int finalize_frame(const int64_t* src, const int64_t* dst, int64_t node_b
     if (!s.load(src, dst, node_base, n_nodes, n_edges, probs)) return GNNCCA_ERR_INVALID_ARG;
     Pred& pred = s.work;
     pred.assign(predictions, predictions + n_edges);
+    std::vector<int>& act = s.act;
+    act.clear();
+    for (int k = 0; k < s.E; ++k) {
+        if (pred[k] == 1)
+            act.push_back(k);
+        else if (pred[k] != 0)
+            return GNNCCA_ERR_INVALID_ARG;   // thresholded predictions are 0 / 1 (inference.py:291)
+    }
     const bool do_round = (switches & GNNCCA_POST_ROUNDING) != 0, do_prune = (switches & GNNCCA_POST_PRUNING) != 0,
                do_split = (switches & GNNCCA_POST_SPLITTING) != 0;
-    if (do_prune) s.prune(pred, s.tmp), pred.swap(s.tmp);
-    if (do_round) (void)s.rounding(pred);
-    if (do_prune) s.prune(pred, s.tmp), pred.swap(s.tmp);
-    s.active_edges(pred, s.act2);
-    int k = s.cluster_ids(s.act2, s.ids);
+    if (do_prune) s.prune(pred, act);
+    if (do_round) (void)s.rounding(pred, act);
+    if (do_prune) s.prune(pred, act);
+    int k = s.cluster_ids(act, s.ids);
     if (do_split) {
-        s.split_big_clusters(pred);
-        s.active_edges(pred, s.act2);
-        k = s.cluster_ids(s.act2, s.ids);
+        s.split_big_clusters(pred, act);
+        k = s.cluster_ids(act, s.ids);
     }
     for (int e = 0; e < s.E; ++e) predictions[e] = pred[e];
     if (id_pred_out)
@@ -678,8 +682,10 @@ int64_t gnncca_post_pool_submit_copy(gnncca_post_pool* pool, const gnncca_post_b
             j->e_copy = pool->free_events.back(), pool->free_events.pop_back();
         }
     }
+    // (e_copy is what a pool thread waits on: GNNCCA_POOL_BLOCKING=1 under GNNCCA_DIAG makes that wait a sleep instead of a spin)
+    static const bool blocking = gnncca::diag_env("GNNCCA_POOL_BLOCKING") != nullptr;
     if (!j->e_chain && (hipEventCreateWithFlags(&j->e_chain, hipEventDisableTiming) != hipSuccess ||
-                        hipEventCreateWithFlags(&j->e_copy, hipEventDisableTiming) != hipSuccess))
+                        hipEventCreateWithFlags(&j->e_copy, hipEventDisableTiming | (blocking ? hipEventBlockingSync : 0)) != hipSuccess))
         return -(int64_t)GNNCCA_ERR_HIP;
     if (hipEventRecord(j->e_chain, static_cast<hipStream_t>(stream)) != hipSuccess || hipStreamWaitEvent(cs, j->e_chain, 0) != hipSuccess ||
         hipMemcpyAsync(host_dst, device_src, nbytes, hipMemcpyDeviceToHost, cs) != hipSuccess || hipEventRecord(j->e_copy, cs) != hipSuccess)

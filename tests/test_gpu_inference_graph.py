@@ -254,10 +254,10 @@ def test_sharded_forward_as_one_graph_replay_per_step():
                 lo2, hi2, got = forward_sharded(m, graphs, rank, world, batch=batch, graphed=gf)
                 assert (lo2, hi2) == (lo, hi) and len(got) == hi - lo
                 for a, b in zip(got, want):
-                    _eq(a, b)
+                    assert _eq(a, b)
             batch.edge_attr.mul_(0.5)              # the producer overwrites the resident union in place
             want2 = [[t.clone() for t in steps] for steps in forward_sharded(m, graphs, rank, world, batch=batch)[2]]
             _, _, got2 = forward_sharded(m, graphs, rank, world, batch=batch, graphed=gf)
             for a, b, c in zip(got2, want2, want):
-                _eq(a, b)
+                assert _eq(a, b)
                 assert not torch.equal(b[-1], c[-1])
