@@ -593,10 +593,10 @@ def terrace_leg(device, args, batch=64, n_batches=16, cpu_budget_s=12.0):
         flagged += len(post["_keep"].final()["frames_finalized"])
     torch.cuda.synchronize()
     dt_final = time.perf_counter() - t0
-    # ... and OVERLAPPED (round 6): FrameResult.final_async() hands batch k to the pipeline's pool of host threads behind one D2H copy on the
-    # pool's own stream -- no synchronisation -- while this loop enqueues batch k + 1's chain; a batch is collected three batches later.  Every
+    # ... and OVERLAPPED (round 6): FrameResult.final_async() hands batch k to the pipeline's pool of host threads behind one D2H copy enqueued
+    # behind the chain -- no synchronisation -- while this loop enqueues batch k + 1's chain; a batch is collected four batches later.  Every
     # batch still ends with its FINAL host-side predictions / labels (what the reference's loop has after inference.py:345).
-    depth, pend, flagged_o, done_o = 3, [], 0, 0
+    depth, pend, flagged_o, done_o = 4, [], 0, 0
     for i in range(min(4, n_batches)):      # pool threads, pinned buffers, the copy stream: created on first use
         run(i)[3]["_keep"].final_async().result()
     torch.cuda.synchronize()
@@ -693,7 +693,7 @@ def terrace_leg(device, args, batch=64, n_batches=16, cpu_budget_s=12.0):
                                             "overlapped_host_threads": int(nat_threads(pipe)),
                                             "note": "ms_per_batch: FrameResult.final() per batch, one after the other (waits for the batch, host pass, results "
                                                     "uploaded again); overlapped_*: FrameResult.final_async(), batch k's host pass (pool of host threads, "
-                                                    "csrc/post_host.cpp) overlaps batch k + 1's GPU chain, results collected three batches later.  The synthetic "
+                                                    "csrc/post_host.cpp) overlaps batch k + 1's GPU chain, results collected four batches later.  The synthetic "
                                                     "model's predictions are near-random, so MOST frames raise a trigger here; a trained model's rarely do"},
             "stage_ms_per_batch_synchronised": {k: v / n_batches * 1e3 for k, v in stage.items()},
             "parity": {"ok": bool(checks) and all(c["ok"] for c in checks), "tolerance_abs": 1e-4, "batches": checks,

@@ -119,6 +119,7 @@ _SIGNATURES = {
     "gnncca_post_pool_submit": (C.c_int64, [C.c_void_p, C.POINTER(PostBatch)]),
     "gnncca_post_pool_submit_copy": (C.c_int64, [C.c_void_p, C.POINTER(PostBatch), C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p]),
     "gnncca_post_pool_wait": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "gnncca_post_pool_wait_timed": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gnncca_backward_supported": (C.c_int, [C.POINTER(MpnDims)]),
     "gnncca_backward_workspace_bytes": (C.c_size_t, [C.POINTER(MpnDims), C.c_int64, C.c_int64]),
     "gnncca_mpn_backward": (C.c_int, [C.POINTER(MpnDims), C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,

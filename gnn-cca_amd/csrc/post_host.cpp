@@ -28,6 +28,7 @@
 // pool finalizes them while the caller enqueues the next batch's GPU chain.
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdint>
 #include <cstring>
@@ -448,14 +449,17 @@ static int finalize_frame(const int64_t* src, const int64_t* dst, int64_t node_b
 // ---- the persistent pool ------------------------------------------------------------------------------------------------------------
 struct Job {
     gnncca_post_batch b;
-    hipEvent_t e_chain = nullptr, e_copy = nullptr;   // gnncca_post_pool_submit_copy's events (the pool's: returned to its free list by wait)
+    hipEvent_t e_copy = nullptr;   // gnncca_post_pool_submit_copy's event (the pool's: returned to its free list by wait)
     std::vector<int32_t> flagged, k_new;
     std::atomic<int> next{0}, left{0}, status{GNNCCA_OK};
     int before = 0;
     bool done = false;
+    double t_submit = 0, t_head = 0, t_event = 0, t_done = 0;   // microseconds on the steady clock (gnncca_post_pool_wait_timed)
     std::mutex m;
     std::condition_variable cv;
 };
+
+static double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 struct Task {
     std::shared_ptr<Job> job;   // (a queued or running task keeps its job alive: the waiter may collect the ticket while helpers are still leaving)
@@ -472,12 +476,14 @@ struct gnncca_post_pool {
     std::unordered_map<int64_t, std::shared_ptr<Job>> jobs;
     int64_t next_ticket = 0;
     bool stop = false;
-    std::unordered_map<int, hipStream_t> copy_streams;   // device -> the pool's own D2H stream (gnncca_post_pool_submit_copy)
-    std::vector<hipEvent_t> free_events;                 // recycled (creating and destroying two events per batch cost 4 us of the caller's thread)
+    std::atomic<int> queued{0};            // tasks in the queue (what a spinning thread polls without the mutex)
+    std::atomic<bool> stop_flag{false};
+    std::vector<hipEvent_t> free_events;   // recycled (creating and destroying events per batch cost microseconds of the caller's thread)
 
     void finish(Job* j) {
         {
             std::lock_guard<std::mutex> g(j->m);
+            j->t_done = now_us();
             j->done = true;
         }
         j->cv.notify_all();
@@ -509,6 +515,7 @@ struct gnncca_post_pool {
     void head(const std::shared_ptr<Job>& jp) {
         Job* j = jp.get();
         gnncca_post_batch& b = j->b;
+        j->t_head = now_us();
         if (b.ready_event) {
             (void)hipSetDevice(b.device);
             if (hipEventSynchronize(static_cast<hipEvent_t>(b.ready_event)) != hipSuccess) {
@@ -517,6 +524,7 @@ struct gnncca_post_pool {
                 return;
             }
         }
+        j->t_event = now_us();
         const int want = ((b.switches & GNNCCA_POST_ROUNDING) ? GNNCCA_POST_TRIGGER_ROUNDING : 0) |
                          ((b.switches & GNNCCA_POST_SPLITTING) ? GNNCCA_POST_TRIGGER_SPLITTING : 0);
         for (int32_t g = 0; g < b.n_frames; ++g)
@@ -530,26 +538,42 @@ struct gnncca_post_pool {
             for (int32_t g : j->flagged)
                 for (int32_t v = b.node_ptr[g]; v < b.node_ptr[g + 1]; ++v) j->before += b.labels[v] == v;
         j->left.store((int)j->flagged.size());
-        const int helpers = std::min<int>((int)j->flagged.size(), (int)threads.size()) - 1;
+        // helpers: one per `chunk` flagged frames, not one per thread -- waking a sleeping thread costs 50-100 us on the GPU boxes' hosts, a
+        // frame 10 us: sixteen helpers for 58 frames spent 175 us, most of it waiting for each other to wake (tools/time_final_async.py)
+        static const int chunk = gnncca::diag_env_int("GNNCCA_POOL_CHUNK", 12, 1, 1 << 20);
+        const int helpers = std::min<int>(((int)j->flagged.size() + chunk - 1) / chunk, (int)threads.size()) - 1;
         if (helpers > 0) {
             {
                 std::lock_guard<std::mutex> g(m);
                 for (int h = 0; h < helpers; ++h) tasks.push_back(Task{jp, false});
+                queued.fetch_add(helpers);
             }
-            cv.notify_all();
+            for (int h = 0; h < helpers; ++h) cv.notify_one();
         }
         frames_of(j);
     }
 
     void loop() {
+        static const int spin_us = gnncca::diag_env_int("GNNCCA_POOL_SPIN_US", 60, 0, 100000);
         for (;;) {
             Task t;
             {
+                // a thread that has just finished a task looks for the next one for a few tens of microseconds before it goes to sleep:
+                // in a running pipeline the next batch's tasks arrive within that time, and the wake-up is what a job's latency is made of
+                if (spin_us > 0 && queued.load(std::memory_order_relaxed) == 0) {
+                    const double until = now_us() + spin_us;
+                    while (queued.load(std::memory_order_relaxed) == 0 && !stop_flag.load(std::memory_order_relaxed) && now_us() < until) {
+#if defined(__x86_64__)
+                        __builtin_ia32_pause();
+#endif
+                    }
+                }
                 std::unique_lock<std::mutex> g(m);
                 cv.wait(g, [&] { return stop || !tasks.empty(); });
                 if (tasks.empty()) return;   // (stop, and nothing left to do)
                 t = tasks.front();
                 tasks.pop_front();
+                queued.fetch_sub(1);
             }
             if (t.head)
                 head(t.job);
@@ -624,14 +648,13 @@ void gnncca_post_pool_destroy(gnncca_post_pool* pool) {
     {
         std::lock_guard<std::mutex> g(pool->m);
         pool->stop = true;
+        pool->stop_flag.store(true);
     }
     pool->cv.notify_all();
     for (auto& t : pool->threads)
         if (t.joinable()) t.join();   // (queued tasks are drained first: loop() leaves only on an empty queue)
-    for (auto& kv : pool->copy_streams) (void)hipStreamDestroy(kv.second);
     for (hipEvent_t e : pool->free_events) (void)hipEventDestroy(e);
     for (auto& kv : pool->jobs) {   // (tickets nobody collected)
-        if (kv.second->e_chain) (void)hipEventDestroy(kv.second->e_chain);
         if (kv.second->e_copy) (void)hipEventDestroy(kv.second->e_copy);
     }
     delete pool;
@@ -644,52 +667,43 @@ static bool batch_ok(const gnncca_post_batch* batch) {
 
 static int64_t enqueue(gnncca_post_pool* pool, std::shared_ptr<Job> j) {
     int64_t ticket;
+    j->t_submit = now_us();
     {
         std::lock_guard<std::mutex> g(pool->m);
         ticket = pool->next_ticket++;
         pool->tasks.push_back(Task{j, true});
+        pool->queued.fetch_add(1);
         pool->jobs.emplace(ticket, std::move(j));
     }
     pool->cv.notify_one();
     return ticket;
 }
 
-// submit for results that still sit in DEVICE memory: an event on `stream` (the stream the batch's chain was enqueued on), the pool's own
-// copy stream waits for it, copies `nbytes` from device_src to host_dst (pinned) and records the event the job waits for.  One call, no
-// synchronisation; `batch` points into host_dst.
+// submit for results that still sit in DEVICE memory: the D2H copy of `nbytes` from device_src to host_dst (pinned) is enqueued on `stream`
+// itself -- the stream the batch's chain was enqueued on -- with the event the job waits for right behind it.  One call, no synchronisation;
+// `batch` points into host_dst.  (The first version copied on a stream of the pool's own behind an event: one event and one cross-stream wait
+// more per batch, and in a process that already uses several streams the new stream shares a hardware queue with one of them -- this device
+// maps streams onto four queues -- so the copy queued up behind LATER batches' kernels: 0.15 ms per batch in a fresh process, 0.3-0.4 ms
+// inside bench.py.  The copy is 0.6 MB, ~15 us of a stream whose chain is host-bound.)
 int64_t gnncca_post_pool_submit_copy(gnncca_post_pool* pool, const gnncca_post_batch* batch, const void* device_src, void* host_dst,
                                      size_t nbytes, int32_t device, gnncca_stream_t stream) {
     if (!pool || !batch_ok(batch) || !device_src || !host_dst || nbytes == 0 || device < 0) return -(int64_t)GNNCCA_ERR_INVALID_ARG;
     std::shared_ptr<Job> j(new (std::nothrow) Job());
     if (!j) return -(int64_t)GNNCCA_ERR_INVALID_ARG;
     j->b = *batch;
-    hipStream_t cs = nullptr;
     {
         std::lock_guard<std::mutex> g(pool->m);
-        auto q = pool->copy_streams.find(device);
-        if (q != pool->copy_streams.end()) cs = q->second;
-    }
-    if (!cs) {
-        if (hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess) return -(int64_t)GNNCCA_ERR_HIP;
-        std::lock_guard<std::mutex> g(pool->m);
-        auto ins = pool->copy_streams.emplace(device, cs);
-        if (!ins.second) (void)hipStreamDestroy(cs), cs = ins.first->second;
-    }
-    {
-        std::lock_guard<std::mutex> g(pool->m);
-        if (pool->free_events.size() >= 2) {
-            j->e_chain = pool->free_events.back(), pool->free_events.pop_back();
-            j->e_copy = pool->free_events.back(), pool->free_events.pop_back();
-        }
+        if (!pool->free_events.empty()) j->e_copy = pool->free_events.back(), pool->free_events.pop_back();
     }
     // (e_copy is what a pool thread waits on: GNNCCA_POOL_BLOCKING=1 under GNNCCA_DIAG makes that wait a sleep instead of a spin)
     static const bool blocking = gnncca::diag_env("GNNCCA_POOL_BLOCKING") != nullptr;
-    if (!j->e_chain && (hipEventCreateWithFlags(&j->e_chain, hipEventDisableTiming) != hipSuccess ||
-                        hipEventCreateWithFlags(&j->e_copy, hipEventDisableTiming | (blocking ? hipEventBlockingSync : 0)) != hipSuccess))
+    if (!j->e_copy && hipEventCreateWithFlags(&j->e_copy, hipEventDisableTiming | (blocking ? hipEventBlockingSync : 0)) != hipSuccess)
         return -(int64_t)GNNCCA_ERR_HIP;
-    if (hipEventRecord(j->e_chain, static_cast<hipStream_t>(stream)) != hipSuccess || hipStreamWaitEvent(cs, j->e_chain, 0) != hipSuccess ||
-        hipMemcpyAsync(host_dst, device_src, nbytes, hipMemcpyDeviceToHost, cs) != hipSuccess || hipEventRecord(j->e_copy, cs) != hipSuccess)
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (hipMemcpyAsync(host_dst, device_src, nbytes, hipMemcpyDeviceToHost, st) != hipSuccess || hipEventRecord(j->e_copy, st) != hipSuccess) {
+        (void)hipEventDestroy(j->e_copy);
         return -(int64_t)GNNCCA_ERR_HIP;
+    }
     j->b.ready_event = j->e_copy;
     j->b.device = device;
     return enqueue(pool, std::move(j));
@@ -700,18 +714,16 @@ int64_t gnncca_post_pool_submit(gnncca_post_pool* pool, const gnncca_post_batch*
     std::shared_ptr<Job> j(new (std::nothrow) Job());
     if (!j) return -(int64_t)GNNCCA_ERR_INVALID_ARG;
     j->b = *batch;
-    int64_t ticket;
-    {
-        std::lock_guard<std::mutex> g(pool->m);
-        ticket = pool->next_ticket++;
-        pool->tasks.push_back(Task{j, true});
-        pool->jobs.emplace(ticket, std::move(j));
-    }
-    pool->cv.notify_one();
-    return ticket;
+    return enqueue(pool, std::move(j));
 }
 
 int gnncca_post_pool_wait(gnncca_post_pool* pool, int64_t ticket, int32_t* frames_out, int32_t* n_frames_out) {
+    return gnncca_post_pool_wait_timed(pool, ticket, frames_out, n_frames_out, nullptr);
+}
+
+// diagnostics: the same, plus the job's life in microseconds -- times_us_out[0..3] = submit -> a pool thread picked it up, -> its event had
+// completed (the D2H copy behind the GPU chain), -> the last frame was final, -> this call returned
+int gnncca_post_pool_wait_timed(gnncca_post_pool* pool, int64_t ticket, int32_t* frames_out, int32_t* n_frames_out, double* times_us_out) {
     if (!pool) return GNNCCA_ERR_INVALID_ARG;
     std::shared_ptr<Job> j;
     {
@@ -725,12 +737,15 @@ int gnncca_post_pool_wait(gnncca_post_pool* pool, int64_t ticket, int32_t* frame
         j->cv.wait(g, [&] { return j->done; });
     }
     const int st = j->status.load();
+    if (times_us_out) {
+        times_us_out[0] = j->t_head - j->t_submit, times_us_out[1] = j->t_event - j->t_head;
+        times_us_out[2] = j->t_done - j->t_event, times_us_out[3] = now_us() - j->t_done;
+    }
     if (n_frames_out) *n_frames_out = (int32_t)j->flagged.size();
     if (frames_out)
         for (size_t i = 0; i < j->flagged.size(); ++i) frames_out[i] = j->flagged[i];
     {
         std::lock_guard<std::mutex> g(pool->m);
-        if (j->e_chain) pool->free_events.push_back(j->e_chain), j->e_chain = nullptr;
         if (j->e_copy) pool->free_events.push_back(j->e_copy), j->e_copy = nullptr;
         pool->jobs.erase(ticket);
     }

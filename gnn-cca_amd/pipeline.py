@@ -15,7 +15,7 @@ and the Python between five calls is a third of it: 0.143 -> 0.11 ms per batch.
     f['predictions'], f['labels'], f['n_clusters']                  # ROUNDING / PRUNING / SPLITTING (config_inference.yaml:6-8)
 
 `r.final_async()` (round 6) hands the batch to a persistent pool of host threads WITHOUT synchronising -- one D2H copy of the batch's trigger
-words / edges / probabilities / pruned predictions / labels on the pool's own stream behind an event, the flagged frames finalized by the
+words / edges / probabilities / pruned predictions / labels enqueued behind the chain, the flagged frames finalized by the
 pool while the caller enqueues the next batch -- and returns a `PendingFinal`; `.result()` waits for that batch only:
 
     pending = [pipe(*batch_k).final_async() for ...]                # batch k's host pass overlaps batch k + 1's GPU chain
@@ -56,7 +56,9 @@ class PendingFinal:
         if self._res is None:
             host, start, off, n, e, g = self._views
             frames, count = np.empty(max(g, 1), dtype=np.int32), C.c_int32(0)
-            st = nat.lib().gnncca_post_pool_wait(self._pipe._pool_handle(), self._ticket, frames.ctypes.data, C.byref(count))
+            times = np.zeros(4, dtype=np.float64)
+            st = nat.lib().gnncca_post_pool_wait_timed(self._pipe._pool_handle(), self._ticket, frames.ctypes.data, C.byref(count), times.ctypes.data)
+            self.times_us = times      # submit -> picked up -> event complete -> last frame final -> collected
             self._keep = None      # the device buffers may go: everything is on the host now
             if st:
                 nat.check(st, "gnncca_post_pool_wait")
@@ -177,8 +179,8 @@ class FramePipeline:
             self._pinned.setdefault(host.numel(), []).append(host)
 
     def _submit_final(self, r):
-        """One D2H copy of [probs | edge_index | pruned | counters | labels] (contiguous in the batch's arena) behind the chain, on the pool's own
-        stream, and the job behind that copy: nothing here waits for the device."""
+        """One D2H copy of [probs | edge_index | pruned | counters | labels] (contiguous in the batch's arena) behind the chain on its stream, and
+        the job behind that copy: nothing here waits for the device."""
         arena, start, end, off, n, e, g = r._d2h
         dev = arena.device
         nbytes = end - start

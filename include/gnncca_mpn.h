@@ -358,12 +358,16 @@ GNNCCA_API gnncca_post_pool* gnncca_post_pool_create(int32_t n_threads);
 GNNCCA_API int32_t gnncca_post_pool_threads(const gnncca_post_pool* pool);
 GNNCCA_API void gnncca_post_pool_destroy(gnncca_post_pool* pool);
 GNNCCA_API int64_t gnncca_post_pool_submit(gnncca_post_pool* pool, const gnncca_post_batch* batch);
-/* gnncca_post_pool_submit for results that still sit in DEVICE memory: records an event on `stream` (the stream the batch's chain was
- * enqueued on), makes the pool's own copy stream wait for it, copies `nbytes` from device_src to host_dst (pinned) there and submits
- * `batch` -- whose pointers point into host_dst -- behind that copy.  One call, no synchronisation. */
+/* gnncca_post_pool_submit for results that still sit in DEVICE memory: enqueues the D2H copy of `nbytes` from device_src to host_dst
+ * (pinned) on `stream` -- the stream the batch's chain was enqueued on -- records the event the job waits for behind it and submits
+ * `batch`, whose pointers point into host_dst.  One call, no synchronisation. */
 GNNCCA_API int64_t gnncca_post_pool_submit_copy(gnncca_post_pool* pool, const gnncca_post_batch* batch, const void* device_src,
                                                 void* host_dst, size_t nbytes, int32_t device, gnncca_stream_t stream);
 GNNCCA_API int gnncca_post_pool_wait(gnncca_post_pool* pool, int64_t ticket, int32_t* frames_out, int32_t* n_frames_out);
+/* diagnostics: gnncca_post_pool_wait plus the job's life in microseconds -- times_us_out[0..3] = submit -> picked up by a pool thread,
+ * -> its event had completed, -> its last frame was final, -> this call returned (negative: the caller arrived before the job was done). */
+GNNCCA_API int gnncca_post_pool_wait_timed(gnncca_post_pool* pool, int64_t ticket, int32_t* frames_out, int32_t* n_frames_out,
+                                           double* times_us_out);
 
 /* ---- rows N1 + the path + N2 in ONE call: a batch of frames from the uploaded staging image to identity clusters -------------------
  * The per-batch body of inference.py:189-345 (normalise the embeddings, build the graph, MOTMPNet.forward, sigmoid / threshold,

@@ -128,8 +128,8 @@ def test_shapes_alternate_and_fallbacks_agree():
 
 
 def test_final_async_overlaps_batches_and_equals_the_synchronous_finalize():
-    """FrameResult.final_async (round 6): several batches in flight -- each handed to the pool of host threads behind ONE D2H copy on the
-    pool's own stream, no synchronisation in between -- collected OUT OF ORDER; every result equals postprocess.finalize (the synchronous
+    """FrameResult.final_async (round 6): several batches in flight -- each handed to the pool of host threads behind ONE D2H copy behind the
+    chain, no synchronisation in between -- collected OUT OF ORDER; every result equals postprocess.finalize (the synchronous
     host pass, pinned against the reference's goldens) on the same device tensors, and FrameResult.final() returns the same as device tensors.
     A result of the step-by-step path (more than 4096 detections) goes through the same interface."""
     from gnn_cca_amd.pipeline import FramePipeline

@@ -39,6 +39,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames", type=int, default=1024)
     ap.add_argument("--threads", default="1,4,8,16")
+    ap.add_argument("--pinned", action="store_true", help="the batch arrays in pinned host memory (torch pin_memory), as final_async hands them over")
     args = ap.parse_args()
     from gnn_cca_amd import _native as nat
     lib = nat.lib()
@@ -52,12 +53,25 @@ def main():
     pred0 = np.ascontiguousarray(np.concatenate([p for _, _, _, p in fr]))
     np_h, ep_h = np.asarray(node_ptr, np.int32), np.asarray(edge_ptr, np.int32)
     listed = np.arange(len(fr), dtype=np.int32)
+    keep = []
+    if args.pinned:
+        import torch
+
+        def pin(a):
+            t = torch.empty(a.nbytes, dtype=torch.uint8, pin_memory=True)
+            keep.append(t)
+            v = t.numpy().view(a.dtype)
+            v[:] = a
+            return v
+        src, dst, probs, pred0 = pin(src), pin(dst), pin(probs), pin(pred0)
     print(f"{len(fr)} frames, {node_ptr[-1] / len(fr):.1f} nodes / {edge_ptr[-1] / len(fr):.0f} edges per frame")
     ref = None
     for t in [int(v) for v in args.threads.split(",")]:
         best = 1e9
         for _ in range(3):
             pred, labels, k = pred0.copy(), np.zeros(node_ptr[-1], np.int32), np.zeros(len(fr), np.int32)
+            if args.pinned:
+                pred = pin(pred)
             t0 = time.perf_counter()
             st = lib.gnncca_post_finalize_frames_host(src.ctypes.data, dst.ctypes.data, np_h.ctypes.data, ep_h.ctypes.data, listed.ctypes.data, len(fr),
                                                       probs.ctypes.data, pred.ctypes.data, 7, labels.ctypes.data, k.ctypes.data, t)

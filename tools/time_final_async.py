@@ -76,16 +76,34 @@ def main():
         print(f"threads {th:2d}: submit all, collect at the end: {ms:.4f} ms / batch (drain {submit_only.drain:.2f} ms total)")
         for depth in [int(v) for v in args.depth.split(",")]:
             for cp in (True, False):
+                acc = []
+
                 def overlapped():
                     pend = []
+                    t_sub = t_res = 0.0
                     for _ in range(args.reps):
                         for i in range(args.batches):
-                            pend.append(run(pipe, i).final_async())
+                            r = run(pipe, i)
+                            t1 = time.perf_counter()
+                            pend.append(r.final_async())
+                            t2 = time.perf_counter()
                             if len(pend) > depth:
-                                pend.pop(0).result(copy=cp)
+                                p = pend.pop(0)
+                                p.result(copy=cp)
+                                acc.append(p.times_us)
+                            t3 = time.perf_counter()
+                            t_sub += t2 - t1
+                            t_res += t3 - t2
                     while pend:
-                        pend.pop(0).result(copy=cp)
-                print(f"threads {th:2d} depth {depth} copy {int(cp)}: {timed(overlapped):.4f} ms / batch")
+                        p = pend.pop(0)
+                        p.result(copy=cp)
+                        acc.append(p.times_us)
+                    overlapped.sub, overlapped.res = t_sub / n * 1e6, t_res / n * 1e6
+                ms = timed(overlapped)
+                import numpy as np
+                a = np.mean(np.asarray(acc), axis=0)
+                print(f"threads {th:2d} depth {depth} copy {int(cp)}: {ms:.4f} ms / batch | main thread: submit {overlapped.sub:.1f} us, result {overlapped.res:.1f} us | "
+                      f"job: pickup {a[0]:.0f} us, event {a[1]:.0f} us, frames {a[2]:.0f} us, slack before collection {-a[3]:.0f} us")
         # the synchronous form
         def sync_final():
             for _ in range(args.reps):
