@@ -28,6 +28,7 @@
 #include "step_fast.cuh"
 #include "step_pipe.cuh"
 #include "enc_f16.cuh"
+#include "enc_f16_slices.cuh"
 #include "generic_fused.cuh"
 #include "generic.cuh"
 #include "postprocess.cuh"
@@ -150,7 +151,16 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
         // 10.5 / 13.2 us at 384 / 512 / 768 / 896 nodes, 3 x dense256 17.0 -> 10.0; at 256 nodes the f32 form stays ahead, 6.6 vs 7.6;
         // r3_split_min2.log)
         static const int split_min = diag_env("GNNCCA_GEMM_SPLIT_MIN") ? std::atoi(diag_env("GNNCCA_GEMM_SPLIT_MIN")) : 384;   // diagnostics
-        const bool split = g == 0 && hdr.enc_w3 != 0 && N >= split_min && (reinterpret_cast<uintptr_t>(cur_in) & 15) == 0;
+        // round 6: below 4096 nodes the first layer runs on the fp16-split GEMM in 32-row tiles with K split over one round of workgroups
+        // (enc_f16_slices.cuh): a fraction of the slabs of the two forms above (dense1024: 8 x 0.5 MB instead of 16 x 0.5 MB written and read
+        // back; dense256: 16 instead of 32) and half the matrix work of the six-product form.  nks: powers of two while one round of
+        // workgroups holds the tiles (nrt * nks <= 384), a slice stays >= 128 deep and the workspace has the slabs.
+        static const int slices_min = diag_env_int("GNNCCA_GEMM_SLICES_MIN", 1, 0, 0x7FFFFFFF);
+        static const int slices_max = diag_env_int("GNNCCA_GEMM_SLICES_MAX", 4095, 0, 0x7FFFFFFF);
+        static const bool slices_bf16 = diag_env("GNNCCA_GEMM_BF16") != nullptr;
+        const bool use_slices = g == 0 && hdr.enc_w2h != 0 && O == 128 && K >= 64 && (K & (K - 1)) == 0 && K / kF16SlMaxKs <= ws.ksplit && N >= slices_min && N <= slices_max && N < 4096 && !split3 &&
+                                !slices_bf16 && (options & GNNCCA_OPT_ENC_UNSPLIT) == 0 && (reinterpret_cast<uintptr_t>(cur_in) & 15) == 0;
+        const bool split = !use_slices && g == 0 && hdr.enc_w3 != 0 && N >= split_min && (reinterpret_cast<uintptr_t>(cur_in) & 15) == 0;
         EncPlanParams ep;
         std::memset(&ep, 0, sizeof(ep));
         ep.in = cur_in;
@@ -177,6 +187,48 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
             plan_blocks = plan_num_blocks(E);
         }
         int ks_split = 1;
+        if (use_slices) {
+            const int nrt = (N + 31) / 32;
+            // slices: at least K / 256 (a workgroup's x tile is 32 KB of LDS), then powers of two while one round of workgroups holds the tiles, a
+            // slice stays >= 64 deep and the workspace has the slabs (dense1024 -> 8, dense256 and below -> 16: 32 slices of 64 measured 0.7 us slower per dense256 forward, 8 of 256 1.4 us)
+            static const int nks_cap = diag_env_int("GNNCCA_GEMM_SLICES_NKS", 16, 1, 32);       // diagnostics: cap of the slice count
+            static const int wg_cap = diag_env_int("GNNCCA_GEMM_SLICES_WGS", 256, 1, 1 << 20);    // diagnostics: workgroups one round may hold
+            int nks = 1;
+            while (K / nks > kF16SlMaxKs) nks *= 2;
+            while (nks * 2 <= std::min(nks_cap, ws.ksplit) && nrt * nks * 2 <= wg_cap && K / (nks * 2) >= 64 && (K / (nks * 2)) % 64 == 0) nks *= 2;
+            EncF16SlicesParams q;
+            std::memset(&q, 0, sizeof(q));
+            q.x = cur_in;
+            q.w2h = reinterpret_cast<const unsigned short*>(blob + hdr.enc_w2h);
+            q.w_bad = reinterpret_cast<const unsigned*>(blob + hdr.enc_w2h_bad);
+            q.w32 = blob + hdr.enc_node_w[0];
+            q.part = part;
+            q.M = N, q.K = K, q.nrt = nrt, q.nks = nks, q.Ks = K / nks;
+            static const int sl_force_arm = diag_env_int("GNNCCA_GEMM_F16_ARM", 0, 0, 1);   // diagnostics / tests: every wave on the fp32 arm
+            q.force_arm = sl_force_arm;
+            EncPlanParams pl = ep;
+            int ride = 0;
+            if (plan_blocks > 0) {   // the plan rides in this launch (extra workgroups beyond the GEMM tiles)
+                pl.plan_span = plan_span(edge_index, E);
+                ride = pl.plan_span > 1 ? (plan_blocks + pl.plan_span - 1) / pl.plan_span : plan_blocks;
+                ride = (ride + 1) / 2;   // two plan blocks per 512-thread workgroup
+            } else {
+                pl.E = 0;
+            }
+            const dim3 sgrid((unsigned)(nrt * nks + ride));
+            if (q.Ks == 256)
+                GNNCCA_LAUNCH(enc_gemm_f16_slices8_kernel, sgrid, dim3(kF16SlThreads), 0, st, q, pl);
+            else if (q.Ks == 128)
+                GNNCCA_LAUNCH(enc_gemm_f16_slices4_kernel, sgrid, dim3(kF16SlThreads), 0, st, q, pl);
+            else
+                GNNCCA_LAUNCH(enc_gemm_f16_slices2_kernel, sgrid, dim3(kF16SlThreads), 0, st, q, pl);
+            HIP_TRY(hipGetLastError());
+            PROF_MARK(GNNCCA_K_ENC_GEMM);
+            plan_launched = true;
+            ep.gemm_blocks = 0;
+            plan_blocks = 0;
+            ks_split = nks;
+        }
         if (split) {  // big batches: split-bf16 MFMA GEMM; the plan gets its own launch
             const unsigned short* w3 = reinterpret_cast<const unsigned short*>(blob + hdr.enc_w3);
             static const bool force_direct = diag_env("GNNCCA_GEMM_DIRECT") != nullptr;  // diagnostics: A/B the GEMMs
@@ -415,7 +467,7 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
             HIP_TRY(hipGetLastError());
             PROF_MARK(split ? GNNCCA_K_PLAN_ROWS : GNNCCA_K_ENC_GEMM);
         }
-        ks_last = split ? ks_split : ks;
+        ks_last = (split || use_slices) ? ks_split : ks;
         if (g < n_gemm - 1) {
             float* dst = act + (size_t)(g & 1) * N * O;
             GNNCCA_LAUNCH(reduce_bias_act_kernel, grid1((size_t)N * O, 256), dim3(256), 0, st, (const float*)part,

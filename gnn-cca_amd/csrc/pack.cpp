@@ -694,7 +694,7 @@ static const char* const kDiagSwitches[] = {
     "GNNCCA_DIAG", "GNNCCA_LIB", "GNNCCA_STAMPS", "GNNCCA_STEP_R2", "GNNCCA_STEP_NOMEM", "GNNCCA_STEP_NOEPI", "GNNCCA_STEP_NOHOOK", "GNNCCA_STEP_EARLYBAR",
     "GNNCCA_STEP_NORANGE", "GNNCCA_RANGE_MAX_E", "GNNCCA_PD_LDS_MIN", "GNNCCA_PD_LDS_MAX", "GNNCCA_TAIL_NPW", "GNNCCA_WPS", "GNNCCA_NO_NT", "GNNCCA_NO_PAD",
     "GNNCCA_GEMM_DIRECT", "GNNCCA_GEMM_SPLIT_MIN", "GNNCCA_GEMM_LDS_MIN", "GNNCCA_GEMM_NOPIPE", "GNNCCA_NO_FUSE", "GNNCCA_NO_MFMA_TAIL",
-    "GNNCCA_TAIL_MFMA_MIN", "GNNCCA_NO_RIDE", "GNNCCA_GEMM_DIRECT_WG", "GNNCCA_GEMM_R32_NST", "GNNCCA_GEN_UNFUSED", "GNNCCA_NPW", "GNNCCA_NPW_MIN_N", "GNNCCA_NPW_MIN_N_FIRST", "GNNCCA_DEFER_CLS", "GNNCCA_GEMM_X_L2_ROWS", "GNNCCA_NPW_MAX_CHUNKS", "GNNCCA_GEMM_KROT", "GNNCCA_GEMM_BF16", "GNNCCA_GEMM_F16_ARM", "GNNCCA_GEMM_F16_DIAG", "GNNCCA_GEMM_F16_PRIO", "GNNCCA_GEMM_R32F_MIN", "GNNCCA_GEMM_R32F_MAX", "GNNCCA_GEMM_F16_XNT", "GNNCCA_STEP_NT", "GNNCCA_COLNORM_NOLDS", "GNNCCA_POOL_BLOCKING", "GNNCCA_POOL_CHUNK", "GNNCCA_POOL_SPIN_US"};
+    "GNNCCA_TAIL_MFMA_MIN", "GNNCCA_NO_RIDE", "GNNCCA_GEMM_DIRECT_WG", "GNNCCA_GEMM_R32_NST", "GNNCCA_GEN_UNFUSED", "GNNCCA_NPW", "GNNCCA_NPW_MIN_N", "GNNCCA_NPW_MIN_N_FIRST", "GNNCCA_DEFER_CLS", "GNNCCA_GEMM_X_L2_ROWS", "GNNCCA_NPW_MAX_CHUNKS", "GNNCCA_GEMM_KROT", "GNNCCA_GEMM_BF16", "GNNCCA_GEMM_F16_ARM", "GNNCCA_GEMM_F16_DIAG", "GNNCCA_GEMM_F16_PRIO", "GNNCCA_GEMM_R32F_MIN", "GNNCCA_GEMM_R32F_MAX", "GNNCCA_GEMM_F16_XNT", "GNNCCA_STEP_NT", "GNNCCA_COLNORM_NOLDS", "GNNCCA_POOL_BLOCKING", "GNNCCA_POOL_CHUNK", "GNNCCA_POOL_SPIN_US", "GNNCCA_GEMM_SLICES_MIN", "GNNCCA_GEMM_SLICES_MAX", "GNNCCA_GEMM_SLICES_NKS", "GNNCCA_GEMM_SLICES_WGS"};
 
 extern "C" char** environ;
 

@@ -104,10 +104,13 @@ __device__ __forceinline__ unsigned plan_edge(int k, long long r, long long c, l
 
 // Per-edge part of the plan.  Every workgroup reports its findings in its OWN word (`blockflags[b]`, always
 // written, so there is no state to clear between forwards); the tail launch ORs them into flags[0].
+// `tx`: the thread's index inside ITS 256-thread plan block (default threadIdx.x).  A 512-thread workgroup runs two plan blocks side by side
+// (enc_f16_slices.cuh: tx = threadIdx.x & 255, one `s_fl` word per half): both halves pass the same barriers.
 __device__ __forceinline__ void plan_block(int pb, const long long* __restrict__ ei, int E, int N,
                                            int* __restrict__ seg_ptr, int* __restrict__ col32,
-                                           unsigned* __restrict__ blockflags, unsigned* s_fl, int ell_S = 0, int span = 0) {
-    if (threadIdx.x == 0) *s_fl = 0u;
+                                           unsigned* __restrict__ blockflags, unsigned* s_fl, int ell_S = 0, int span = 0, int tx = -1) {
+    if (tx < 0) tx = (int)threadIdx.x;
+    if (tx == 0) *s_fl = 0u;
     __syncthreads();
     const int per = plan_edges_per_block(E) / 256;
     unsigned fl = 0u;
@@ -118,14 +121,14 @@ __device__ __forceinline__ void plan_block(int pb, const long long* __restrict__
     typedef long long ll2 __attribute__((ext_vector_type(2)));
     typedef int i32x2 __attribute__((ext_vector_type(2)));
     if (span == kPlanSpan) {   // (the host checked: per == 4, E even, both index rows 16-byte aligned)
-        const int lane = threadIdx.x & 63;
+        const int lane = tx & 63;
         constexpr int U = 2 * kPlanSpan;
         ll2 r2[U], c2[U], a2[U];
         long long rlast[U];
         int kk[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int k = pb * (1024 * kPlanSpan) + u * 512 + 2 * (int)threadIdx.x;
+            const int k = pb * (1024 * kPlanSpan) + u * 512 + 2 * tx;
             kk[u] = k;
             const bool on = k < E;   // E is even: a pair is inside or outside as a whole
             const int kl = on ? k : 0;
@@ -158,7 +161,7 @@ __device__ __forceinline__ void plan_block(int pb, const long long* __restrict__
             }
         }
     } else {
-        const int k0 = pb * 256 * per + threadIdx.x;
+        const int k0 = pb * 256 * per + tx;
         long long r[4], c[4], rp[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {  // all loads first
@@ -182,7 +185,7 @@ __device__ __forceinline__ void plan_block(int pb, const long long* __restrict__
     __syncthreads();
     // one word per 1024-edge (or 256-edge) block, always written: a wide workgroup reports its findings in each of its blocks' words
     const int nb = plan_num_blocks(E), wspan = span > 1 ? span : 1;
-    if ((int)threadIdx.x < wspan && pb * wspan + (int)threadIdx.x < nb) blockflags[pb * wspan + threadIdx.x] = *s_fl;
+    if (tx < wspan && pb * wspan + tx < nb) blockflags[pb * wspan + tx] = *s_fl;
 }
 
 // OR of the per-block findings -> flags[0]; stable counting sort if the rows were not sorted.  `smem` >= 3 KB.

@@ -282,10 +282,12 @@ def test_fp16_split_gemm_short_k(n_nodes):
         assert np.abs(o.cpu().numpy() - r).max() <= TOL_TIGHT * 2
 
 
-@pytest.mark.parametrize("n_nodes", [6144 + 9, 51200 + 33])
+@pytest.mark.parametrize("n_nodes", [301, 1229, 3000 + 7, 6144 + 9, 51200 + 33])
 @pytest.mark.parametrize("what", ["x_beyond_fp16", "w_beyond_fp16", "x_tiny"])
 def test_fp16_split_gemm_range_guard(n_nodes, what):
-    """The fp16-split GEMM (csrc/enc_f16.cuh, round 5) carries x and W as two fp16 pieces each.  fp16's exponent is narrow: a workgroup
+    """(301 / 1229 / 3007 nodes: round 6's 32-row slices kernel, csrc/enc_f16_slices.cuh, at 16 / 8 / 8 slices -- its arm is per WAVE, an
+    exact-fp32 MFMA chain; the others: round 5's kernels.)
+    The fp16-split GEMM (csrc/enc_f16.cuh, round 5) carries x and W as two fp16 pieces each.  fp16's exponent is narrow: a workgroup
     that meets a finite |x| >= 65520, or any workgroup when a weight is that large (flag words written by the packers), must recompute
     its tile on the bf16 six-product arm; magnitudes below fp16's normal range (6.1e-5) degrade gracefully (absolute error <= 2^-36 per
     element).  Encoder output against an fp64 evaluation -- RELATIVE to each row's magnitude where huge values are planted -- and logits
