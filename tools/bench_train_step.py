@@ -19,8 +19,8 @@ frames = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 cams = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 per = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 params = bench.graph_net_params(cls_bn=False)  # config_training.yaml shape
-ENGINE = os.environ.get("GNNCCA_TRAIN_ENGINE", "auto")   # 'layerwise': the layer-by-layer engine; + GNNCCA_TRAIN_BN=1: BatchNorm in every MLP
-if os.environ.get("GNNCCA_TRAIN_BN"):
+ENGINE = os.environ.get("BENCH_TRAIN_ENGINE", "auto")   # 'layerwise': the layer-by-layer engine; + BENCH_TRAIN_BN=1: BatchNorm in every MLP
+if os.environ.get("BENCH_TRAIN_BN"):
     params["encoder_feats_dict"]["nodes"]["resnet50"]["use_batchnorm"] = True
     params["edge_model_feats_dict"]["use_batchnorm"] = True
     params["node_model_feats_dict"]["use_batchnorm"] = True
@@ -93,6 +93,6 @@ orc.loss_and_grads(x, ei, ea, lab)
 t0 = time.perf_counter()
 for _ in range(3): orc.loss_and_grads(x, ei, ea, lab)
 t_cpu = (time.perf_counter() - t0) / 3
-print(json.dumps({"stage": "train step (fwd+loss+bwd+SGD)", "engine": model._train_path, "batchnorm_everywhere": bool(os.environ.get("GNNCCA_TRAIN_BN")), "frames": frames, "nodes": N, "edges": E, "gpu_ms": t_gpu * 1e3, "gpu_ms_hip_graph_replay": None if t_graph is None else t_graph * 1e3,
+print(json.dumps({"stage": "train step (fwd+loss+bwd+SGD)", "engine": model._train_path, "batchnorm_everywhere": bool(os.environ.get("BENCH_TRAIN_BN")), "frames": frames, "nodes": N, "edges": E, "gpu_ms": t_gpu * 1e3, "gpu_ms_hip_graph_replay": None if t_graph is None else t_graph * 1e3,
                   "graph_replay_loss_matches_eager": graph_ok,
                   "cpu_autograd_oracle_ms_16thr": t_cpu * 1e3, "speedup": t_cpu / t_gpu}))

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Phase totals of enc_gemm_split_lds_kernel<.., PIPE> (diagnostic build -DGNNCCA_STAMPS; per-wave s_memtime totals, median over waves).
-usage (GPU box): GNNCCA_GEMM_PIPE=1 GNNCCA_LIB=.../libgnncca_mpn_stamps.so python3 tools/stamps_gemm.py [nodes] [graphs]"""
+usage (GPU box): GNNCCA_DIAG=1 GNNCCA_GEMM_BF16=1 GNNCCA_LIB=.../libgnncca_mpn_stamps.so python3 tools/stamps_gemm.py [nodes] [graphs]"""
 import ctypes as C
 import os
 import sys

@@ -1,3 +1,8 @@
+#!/usr/bin/env python3
+"""GPU box: the one-launch column normalisation of a Terrace batch's two embedding matrices (gnncca_normalize_columns2), median of 50 calls.
+A/B: the default LDS-resident kernel against round 4's two-pass kernel --
+    python tools/time_colnorm.py [rows]                                  (A)
+    GNNCCA_DIAG=1 GNNCCA_COLNORM_NOLDS=1 python tools/time_colnorm.py    (B)"""
 import sys,os,torch,time
 sys.path.insert(0,os.environ.get("GRAFT_REPO_ROOT",os.getcwd()))
 from gnn_cca_amd.graph_build import normalize_columns
@@ -9,4 +14,4 @@ ts=[]
 for _ in range(50):
     e0=torch.cuda.Event(enable_timing=True); e1=torch.cuda.Event(enable_timing=True)
     e0.record(); normalize_columns(a,b); e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1)*1e3)
-ts.sort(); print(os.environ.get("GNNCCA_COLNORM_ABL","0"), os.environ.get("GNNCCA_COLNORM_NOLDS","-"), "rows",rows,"median us",ts[len(ts)//2],"min",ts[0])
+ts.sort(); print("GNNCCA_COLNORM_NOLDS", os.environ.get("GNNCCA_COLNORM_NOLDS", "-"), "rows", rows, "median us", ts[len(ts) // 2], "min", ts[0])
