@@ -24,10 +24,10 @@ cp gpurun_out/pmc_kernel/summary.json gpurun_out/r06_tcp_ta_encgemm_f16_slices4_
 PMC_PASS_TIMEOUT=100 python3 tools/pmc_kernel.py "enc_gemm_f16_slices8_kernel" "$G2" -- --nodes 1024 --L 8
 cp gpurun_out/pmc_kernel/summary.json gpurun_out/r06_tcp_ta_encgemm_f16_slices8_dense1024.json
 rm -rf gpurun_out/pmc_kernel
-# the Terrace pipeline's kernels: rocprofv3 --kernel-trace --stats over tools/prof_pipeline_host.py (336 batches of 64 frames through FramePipeline)
+# the Terrace pipeline's kernels: rocprofv3 --kernel-trace --stats over tools/prof_pipeline_host.py (352 batches of 64 frames through FramePipeline)
 here=$PWD
 rm -rf gpurun_out/r06_terrace_trace; (cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats --output-format csv -d $here/gpurun_out/r06_terrace_trace -- python3 $here/tools/prof_pipeline_host.py > $here/gpurun_out/r06_terrace_trace.log 2>&1) || true
 cp gpurun_out/r06_terrace_trace/*/*kernel_stats.csv gpurun_out/terrace_pipeline_r06_kernel_stats.csv 2>/dev/null || true
-python3 tools/kernel_breakdown.py gpurun_out/terrace_pipeline_r06_kernel_stats.csv 336 > gpurun_out/terrace_pipeline_r06_breakdown.txt 2>&1 || true
+python3 tools/kernel_breakdown.py gpurun_out/terrace_pipeline_r06_kernel_stats.csv 352 > gpurun_out/terrace_pipeline_r06_breakdown.txt 2>&1 || true
 rm -rf gpurun_out/r06_terrace_trace
 fi
