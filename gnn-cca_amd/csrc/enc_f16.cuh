@@ -14,8 +14,9 @@ namespace gnncca {
 // bf16 products of round 2's form -- half the matrix work for the same class of accuracy (measured against an fp64 evaluation the result
 // is closer than an fp32 GEMM's: tools/time_encoder.py --check, tests/test_gpu_parity.py).  fp16 has a narrow exponent: a workgroup whose x
 // holds a finite magnitude >= 65520 (it would round to infinity), or any workgroup when a WEIGHT does (flag words written by the packers),
-// recomputes its tile on the bf16 six-product arm inside the same launch (`bf16_arm`: range of fp32, round 2's arithmetic) -- no input
-// makes this kernel wrong, unusual ones make it slower.
+// recomputes its tile on the bf16 six-product arm inside the same launch (`bf16_arm`: range of fp32, round 2's arithmetic); so does (round 6) a
+// workgroup whose LARGEST |x| is below 2^-8 without being zero (kF16Tiny: the pieces' 2^-36 absolute precision would show as relative error against
+// an fp32 GEMM) -- no input makes this kernel wrong, unusual ones make it slower.
 //
 // DATA MOVEMENT.  256 rows x 128 columns per workgroup, 8 waves; wave w owns rows [32 w, 32 w + 32) and ALL 128 columns, so the x operand
 // is wave-private: every wave streams its own 32 rows by LDS-DMA (buffer_load_dwordx4 ... lds: 8 rows x 128 B per instruction, full
@@ -362,9 +363,15 @@ __device__ __forceinline__ void enc_gemm_f16_body(const EncF16Params p, const En
     unsigned* s_flag = reinterpret_cast<unsigned*>(lds_raw);
     if (tid == 0) *s_flag = 0u;
     __syncthreads();
-    if (!(amax < kF16Limit) || wbad != 0u || p.force_arm) atomicOr(s_flag, 1u);   // (a NaN in x: the arm's business too)
+    // bit 0: beyond fp16 (a NaN in x: the arm's business too); bit 1: somebody's |x| reaches 2^-8; bit 2: somebody's is not zero -- a tile
+    // whose largest |x| is below 2^-8 without being zero takes the arm too (kF16Tiny, internal.h)
+    {
+        const unsigned f = ((!(amax < kF16Limit) || wbad != 0u || p.force_arm) ? 1u : 0u) | (amax >= kF16Tiny ? 2u : 0u) | (amax > 0.f ? 4u : 0u);
+        if (f) atomicOr(s_flag, f);
+    }
     __syncthreads();
-    const bool arm = *s_flag != 0u;
+    const unsigned fl_arm = *s_flag;
+    const bool arm = (fl_arm & 1u) != 0u || (fl_arm & 6u) == 4u;
     __syncthreads();
     if (arm) enc_f16_bf16_arm(acc, p.x, p.w3, M, K, row0 + wave * 32, kbeg, nk, lds_raw);
     PHASE_T(5);   // drain, combine, arm decision
@@ -619,9 +626,13 @@ __global__ __launch_bounds__(kF16R32Threads) void enc_gemm_f16_rows32_kernel(con
         }
     }
     __syncthreads();
-    if (!(amax < kF16Limit) || wbad != 0u || p.force_arm) atomicOr(s_flag, 1u);
+    {   // (bits as in the 256-row kernel: 0 beyond fp16, 1 somebody's |x| reaches 2^-8, 2 somebody's is not zero)
+        const unsigned f = ((!(amax < kF16Limit) || wbad != 0u || p.force_arm) ? 1u : 0u) | (amax >= kF16Tiny ? 2u : 0u) | (amax > 0.f ? 4u : 0u);
+        if (f) atomicOr(s_flag, f);
+    }
     __syncthreads();
-    const bool arm = *s_flag != 0u;
+    const unsigned fl_arm = *s_flag;
+    const bool arm = (fl_arm & 1u) != 0u || (fl_arm & 6u) == 4u;
     if (arm) {
         __syncthreads();                                          // (the arm's W stages overwrite the partials)
         // every compute wave recomputes the SAME 32 x 128 tile over all of K on the bf16 arm (its W staging wants all 512 compute threads;

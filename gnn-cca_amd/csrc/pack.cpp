@@ -647,6 +647,8 @@ static int pack_generic(const gnncca_mpn_dims* d, const float* const* params, vo
 
 namespace gnncca {
 
+// (The same invariant as carve()'s: flags / seg_ptr / col32 / perm of the generic family's workspace are read by gnncca_frames_forward's post
+// stage after the forward -- fused generic step, op-by-op form and L == 0 alike.)
 GenWorkspace carve_generic(const gnncca_mpn_dims* d, int64_t n, int64_t e) {
     GenWorkspace w;
     std::memset(&w, 0, sizeof(w));
@@ -763,6 +765,11 @@ int enc_lds_ksplit(int64_t n_nodes, int K) {
     return best;
 }
 
+// INVARIANT (gnncca_frames_forward, csrc/mpn_forward.hip): the plan regions -- flags, seg_ptr, col32, perm -- stay LIVE AND FINAL from the plan's
+// launch(es) until the forward returns: the post stage reads them from this workspace (found by carving it again) instead of building the
+// plan a second time.  Every forward route finishes that plan (the riding plan blocks + plan_finish in a tail / fused-epilogue workgroup, the
+// plan-only launch of big batches, L == 0), and no step kernel may reuse those regions.  tests/test_gpu_pipeline.py holds one pipeline call
+// against the separate calls on every route.
 Workspace carve(const gnncca_mpn_dims* d, int64_t n, int64_t e) {
     Workspace w;
     std::memset(&w, 0, sizeof(w));

@@ -76,6 +76,8 @@ __global__ __launch_bounds__(256) void post_prune_kernel(const long long* __rest
 // `triggers` (optional; zero on entry, with `sizes` [N_all]): this workgroup's frame sets bit 0 of its word when one of its nodes has
 // flow_out or flow_in > 3 (libs/utils.py:58-62: compute_rounding has work to do) and bit 1 when one of its clusters has more than four
 // members (libs/utils.py:321-322: disjoint_big_clusters has) -- the two conditions under which the host heuristics change the frame.
+// LABEL CONVENTION (relied on by the host pass: csrc/post_host.cpp counts the clusters the device chain found in a flagged frame as the nodes with
+// labels[v] == v, and writes its own results in the same form): a node's label is the SMALLEST batch-global node id of its component.
 __global__ __launch_bounds__(1024) void post_cc_kernel(const long long* __restrict__ ei, const long long* __restrict__ pred,
                                                        long long E_all, int N_all, const int* __restrict__ node_ptr,
                                                        const int* __restrict__ edge_ptr, int* labels, int* n_clusters,

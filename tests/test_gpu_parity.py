@@ -337,6 +337,40 @@ def test_fp16_split_gemm_range_guard(n_nodes, what):
         assert (np.abs(o - r64) / s).max() <= max(4 * (np.abs(r - r64) / s).max(), TOL_TIGHT * 2)
 
 
+@pytest.mark.parametrize("n_nodes", [301, 1229, 6144 + 9, 51200 + 33])
+def test_fp16_split_gemm_on_uniformly_tiny_inputs(n_nodes):
+    """below fp16's normal range (6.1e-5) the two fp16 pieces of an operand carry 2^-36 ABSOLUTE precision, so an input that is
+    tiny THROUGHOUT (un-normalised or rescaled features around 1e-6) would lose relative accuracy against an fp32 GEMM (1e-5 instead of
+    6e-8).  Round 6: a wave / workgroup whose largest |x| is below 2^-8 without being zero takes the range arm (kF16Tiny, csrc/internal.h).
+    x scaled by 1e-6 and both encoder biases zeroed, so that the encoder output is proportional to x: its error against an fp64 evaluation
+    RELATIVE to the row's magnitude must stay within 4x the fp32 oracle's own -- at every kernel of the family (slices, 32-row, 256-row)."""
+    params, arch, sd = _default_model(1.0)
+    sd = {k: np.array(v, copy=True) for k, v in sd.items()}
+    sd["encoder.node_mlp.fc_layers.0.bias"][:] = 0.0
+    sd["encoder.node_mlp.fc_layers.3.bias"][:] = 0.0
+    rng = np.random.default_rng(n_nodes)
+    x = rng.standard_normal((n_nodes, 2048)).astype(np.float32)
+    x /= np.linalg.norm(x, axis=0, keepdims=True)
+    x *= np.float32(1e-6)
+    src = np.repeat(np.arange(n_nodes), 2)
+    dst = (src + np.tile([1, 5], n_nodes)) % n_nodes
+    ei = np.stack([src, dst]).astype(np.int64)
+    ea = rng.random((ei.shape[1], 4)).astype(np.float32)
+    tr = {}
+    NumpyOracle(params, arch, sd, np.float32).forward(x, ei, ea, tr)
+    m = build(params, arch, sd)
+    trace = {}
+    with torch.no_grad():
+        m(Data(torch.from_numpy(x).cuda(), torch.from_numpy(ei).cuda(), torch.from_numpy(ea).cuda()), trace=trace)
+    h64 = NumpyOracle(params, arch, sd, np.float64)._mlp("encoder.node_mlp", x.astype(np.float64))
+    got = trace["h_enc"].cpu().numpy().astype(np.float64)
+    scale = np.abs(h64).max(axis=1, keepdims=True)
+    assert scale.min() > 0 and scale.max() < 1e-4          # the outputs ARE tiny: an absolute bound would say nothing
+    err_gpu = (np.abs(got - h64) / scale).max()
+    err_ref = (np.abs(tr["h_enc"] - h64) / scale).max()
+    assert err_gpu <= max(4 * err_ref, 4e-7), (err_gpu, err_ref)
+
+
 @pytest.mark.parametrize("n_nodes,products", [(4096 + 3, 6), (8192, 6), (8192 + 5, 6), (16384 + 77, 6), (30000, 6), (8192 + 5, 3)])
 def test_unsplit_32_row_encoder_vs_fp64_oracle(n_nodes, products):
     """`model.encoder_unsplit = True`: mid-size batches take the un-split 32-row split-bf16 GEMM with the fused epilogue

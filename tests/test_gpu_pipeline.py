@@ -171,3 +171,49 @@ def test_final_async_overlaps_batches_and_equals_the_synchronous_finalize():
     assert touched >= 10
     del pending, results, r, got, fin
     pipe.close()
+
+
+@pytest.mark.parametrize("route", ["generic_fused", "generic_op_by_op", "steps_L0", "max_aggregation", "reattach_both"])
+def test_one_call_equals_the_step_by_step_path_on_every_forward_route(route):
+    """gnncca_frames_forward hands the pruning the CSR plan the MPN forward left in ITS workspace (seg_ptr / col32 / perm / flags), found by
+    carving the workspace again -- an invariant every forward route has to keep (csrc/pack.cpp: carve / carve_generic).  One pipeline call
+    against the separate calls, bit for bit, on the routes beside the shipped shape's: the generic family's fused step (node latent 48) and
+    its op-by-op form (node latent 160), L = 0 (no step kernel at all), the general step kernel (max aggregation; both reattach flags)."""
+    from gnn_cca_amd import MOTMPNet
+    from gnn_cca_amd.pipeline import FramePipeline
+    import bench
+    params = copy.deepcopy(bench.graph_net_params(L=4))
+    if route == "generic_fused":
+        params["encoder_feats_dict"]["nodes"]["resnet50"]["node_out_dim"] = 48
+        params["node_model_feats_dict"]["fc_dims"] = [48]
+    elif route == "generic_op_by_op":
+        params["encoder_feats_dict"]["nodes"]["resnet50"]["node_out_dim"] = 160
+        params["node_model_feats_dict"]["fc_dims"] = [160]
+    elif route == "steps_L0":
+        params["num_enc_steps"], params["num_class_steps"] = 0, 1
+    elif route == "max_aggregation":
+        params["node_agg_fn"] = "max"
+    elif route == "reattach_both":
+        params["reattach_initial_nodes"] = params["reattach_initial_edges"] = True
+    torch.manual_seed(3)
+    m = MOTMPNet(copy.deepcopy(params), None, "resnet50")
+    with torch.no_grad():
+        for p in m.MPNet.node_model.node_mlp.parameters():
+            p.mul_(1.0 / 20)
+    m = m.cuda().eval()
+    rng = np.random.default_rng(5)
+    f = _frames(rng, 24)
+    node, reid = torch.from_numpy(f["node"]).cuda(), torch.from_numpy(f["reid"]).cuda()
+    ref = _stepwise(m, f, node, reid)
+    with torch.no_grad():   # centre the logits: pruning and clustering get work to do
+        sd = m.state_dict()
+        key = [k for k in sd if k.startswith("classifier.") and k.endswith(".bias")][-1]
+        sd[key] -= ref[1]["classified_edges"][-1].median()
+        m.load_state_dict(sd)
+    ref = _stepwise(m, f, node, reid)
+    pipe = FramePipeline(m)
+    for _ in range(2):
+        r = pipe(f["xw"], f["yw"], f["ids"], f["id_cam"], f["sizes"], f["max_dist"], node, reid)
+    torch.cuda.synchronize()
+    _same(r, ref)
+    assert 0 < int(r.pruned.sum().item()) < r.pruned.numel()
