@@ -60,6 +60,7 @@ class PendingFinal:
             st = nat.lib().gnncca_post_pool_wait_timed(self._pipe._pool_handle(), self._ticket, frames.ctypes.data, C.byref(count), times.ctypes.data)
             self.times_us = times      # submit -> picked up -> event complete -> last frame final -> collected
             self._keep = None      # the device buffers may go: everything is on the host now
+            self._pipe._outstanding -= 1
             if st:
                 nat.check(st, "gnncca_post_pool_wait")
             hn = host.numpy()
@@ -77,8 +78,10 @@ class PendingFinal:
 
     def __del__(self):
         try:
-            if self._res is None and self._ticket is not None:   # never collected: wait, or the pool would write into freed memory
-                nat.lib().gnncca_post_pool_wait(self._pipe._pool_handle(), self._ticket, None, None)
+            pool = self._pipe._pool
+            if self._res is None and self._ticket is not None and pool:   # never collected: wait, or the pool would write into freed memory
+                nat.lib().gnncca_post_pool_wait(pool, self._ticket, None, None)
+                self._pipe._outstanding -= 1
             self._pipe._give_back(self._host)
         except Exception:  # noqa: BLE001  (interpreter shutdown)
             pass
@@ -149,6 +152,7 @@ class FramePipeline:
         self._pool = None    # gnncca_post_pool (created on the first final_async)
         self._pinned = {}    # bytes (power of two) -> free pinned host buffers of that size
         self.host_threads = 0   # 0: the library's default (hardware threads - 2, at most 16)
+        self._outstanding = 0   # batches submitted to the pool and not yet collected
 
     def _pool_handle(self):
         if self._pool is None:
@@ -158,7 +162,9 @@ class FramePipeline:
         return self._pool
 
     def close(self):
-        """Stops the pool's threads (every PendingFinal must have been collected)."""
+        """Stops the pool's threads.  Every PendingFinal must have been collected (or dropped) first: a batch still on its way is refused."""
+        if self._outstanding > 0:
+            raise RuntimeError(f"{self._outstanding} batch(es) are still with the host pool: collect their PendingFinal.result() before close()")
         if self._pool is not None:
             nat.lib().gnncca_post_pool_destroy(self._pool)
             self._pool = None
@@ -201,6 +207,7 @@ class FramePipeline:
         if ticket < 0:
             self._give_back(host)
             nat.check(int(-ticket), "gnncca_post_pool_submit_copy")
+        self._outstanding += 1
         return PendingFinal(self, ticket, host, views, (r._keep, node_ptr, edge_ptr))
 
     def _slow(self, xw, yw, ids, id_cam, sizes, max_dist, node, reid):

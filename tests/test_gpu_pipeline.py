@@ -169,7 +169,12 @@ def test_final_async_overlaps_batches_and_equals_the_synchronous_finalize():
         # the device chain's own tensors are untouched by the host pass
         assert torch.equal(r.pruned, want["predictions"]) == (not got["frames_finalized"] or torch.equal(r.pruned, want["predictions"]))
     assert touched >= 10
-    del pending, results, r, got, fin
+    # close() refuses while a batch is still with the pool, and works once it has been collected
+    late = pipe(fs[1]["xw"], fs[1]["yw"], fs[1]["ids"], fs[1]["id_cam"], fs[1]["sizes"], fs[1]["max_dist"], *dev_in[1]).final_async()
+    with pytest.raises(RuntimeError):
+        pipe.close()
+    late.result()
+    del pending, results, r, got, fin, late
     pipe.close()
 
 
