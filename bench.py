@@ -767,8 +767,9 @@ def config_leg(nodes, L, edge_state, device, args, steps, cpu_budget_s=6.0, fuse
            "roofline": {"bound": "latency" if E * 2 * e_bytes < 32e6 else "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "avg_launch_us": step_us, "algorithmic_bytes_per_launch": alg,
                         "kernel": ("mpn_step_fast_kernel" if N <= 512 else "mpn_step_pipe_kernel") + ", mean over the L-1 message steps (HIP events per launch)",
-                        "note": ("edge state %.0f MB: beyond the 32 MB of L2 but inside the 256 MB Infinity Cache -- `frac` is algorithmic bytes / time / HBM "
-                                 "peak, a number to compare runs by, not this launch's bound (floor + a dependent chain)" % (E * e_bytes / 1e6))
+                        "note": ("a step reads and writes %.0f MB of edge state: beyond the 32 MB of L2 but inside the 256 MB Infinity Cache -- `frac` is "
+                                 "algorithmic bytes / time / HBM peak, a number to compare runs by, not this launch's bound (floor + a dependent chain)"
+                                 % (2 * E * e_bytes / 1e6))
                         if 32e6 <= E * 2 * e_bytes < 256e6 else ""},
            "kernels_us": {k: float(np.mean(v)) * 1e3 for k, v in kms.items()},
            "parity": {"max_abs_err": errs, "max_rel_err": max(errs) / max(scale, 1e-30), "max_abs_logit": scale, "tolerance_abs": 1e-4,
