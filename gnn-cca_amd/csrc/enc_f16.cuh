@@ -15,7 +15,7 @@ namespace gnncca {
 // is closer than an fp32 GEMM's: tools/time_encoder.py --check, tests/test_gpu_parity.py).  fp16 has a narrow exponent: a workgroup whose x
 // holds a finite magnitude >= 65520 (it would round to infinity), or any workgroup when a WEIGHT does (flag words written by the packers),
 // recomputes its tile on the bf16 six-product arm inside the same launch (`bf16_arm`: range of fp32, round 2's arithmetic); so does (round 6) a
-// workgroup whose LARGEST |x| is below 2^-8 without being zero (kF16Tiny: the pieces' 2^-36 absolute precision would show as relative error against
+// workgroup whose LARGEST |x| is below 2^-10 without being zero (kF16Tiny: the pieces' 2^-36 absolute precision would show as relative error against
 // an fp32 GEMM) -- no input makes this kernel wrong, unusual ones make it slower.
 //
 // DATA MOVEMENT.  256 rows x 128 columns per workgroup, 8 waves; wave w owns rows [32 w, 32 w + 32) and ALL 128 columns, so the x operand
@@ -363,8 +363,8 @@ __device__ __forceinline__ void enc_gemm_f16_body(const EncF16Params p, const En
     unsigned* s_flag = reinterpret_cast<unsigned*>(lds_raw);
     if (tid == 0) *s_flag = 0u;
     __syncthreads();
-    // bit 0: beyond fp16 (a NaN in x: the arm's business too); bit 1: somebody's |x| reaches 2^-8; bit 2: somebody's is not zero -- a tile
-    // whose largest |x| is below 2^-8 without being zero takes the arm too (kF16Tiny, internal.h)
+    // bit 0: beyond fp16 (a NaN in x: the arm's business too); bit 1: somebody's |x| reaches 2^-10; bit 2: somebody's is not zero -- a tile
+    // whose largest |x| is below 2^-10 without being zero takes the arm too (kF16Tiny, internal.h)
     {
         const unsigned f = ((!(amax < kF16Limit) || wbad != 0u || p.force_arm) ? 1u : 0u) | (amax >= kF16Tiny ? 2u : 0u) | (amax > 0.f ? 4u : 0u);
         if (f) atomicOr(s_flag, f);
@@ -626,7 +626,7 @@ __global__ __launch_bounds__(kF16R32Threads) void enc_gemm_f16_rows32_kernel(con
         }
     }
     __syncthreads();
-    {   // (bits as in the 256-row kernel: 0 beyond fp16, 1 somebody's |x| reaches 2^-8, 2 somebody's is not zero)
+    {   // (bits as in the 256-row kernel: 0 beyond fp16, 1 somebody's |x| reaches 2^-10, 2 somebody's is not zero)
         const unsigned f = ((!(amax < kF16Limit) || wbad != 0u || p.force_arm) ? 1u : 0u) | (amax >= kF16Tiny ? 2u : 0u) | (amax > 0.f ? 4u : 0u);
         if (f) atomicOr(s_flag, f);
     }

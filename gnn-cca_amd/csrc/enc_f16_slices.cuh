@@ -22,7 +22,7 @@ namespace gnncca {
 // (First version of the round: four waves per workgroup, operands straight from global memory into double-buffered registers, 140 VGPRs --
 // two groups of 32 k in flight made dense1024 a chain of four round trips per wave, 9.2 us, and the four column-tile waves read every x
 // line four times; docs/experiments_r06.md.)
-// RANGE.  fp16's exponent is narrow: a wave that meets a finite |x| >= 65520 in its operands, a wave whose largest |x| is below 2^-8 (kF16Tiny: the
+// RANGE.  fp16's exponent is narrow: a wave that meets a finite |x| >= 65520 in its operands, a wave whose largest |x| is below 2^-10 (kF16Tiny: the
 // pieces' 2^-36 absolute precision would show), or any wave when a weight is beyond fp16 (the packers' flag words), recomputes its own 32 x 32 partial tile as an exact-fp32 MFMA chain (v_mfma_f32_32x32x2_f32, the arithmetic of
 // enc_gemm_plan_kernel) -- no input makes this kernel wrong, unusual ones make it slower.  (Per WAVE, before the k-halves meet.)
 // ------------------------------------------------------------------------------------------------------------
@@ -126,7 +126,7 @@ __device__ __forceinline__ void enc_gemm_f16_slices_body(const EncF16SlicesParam
     for (int i = 0; i < 16; ++i) acc[i] = fmaf(accB[i], 1.0f / 2048.0f, accA[i]);
     // ---- the range arm, per wave: this wave's 32 x 32 partial tile again as an exact fp32 FMA chain (k-permuted operands as in gemm_tile:
     //      lane (r, h) feeds k = kc + 8 h + s at MFMA step s to both operands; 16 deep at a time) ---------------------------------------------
-    // ... or whose largest |x| is below 2^-8 without being zero (the pieces' absolute precision would show as relative error)
+    // ... or whose largest |x| is below 2^-10 without being zero (the pieces' absolute precision would show as relative error)
     const bool too_small = __builtin_amdgcn_ballot_w64(amax >= kF16Tiny) == 0ull && __builtin_amdgcn_ballot_w64(amax > 0.f) != 0ull;
     const bool out_of_range = too_small || __builtin_amdgcn_ballot_w64(!(amax < kF16Limit) || wbad != 0u) != 0ull;
     if (out_of_range || p.force_arm) {

@@ -59,10 +59,12 @@ struct BlobHeader {
 };
 constexpr int kW2hBadWords = 64;            // one per pack block (pack_device_kernel's grid is 64 wide): no atomics, nothing to reset
 constexpr float kF16Limit = 65520.0f;       // the smallest magnitude that fp16 round-to-nearest-even turns into infinity
-constexpr float kF16Tiny = 0.00390625f;      // 2^-8.  The fp16 pieces carry 2^-36 ABSOLUTE precision below fp16's normal range (6.1e-5): a tile whose
-                                            // LARGEST |x| is under this (and not zero) would lose relative accuracy against an fp32 GEMM
-                                            // (sqrt(K) 2^-36 / |x|: 1.7e-7 at 2^-8, 1e-5 at 1e-6), so it takes the range arm like a tile beyond
-                                            // 65520 does.  Column-normalised embeddings sit at 1 / sqrt(N): 3.9e-3 is N = 65 536.
+constexpr float kF16Tiny = 0.0009765625f;   // 2^-10.  The fp16 pieces carry 2^-36 ABSOLUTE precision below fp16's normal range (6.1e-5): per dot product
+                                            // sqrt(K) |w| 2^-36 ~ 1e-11 -- far below an fp32 ulp of the biased sum it feeds, but as RELATIVE error of
+                                            // the product alone sqrt(K) 2^-36 / |x| (2.5e-6 at a largest |x| of 2^-10, 1e-5 at 1e-6).  A tile whose
+                                            // LARGEST |x| is under this (and not zero) therefore takes the range arm like a tile beyond 65520 does
+                                            // (ADVICE r5).  Column-normalised embeddings sit at 1 / sqrt(N): a million-node batch still has tile
+                                            // maxima of 3.7e-3, so no ordinary input pays for the guard.
 
 // Layout of the `fast_consts` block (floats): the per-step scalars mpn_step_fast_kernel reads into SGPRs.
 // Present when edge_in == 4, no reattach flags and the classifier is Linear(6,4)+ReLU+Linear(4,1).

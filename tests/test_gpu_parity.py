@@ -341,7 +341,7 @@ def test_fp16_split_gemm_range_guard(n_nodes, what):
 def test_fp16_split_gemm_on_uniformly_tiny_inputs(n_nodes):
     """below fp16's normal range (6.1e-5) the two fp16 pieces of an operand carry 2^-36 ABSOLUTE precision, so an input that is
     tiny THROUGHOUT (un-normalised or rescaled features around 1e-6) would lose relative accuracy against an fp32 GEMM (1e-5 instead of
-    6e-8).  Round 6: a wave / workgroup whose largest |x| is below 2^-8 without being zero takes the range arm (kF16Tiny, csrc/internal.h).
+    6e-8).  Round 6: a wave / workgroup whose largest |x| is below 2^-10 without being zero takes the range arm (kF16Tiny, csrc/internal.h).
     x scaled by 1e-6 and both encoder biases zeroed, so that the encoder output is proportional to x: its error against an fp64 evaluation
     RELATIVE to the row's magnitude must stay within 4x the fp32 oracle's own -- at every kernel of the family (slices, 32-row, 256-row)."""
     params, arch, sd = _default_model(1.0)
