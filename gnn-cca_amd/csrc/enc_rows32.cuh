@@ -25,7 +25,7 @@ namespace gnncca {
 // 41 us at N = 8192 (split-K + tail: 31 / 38), 76-84 us at N = 16 384.  At N <= 8192 there is ONE wave per SIMD and one dependent
 // accumulation chain per wave: with every load, LDS access and conversion removed the 768 MFMAs alone take 24 us (timing-only
 // ablation) -- a lone wave retires a v_mfma_f32_32x32x16_bf16 per 32 cycles where two / four waves on a SIMD get 24 / 20
-// (tools/ubench_mfma_chain.hip), at the ~1.3 GHz the chip sustains under this load -- and nothing hides its own waits: the W
+// (tools/archive/ubench_mfma_chain.hip), at the ~1.3 GHz the chip sustains under this load -- and nothing hides its own waits: the W
 // fragments (every workgroup streams all 1.5 MB of pieces from L2, 515 MB of L2 requests per launch at N = 8192, 84 % hits) cost
 // 7.5 us, x and its conversion 3.5 us.  A bare sweep of a 1.5 MB L2-resident table reaches 106-135 GB/s per CU
 // (tools/ubench_l2_per_cu.hip: 64 B/clk, the L1's width), this kernel 42-50; reading the pieces in a fragment-ordered 1 KB-contiguous

@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void plan_only_kernel(const EncPlanParams p) {
 // Every product of two bf16 values is exact in fp32 and the MFMA accumulates in fp32: measured against fp64 the
 // result is MORE accurate than an fp32 GEMM (1.9e-9 vs 1.4e-7 on the N=64 golden case), while the six
 // v_mfma_f32_32x32x16_bf16 cost 6/16 of the v_mfma_f32_32x32x2_f32 time.  (Keeping only x0w0 + x0w1 + x1w0 would
-// halve the MFMA work again -- GNNCCA_OPT_ENC_SPLIT3, off by default.  Measured (tools/exp_enc_products.py, x ~ N(0,1),
+// halve the MFMA work again -- GNNCCA_OPT_ENC_SPLIT3, off by default.  Measured (tools/archive/exp_enc_products.py, x ~ N(0,1),
 // N = 8 192 / 51 233): encoder output 5.0e-6 / 5.5e-6 from an fp64 evaluation instead of 3.0e-7 / 9.9e-7 (an fp32 GEMM:
 // 4.9e-7 / 5.7e-7), logits 0.9e-7 / 1.5e-7 from the fp32 oracle instead of 0.6e-7 (tolerance 1e-4); GEMM 30.8 -> 22.3 us at
 // N = 8 192, 57.7 -> 44.7 at 16 384, 225 -> 183 at 65 536.)

@@ -273,7 +273,7 @@ class GraphedForward:
                 depth = max(1, int(depth))
                 # groups of <= `depth` consecutive frames, their number a multiple of S and their sizes within one frame of each other, so
                 # that every stream carries the same number of frames (20 frames, depth 2, S = 3: 7 / 7 / 6 frames per stream; plain groups
-                # of two gave 8 / 6 / 6).  Measured at K = 20 (tools/chains_sweep.py 20): 19.7-20.7 us per forward for every depth from 1 to
+                # of two gave 8 / 6 / 6).  Measured at K = 20 (tools/archive/chains_sweep.py 20): 19.7-20.7 us per forward for every depth from 1 to
                 # 7 -- a short block is bound by its fixed costs (fork, three staggered first launches, join: ~70 us), not by the cut)
                 k = len(inputs)
                 n_groups = min(k, chains * -(-k // (chains * depth)))
