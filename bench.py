@@ -366,6 +366,7 @@ def flat_evidence(res):
         put(c, "terrace_final_frames_per_s", fin.get("frames_per_s"))
         put(c, "terrace_final_overlapped_ms_per_batch", fin.get("overlapped_ms_per_batch"))
         put(c, "terrace_final_overlapped_frames_per_s", fin.get("overlapped_frames_per_s"))
+        put(c, "terrace_final_over_chain", tp.get("final_over_chain"))
         put(c, "terrace_flagged_per_batch", fin.get("frames_through_the_host_heuristics_per_batch"))
         put(c, "terrace_parity_ok", (tp.get("parity") or {}).get("ok"))
     tr = res.get("train_step")
@@ -686,6 +687,8 @@ def terrace_leg(device, args, batch=64, n_batches=16, cpu_budget_s=12.0):
                         "postprocess.prune_and_cluster (+ trigger words) as ONE native call per batch (gnncca_frames_forward), host planning "
                         "and H2D of the per-detection arrays included; `stage_ms_per_batch_synchronised` times the separate functions",
             "ms_per_batch": dt / n_done * 1e3, "frames_per_s": batch * n_done / dt, "edges_per_s": edges / dt,
+            # the pipeline's rate WITH the reference's final partitions (final_async, overlapped) and its cost over the chain alone (target <= 1.5)
+            "final_frames_per_s": batch * done_o / dt_over, "final_over_chain": (dt_over / done_o) / (dt / n_done),
             "with_rounding_and_splitting": {"ms_per_batch": dt_final / n_batches * 1e3, "frames_per_s": batch * n_batches / dt_final,
                                             "frames_through_the_host_heuristics_per_batch": flagged / n_batches,
                                             "overlapped_ms_per_batch": dt_over / done_o * 1e3, "overlapped_frames_per_s": batch * done_o / dt_over,

@@ -25,7 +25,7 @@ def test_flat_evidence_keys_and_string_lengths():
                              "ms_per_step_graph": 0.088, "projected_8gpu_speedup_eager": 5.7, "enc_frac": 0.32, "step_frac": 0.5, "forward_frac": 0.42,
                              "kernels_us": {"plan": 6.9, "enc_gemm": 26.0}},
            "roofline_at_scale": {"frac": 0.6, "avg_launch_us": 45.0},
-           "terrace_pipeline": {"ms_per_batch": 0.12, "frames_per_s": 5e5, "parity": {"ok": True},
+           "terrace_pipeline": {"ms_per_batch": 0.12, "frames_per_s": 5e5, "final_over_chain": 1.4, "parity": {"ok": True},
                                 "with_rounding_and_splitting": {"ms_per_batch": 0.6, "frames_per_s": 1e5, "overlapped_ms_per_batch": 0.17,
                                                                 "overlapped_frames_per_s": 3.8e5, "frames_through_the_host_heuristics_per_batch": 58.4}},
            "train_step": {"ms_per_iteration": 0.43, "parity": {"grad_max_abs_err": 5e-8, "ok": True}},
@@ -36,7 +36,7 @@ def test_flat_evidence_keys_and_string_lengths():
     out = bench.flat_evidence(res)
     c, r = out["config"], out["roofline"]
     for key, want in {"share_ms": 0.084, "union_ms": 0.48, "projected_8gpu_speedup": 5.7, "cfg4_ms": 0.48, "cfg4_ms_graph": 0.49, "terrace_ms_per_batch": 0.12,
-                      "terrace_final_ms_per_batch": 0.6, "terrace_final_overlapped_ms_per_batch": 0.17, "train_ms_per_iteration": 0.43, "cfg2_ms": 0.024,
+                      "terrace_final_ms_per_batch": 0.6, "terrace_final_over_chain": 1.4, "terrace_final_overlapped_ms_per_batch": 0.17, "train_ms_per_iteration": 0.43, "cfg2_ms": 0.024,
                       "cfg2_err": 6e-8, "headline_err": 3e-8, "dynrange_max_abs_logit": 79.4, "ms_eager": 0.03, "ms_graph_block": 0.027}.items():
         assert c[key] == want, key
     for key, want in {"cfg4_step_frac": 0.64, "cfg4_enc_frac": 0.5, "cfg4_enc_us": 135.0, "share_enc_frac": 0.32, "share_plan_us": 6.9, "at_scale_frac": 0.6,
