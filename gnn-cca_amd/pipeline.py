@@ -115,10 +115,15 @@ class FrameResult:
                 if not res["frames_finalized"]:      # nothing changed: the device chain's tensors ARE the final result
                     self._final = {"predictions": self.pruned, "labels": self.labels, "n_clusters": self.n_clusters,
                                    "frames_finalized": [], "triggers": res["triggers"]}
-                else:
-                    self._final = {"predictions": torch.from_numpy(res["predictions"]).to(dev, non_blocking=True),
-                                   "labels": torch.from_numpy(res["labels"]).to(dev, non_blocking=True),
-                                   "n_clusters": torch.tensor([res["n_clusters"]], dtype=torch.int32, device=dev),
+                else:   # upload from the PINNED buffer itself (torch views of it: truly asynchronous copies on the current stream, which is also
+                    #        the stream the next batch's D2H into a recycled buffer would be ordered behind; pageable uploads: 0.59-0.64 -> 0.48-0.49 ms
+                    #        per batch, same box)
+                    host, start, off, n, e, _g = self._pending._views
+                    pv = host[off["pruned"] - start:off["pruned"] - start + 8 * e].view(torch.int64)
+                    lv = host[off["labels"] - start:off["labels"] - start + 4 * n].view(torch.int32)
+                    kv = host[off["n_clusters"] - start:off["n_clusters"] - start + 4].view(torch.int32)
+                    self._final = {"predictions": pv.to(dev, non_blocking=True), "labels": lv.to(dev, non_blocking=True),
+                                   "n_clusters": kv.to(dev, non_blocking=True),
                                    "frames_finalized": res["frames_finalized"], "triggers": res["triggers"]}
         return self._final
 
