@@ -662,6 +662,7 @@ void gnncca_post_pool_destroy(gnncca_post_pool* pool) {
 
 static bool batch_ok(const gnncca_post_batch* batch) {
     if (!batch || batch->n_frames < 0) return false;
+    if (batch->n_clusters && !batch->labels) return false;   // the final count is the device chain's count corrected by the flagged frames' labels
     return batch->n_frames == 0 || (batch->node_ptr && batch->edge_ptr && batch->triggers && batch->src && batch->dst && batch->probs && batch->predictions);
 }
 

@@ -311,7 +311,8 @@ GNNCCA_API int gnncca_post_prune_cluster_frames_ex(const int64_t* edge_index, co
  * [E] in: the thresholded (or already pruned) 0 / 1 predictions, out: the final ones.  labels_out [n_nodes] (optional) = smallest
  * batch-global node id of the node's final cluster, *n_clusters_out (optional) = number of final clusters, id_pred_out [n_nodes]
  * (optional) = the reference's ID_pred, its label NUMBERING included (networkx's generation order: see csrc/post_host.cpp).
- * Frames are processed one at a time as the reference does (validation batch size 1, main.py:368). */
+ * Frames are processed one at a time as the reference does (validation batch size 1, main.py:368).  Predictions other than 0 / 1 (inference.py:291
+ * thresholds to exactly those) are GNNCCA_ERR_INVALID_ARG since round 6. */
 #define GNNCCA_POST_ROUNDING 1
 #define GNNCCA_POST_PRUNING 2
 #define GNNCCA_POST_SPLITTING 4
@@ -336,7 +337,8 @@ GNNCCA_API int gnncca_post_finalize_frames_host(const int64_t* src, const int64_
  * trigger word meets the switches and the pool's threads finalize them (gnncca_post_finalize_frame_host per frame; no allocation per
  * frame).  gnncca_post_pool_submit returns a ticket >= 0 (or -status); gnncca_post_pool_wait blocks until that batch is final, writes
  * the finalized frame ids to frames_out [<= G] / their number to *n_frames_out (either may be null), releases the ticket and returns
- * the first non-zero status of any frame.  The buffers must stay valid until the wait returns.  n_threads 0 = hardware threads - 2,
+ * the first non-zero status of any frame.  The buffers must stay valid until the wait returns; `n_clusters` needs `labels` (the correction counts the
+ * flagged frames' components in them).  n_threads 0 = hardware threads - 2,
  * at most 16. */
 typedef struct gnncca_post_pool gnncca_post_pool;
 typedef struct gnncca_post_batch {
