@@ -158,7 +158,7 @@ static int forward_impl(const gnncca_mpn_dims* d, const void* packed_dev, const 
         static const int slices_min = diag_env_int("GNNCCA_GEMM_SLICES_MIN", 1, 0, 0x7FFFFFFF);
         static const int slices_max = diag_env_int("GNNCCA_GEMM_SLICES_MAX", 4095, 0, 0x7FFFFFFF);
         static const bool slices_bf16 = diag_env("GNNCCA_GEMM_BF16") != nullptr;
-        const bool use_slices = g == 0 && hdr.enc_w2h != 0 && O == 128 && K >= 64 && (K & (K - 1)) == 0 && K / kF16SlMaxKs <= ws.ksplit && N >= slices_min && N <= slices_max && N < 4096 && !split3 &&
+        const bool use_slices = g == 0 && hdr.enc_w2h != 0 && O == 128 && K >= 64 && (K & (K - 1)) == 0 && K / kF16SlMaxKs <= ws.ksplit && N >= slices_min && N <= slices_max && !split3 &&
                                 !slices_bf16 && (options & GNNCCA_OPT_ENC_UNSPLIT) == 0 && (reinterpret_cast<uintptr_t>(cur_in) & 15) == 0;
         const bool split = !use_slices && g == 0 && hdr.enc_w3 != 0 && N >= split_min && (reinterpret_cast<uintptr_t>(cur_in) & 15) == 0;
         EncPlanParams ep;
